@@ -1,0 +1,99 @@
+"""ctypes binding of the C-ABI in include/quadrotor_hip.h (libquadrotor_hip.so).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C gym_rotor_amd/csrc`.
+There is deliberately NO fallback: if the shared library is missing or a symbol is absent
+the import of the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libquadrotor_hip.so")
+
+KIND_QUAD, KIND_COUPLED, KIND_DECOUPLED = 0, 1, 2
+KIND_ID = {"quad": KIND_QUAD, "coupled": KIND_COUPLED, "decoupled": KIND_DECOUPLED}
+FLAG_AUTO_RESET, FLAG_EVAL_RESET, FLAG_NO_UDM = 1, 2, 4
+ABI_VERSION = 1
+
+ERRORS = {-1: "QR_E_NULL: a required pointer is NULL", -2: "QR_E_KIND: bad env kind",
+          -3: "QR_E_SIZE: bad num_envs / substeps / n_steps", -4: "QR_E_ALIGN: buffer not 16-byte aligned"}
+
+# every symbol include/quadrotor_hip.h declares
+SYMBOLS = ("qr_step", "qr_rollout", "qr_error_obs", "qr_reset", "qr_default_coeffs", "qr_abi_version",
+           "qr_step_kernel_info")
+
+
+class QrCoeffs(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "Cx", "CIx", "Cv", "Cb1", "CIb1", "CW", "Cw12", "CW3", "alpha", "beta", "dt",
+        "x_lim", "v_lim", "W_lim", "eIx_lim", "eIb1_lim", "euler_lim_deg", "udm_fraction")]
+
+
+class QrEnv(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("state_f64", C.c_int32), ("num_envs", C.c_int64),
+                ("env_offset", C.c_int64), ("seed", C.c_uint64),
+                ("state", C.c_void_p), ("integ", C.c_void_p), ("params", C.c_void_p), ("goal", C.c_void_p),
+                ("episode", C.c_void_p), ("steps", C.c_void_p),
+                ("max_episode_steps", C.c_int32), ("flags", C.c_uint32), ("coeffs", QrCoeffs)]
+
+
+class QrStepOut(C.Structure):
+    _fields_ = [("obs0", C.c_void_p), ("obs1", C.c_void_p), ("reward", C.c_void_p),
+                ("reward_raw", C.c_void_p), ("done", C.c_void_p), ("truncated", C.c_void_p)]
+
+
+class QuadrotorLibError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libquadrotor_hip.so (once) and type its entry points.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QuadrotorLibError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C gym_rotor_amd/csrc`.  gym_rotor_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for s in SYMBOLS:
+        if not hasattr(lib, s):
+            raise QuadrotorLibError(f"{LIB_PATH} does not export {s}")
+    P = C.POINTER
+    lib.qr_abi_version.restype = C.c_int
+    lib.qr_abi_version.argtypes = []
+    lib.qr_default_coeffs.restype = None
+    lib.qr_default_coeffs.argtypes = [P(QrCoeffs)]
+    lib.qr_step.restype = C.c_int
+    lib.qr_step.argtypes = [P(QrEnv), C.c_void_p, C.c_int32, P(QrStepOut), C.c_void_p]
+    lib.qr_rollout.restype = C.c_int
+    lib.qr_rollout.argtypes = [P(QrEnv), C.c_void_p, C.c_int32, C.c_int32, P(QrStepOut), C.c_void_p]
+    lib.qr_error_obs.restype = C.c_int
+    lib.qr_error_obs.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.qr_reset.restype = C.c_int
+    lib.qr_reset.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p]
+    lib.qr_step_kernel_info.restype = C.c_char_p
+    lib.qr_step_kernel_info.argtypes = [C.c_int32, C.c_int32, C.c_int64, P(C.c_int32), P(C.c_int32)]
+    if lib.qr_abi_version() != ABI_VERSION:
+        raise QuadrotorLibError(f"ABI mismatch: library {lib.qr_abi_version()} vs binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def default_coeffs() -> QrCoeffs:
+    c = QrCoeffs()
+    load().qr_default_coeffs(C.byref(c))
+    return c
+
+
+def check(rc: int, what: str):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise ValueError(f"{what}: {ERRORS.get(rc, rc)}")
+    raise QuadrotorLibError(f"{what}: hipError_t {rc}")

@@ -1,0 +1,305 @@
+"""QuadVecEnv — N independent quadrotors stepped by one fused HIP launch on an MI355X.
+
+Host-side mirror of the reference's env interface for the env.step() hot path
+(QuadEnv / CoupledWrapper / DecoupledWrapper: gym_rotor/envs/quad.py:142-466,
+gym_rotor/wrappers/{coupled,decoupled}_yaw_wrapper.py).  Same method names and argument
+meaning, batched over a leading env axis:
+
+    step(actions[N,A]) -> (obs, reward[N,n_agents], terminated[N,n_agents], truncated[N], info)
+    reset(env_type='train'|'eval', seed=None, options=None, mask=None) -> float32 state [N,18]
+    set_goal_state(xd, vd, b1d, b1d_dot, Wd); get_norm_error_state(framework=None)
+    get_current_state(); close()
+
+All tensors live on the GPU; `step` performs no host synchronisation.  The arithmetic is
+done ONLY by libquadrotor_hip.so (include/quadrotor_hip.h) — there is no torch/NumPy
+fallback, and constructing the env without the library or without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .constants import ACTION_DIM, FRAMEWORK, KINDS, N_AGENTS, OBS_DIMS, QuadConstants
+from .spaces import Box
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class QuadVecEnv:
+    """Batched Quad-v0 / CoupledWrapper / DecoupledWrapper.
+
+    kind            'quad' | 'coupled' | 'decoupled'  (MONO: coupled, MODUL: decoupled)
+    num_envs        N envs owned by this object (this GPU's shard)
+    substeps        fixed RK4 substeps per env-step replacing solve_ivp(DOP853) (quad.py:265)
+    state_dtype     torch.float64 (default; parity mode) or torch.float32
+    use_UDM         per-env domain randomisation at reset (quad.py:359-404)
+    auto_reset      re-sample terminated/truncated envs inside the step launch; the returned
+                    observation is then the first observation of the new episode
+    max_episode_steps  >0 sets truncated when an episode reaches that many steps
+    env_offset      global index of local env 0 (multi-GPU sharding; part of the RNG key)
+    """
+
+    metadata = {"render_modes": []}
+
+    def __init__(self, kind: str = "decoupled", num_envs: int = 1, device="cuda", seed: int = 0,
+                 substeps: int = 2, state_dtype: torch.dtype = torch.float64, use_UDM: bool = True,
+                 UDM_percentage: float = 10.0, auto_reset: bool = False, max_episode_steps: int = 0,
+                 env_offset: int = 0, want_raw_reward: bool = False, constants: Optional[QuadConstants] = None):
+        if kind not in KINDS:
+            raise ValueError(f"kind must be one of {KINDS}, got {kind!r}")
+        if num_envs < 1:
+            raise ValueError("num_envs must be >= 1")
+        if substeps < 1:
+            raise ValueError("substeps must be >= 1")
+        if state_dtype not in (torch.float64, torch.float32):
+            raise ValueError("state_dtype must be torch.float64 or torch.float32")
+        self._lib = _lib.load()  # raises if the HIP library is missing
+        if not torch.cuda.is_available():
+            raise RuntimeError("QuadVecEnv needs an AMD GPU (torch.cuda.is_available() is False); "
+                               "gym_rotor_amd has no CPU execution path")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("device must be a cuda (ROCm) device")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.kind, self.num_envs, self.substeps = kind, int(num_envs), int(substeps)
+        self.framework = FRAMEWORK[kind]
+        self.n_agents, self.action_dim, self.obs_dims = N_AGENTS[kind], ACTION_DIM[kind], OBS_DIMS[kind]
+        self.state_dtype = state_dtype
+        self.use_UDM, self.UDM_percentage = bool(use_UDM), float(UDM_percentage)
+        self.auto_reset, self.max_episode_steps = bool(auto_reset), int(max_episode_steps)
+        self.env_offset, self.seed = int(env_offset), int(seed)
+        c = self.constants = constants or QuadConstants(UDM_percentage=UDM_percentage)
+
+        # ---- attributes the reference's callers read (trajectory_generator.py:44-46,
+        #      policy_regularization.py:31-41, draw_plot.py:37,51-71, main.py:68-73) ----
+        self.dt, self.freq, self.g = c.dt, c.freq, c.g
+        self.x_lim, self.v_lim, self.W_lim, self.euler_lim = c.x_lim, c.v_lim, c.W_lim, c.euler_lim
+        self.eIx_lim, self.eIb1_lim, self.sat_sigma = c.eIx_lim, c.eIb1_lim, c.sat_sigma
+        self.alpha, self.beta = c.alpha, c.beta
+        self.m_nominal, self.d_nominal, self.J_nominal = c.m_nominal, c.d_nominal, c.J_nominal
+        self.c_tf_nominal, self.c_tw_nominal = c.c_tf_nominal, c.c_tw_nominal
+        self.hover_force, self.min_force, self.max_force = c.hover_force, c.min_force, c.max_force
+        self.avrg_act, self.scale_act = c.avrg_act, c.scale_act
+        self.forces_to_fM = c.forces_to_fM
+        self.fM_to_forces = np.linalg.inv(self.forces_to_fM)
+        self.reward_min, self.reward_min_1, self.reward_min_2 = c.reward_min, c.reward_min_1, c.reward_min_2
+        self.reward_crash = c.reward_crash
+        self.e1, self.e2, self.e3 = np.eye(3)
+        low = np.concatenate([-c.x_lim * np.ones(3), -c.v_lim * np.ones(3), -np.ones(9), -c.W_lim * np.ones(3)])
+        self.single_observation_space = Box(low.astype(np.float32), (-low).astype(np.float32), dtype=np.float32)
+        self.single_action_space = Box(-1.0, 1.0, shape=(self.action_dim,), dtype=np.float32)
+        self.observation_space, self.action_space = self.single_observation_space, self.single_action_space
+
+        # ---- device buffers (SoA [field][N]) ----
+        N, dev = self.num_envs, self.device
+        self._state = torch.zeros(18, N, dtype=state_dtype, device=dev)
+        self._state[6].fill_(1.0); self._state[10].fill_(1.0); self._state[14].fill_(1.0)
+        self._integ = None if kind == "quad" else torch.zeros(8, N, dtype=torch.float32, device=dev)
+        self._params = None
+        if self.use_UDM:
+            self._params = torch.tensor(c.nominal_params, dtype=torch.float32, device=dev)[:, None].repeat(1, N).contiguous()
+        self._goal = None  # default hover goal until set_goal_state is called (quad.py:98-101)
+        self._episode = torch.zeros(N, dtype=torch.int32, device=dev)
+        self._steps = torch.zeros(N, dtype=torch.int32, device=dev)
+        # caller-facing rows
+        self._obs0 = torch.empty(N, self.obs_dims[0], dtype=torch.float32, device=dev)
+        self._obs1 = torch.empty(N, self.obs_dims[1], dtype=torch.float32, device=dev) if len(self.obs_dims) > 1 else None
+        self._reward = torch.empty(N, self.n_agents, dtype=torch.float32, device=dev)
+        self._reward_raw = torch.empty(N, self.n_agents, dtype=torch.float32, device=dev) if want_raw_reward else None
+        self._done = torch.zeros(N, self.n_agents, dtype=torch.bool, device=dev)
+        self._trunc = torch.zeros(N, dtype=torch.bool, device=dev)
+
+        # ---- C structs (pointers refreshed lazily) ----
+        self._cenv = _lib.QrEnv()
+        self._cout = _lib.QrStepOut()
+        co = _lib.default_coeffs()
+        for name in ("Cx", "CIx", "Cv", "Cb1", "CIb1", "Cw12", "CW3", "alpha", "beta", "x_lim", "v_lim", "W_lim",
+                     "eIx_lim", "eIb1_lim"):
+            setattr(co, name, float(getattr(c, name)))
+        co.CW, co.dt, co.euler_lim_deg, co.udm_fraction = c.CW, c.dt, c.euler_lim, self.UDM_percentage / 100.0
+        self._cenv.coeffs = co
+        self._sync_structs()
+        self._closed = False
+
+    # ------------------------------------------------------------------------------
+    def _sync_structs(self):
+        e, o = self._cenv, self._cout
+        e.kind, e.state_f64 = _lib.KIND_ID[self.kind], int(self.state_dtype == torch.float64)
+        e.num_envs, e.env_offset, e.seed = self.num_envs, self.env_offset, self.seed & (2 ** 64 - 1)
+        e.state, e.integ, e.params, e.goal = _ptr(self._state), _ptr(self._integ), _ptr(self._params), _ptr(self._goal)
+        e.episode, e.steps = _ptr(self._episode), _ptr(self._steps)
+        e.max_episode_steps = self.max_episode_steps
+        e.flags = (_lib.FLAG_AUTO_RESET if self.auto_reset else 0) | (0 if self.use_UDM else _lib.FLAG_NO_UDM)
+        o.obs0, o.obs1, o.reward, o.reward_raw = _ptr(self._obs0), _ptr(self._obs1), _ptr(self._reward), _ptr(self._reward_raw)
+        o.done, o.truncated = _ptr(self._done), _ptr(self._trunc)
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _check_actions(self, actions: torch.Tensor, lead=()):
+        want = tuple(lead) + (self.num_envs, self.action_dim)
+        if not isinstance(actions, torch.Tensor):
+            raise TypeError("actions must be a torch.Tensor on the env's device")
+        if actions.device != self.device:
+            raise ValueError(f"actions on {actions.device}, env on {self.device}")
+        if actions.dtype != torch.float32:
+            raise TypeError(f"actions must be float32, got {actions.dtype}")
+        if tuple(actions.shape) != want:
+            raise ValueError(f"actions shape {tuple(actions.shape)} != {want}")
+        return actions if actions.is_contiguous() else actions.contiguous()
+
+    def _obs(self):
+        return self._obs0 if self._obs1 is None else (self._obs0, self._obs1)
+
+    # ------------------------------------------------------------------------------
+    def step(self, actions: torch.Tensor):
+        """QuadEnv.step (quad.py:142-168) for all envs.  Returned tensors are the env's
+        output buffers: valid until the next step()/rollout() call."""
+        a = self._check_actions(actions)
+        rc = self._lib.qr_step(C.byref(self._cenv), a.data_ptr(), self.substeps, C.byref(self._cout), self._stream())
+        _lib.check(rc, "qr_step")
+        return self._obs(), self._reward, self._done, self._trunc, {}
+
+    def rollout(self, actions: torch.Tensor, out: Optional[dict] = None):
+        """T env-steps in one launch (state stays in registers).  actions [T,N,A].
+        Returns dict(obs, reward[T,N,n_agents], terminated, truncated[T,N])."""
+        if actions.dim() != 3:
+            raise ValueError("rollout actions must be [T, N, A]")
+        T = actions.shape[0]
+        a = self._check_actions(actions, lead=(T,))
+        N, dev = self.num_envs, self.device
+        if out is None:
+            out = {"obs0": torch.empty(T, N, self.obs_dims[0], dtype=torch.float32, device=dev),
+                   "reward": torch.empty(T, N, self.n_agents, dtype=torch.float32, device=dev),
+                   "terminated": torch.zeros(T, N, self.n_agents, dtype=torch.bool, device=dev),
+                   "truncated": torch.zeros(T, N, dtype=torch.bool, device=dev)}
+            if self._obs1 is not None:
+                out["obs1"] = torch.empty(T, N, self.obs_dims[1], dtype=torch.float32, device=dev)
+        o = _lib.QrStepOut()
+        o.obs0, o.obs1, o.reward = _ptr(out["obs0"]), _ptr(out.get("obs1")), _ptr(out["reward"])
+        o.reward_raw, o.done, o.truncated = _ptr(out.get("reward_raw")), _ptr(out["terminated"]), _ptr(out["truncated"])
+        rc = self._lib.qr_rollout(C.byref(self._cenv), a.data_ptr(), T, self.substeps, C.byref(o), self._stream())
+        _lib.check(rc, "qr_rollout")
+        out["obs"] = out["obs0"] if self._obs1 is None else (out["obs0"], out["obs1"])
+        return out
+
+    def reset(self, env_type: str = "train", seed: Optional[int] = None, options: Optional[dict] = None,
+              mask: Optional[torch.Tensor] = None):
+        """QuadEnv.reset (quad.py:171-222): new parameters (train + use_UDM), initial error
+        state, zero integrators, for envs where mask is True (default all).  Returns the
+        float32 state [N,18] like the reference; callers then set the goal and call
+        get_norm_error_state() for the first observation (main.py:126-129)."""
+        if env_type not in ("train", "eval"):
+            raise ValueError("env_type must be 'train' or 'eval'")
+        if seed is not None:
+            self.seed = int(seed)
+            self._cenv.seed = self.seed & (2 ** 64 - 1)
+        m = None
+        if mask is not None:
+            if mask.shape != (self.num_envs,) or mask.device != self.device:
+                raise ValueError("mask must be a [num_envs] tensor on the env's device")
+            m = mask.to(torch.uint8) if mask.dtype != torch.uint8 else mask
+            m = m.contiguous()
+        flags = self._cenv.flags
+        self._cenv.flags = (flags & ~(_lib.FLAG_EVAL_RESET | _lib.FLAG_AUTO_RESET)) | (_lib.FLAG_EVAL_RESET if env_type == "eval" else 0)
+        try:
+            rc = self._lib.qr_reset(C.byref(self._cenv), _ptr(m), self._stream())
+        finally:
+            self._cenv.flags = flags
+        _lib.check(rc, "qr_reset")
+        return self._state.t().to(torch.float32)
+
+    def get_norm_error_state(self, framework: Optional[str] = None):
+        """quad.py:421-466.  Advances the integral terms (same side effect as the reference)."""
+        if self.kind == "quad":
+            raise RuntimeError("get_norm_error_state is defined for kind 'coupled'/'decoupled'")
+        if framework is not None and framework != self.framework:
+            raise ValueError(f"env kind {self.kind!r} produces {self.framework} observations, not {framework}")
+        rc = self._lib.qr_error_obs(C.byref(self._cenv), _ptr(self._obs0), _ptr(self._obs1), self._stream())
+        _lib.check(rc, "qr_error_obs")
+        return [self._obs0] if self._obs1 is None else [self._obs0, self._obs1]
+
+    # ------------------------------------------------------------------------------
+    def _rows3(self, v, name):
+        t = torch.as_tensor(v, dtype=torch.float32, device=self.device)
+        if t.shape == (3,):
+            t = t.expand(self.num_envs, 3)
+        if tuple(t.shape) != (self.num_envs, 3):
+            raise ValueError(f"{name} must have shape (3,) or ({self.num_envs}, 3)")
+        return t.t()
+
+    def set_goal_state(self, xd, vd, b1d, b1d_dot=None, Wd=None):
+        """quad.py:413-418.  b1d_dot is accepted and ignored (unused by the step path)."""
+        if self._goal is None:
+            self._goal = torch.zeros(12, self.num_envs, dtype=torch.float32, device=self.device)
+            self._cenv.goal = self._goal.data_ptr()
+        self._goal[0:3] = self._rows3(xd, "xd")
+        self._goal[3:6] = self._rows3(vd, "vd")
+        self._goal[6:9] = self._rows3(b1d, "b1d")
+        self._goal[9:12] = self._rows3(np.zeros(3) if Wd is None else Wd, "Wd")
+
+    def get_current_state(self) -> torch.Tensor:
+        """quad.py:409-410: the internal state, [N,18] view (x, v, vec_F(R), W)."""
+        return self._state.t()
+
+    def set_state(self, state, integ=None, params=None):
+        """Inject states (and optionally integrator terms / parameters): [N,18] / [N,8] / [N,6]."""
+        s = torch.as_tensor(state, device=self.device).to(self.state_dtype)
+        if tuple(s.shape) != (self.num_envs, 18):
+            raise ValueError(f"state must be [{self.num_envs}, 18]")
+        self._state.copy_(s.t())
+        if integ is not None and self._integ is not None:
+            self._integ.copy_(torch.as_tensor(integ, device=self.device).to(torch.float32).t())
+        if params is not None:
+            if self._params is None:
+                self._params = torch.empty(6, self.num_envs, dtype=torch.float32, device=self.device)
+                self._cenv.params = self._params.data_ptr()
+            self._params.copy_(torch.as_tensor(params, device=self.device).to(torch.float32).t())
+
+    def state_dict(self) -> dict:
+        """Checkpoint of everything the env owns (18 + 8 words per env + params/goal/counters)."""
+        keys = ("_state", "_integ", "_params", "_goal", "_episode", "_steps")
+        return {k[1:]: (None if getattr(self, k) is None else getattr(self, k).clone()) for k in keys}
+
+    def load_state_dict(self, sd: dict):
+        for k, v in sd.items():
+            cur = getattr(self, "_" + k)
+            if v is None:
+                continue
+            if cur is None:
+                setattr(self, "_" + k, v.to(self.device).clone())
+            else:
+                cur.copy_(v)
+        self._sync_structs()
+
+    @property
+    def params(self):
+        """Per-env (m, d, J1, J3, c_tf, c_tw) as [N,6] view, or None when nominal."""
+        return None if self._params is None else self._params.t()
+
+    @property
+    def integ(self):
+        return None if self._integ is None else self._integ.t()
+
+    @property
+    def episode_steps(self):
+        return self._steps
+
+    def kernel_info(self):
+        g, b = C.c_int32(), C.c_int32()
+        name = self._lib.qr_step_kernel_info(_lib.KIND_ID[self.kind], int(self.state_dtype == torch.float64),
+                                             self.num_envs, C.byref(g), C.byref(b))
+        return name.decode(), g.value, b.value
+
+    def render(self, *a, **k):
+        raise NotImplementedError("render (VPython GUI, quad.py:469-754) is out of scope")
+
+    def close(self):
+        self._closed = True

@@ -1,0 +1,135 @@
+/*
+ * quadrotor_hip.h — C-ABI of the MI355X-native batched quadrotor dynamics engine.
+ *
+ * Drop-in boundary for ONE hot path of fdcl-gwu/gym-rotor: env.step() of Quad-v0 /
+ * CoupledWrapper / DecoupledWrapper (the template method QuadEnv.step,
+ * gym_rotor/envs/quad.py:142-168, and the hooks it calls), batched over N independent
+ * quadrotors that live in device memory.  The reference is pure Python and has no
+ * native layer, so each entry point below names the reference *method* it replaces.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, PODs; no torch / C++ types.  All pointers are DEVICE
+ *     pointers (HBM) unless stated otherwise.  `stream` is a hipStream_t passed as void*
+ *     (NULL = the default stream).  Every call is asynchronous on `stream`.
+ *   - return value: 0 on success; <0 = argument error (QR_E_*); >0 = hipError_t of the
+ *     launch.  Nothing is ever computed on the host: there is no CPU fallback.
+ *   - layout: per-env quantities are SoA, `field-major [F][N]` (lane i touches
+ *     base[f*N + i], so a 64-lane wavefront reads 256/512 contiguous bytes per field).
+ *     Caller-facing rows (actions in, observations/reward/done out) are AoS `[N][D]`
+ *     row-major, i.e. what a policy network produces/consumes; the kernels transpose
+ *     through LDS so that those rows are written with coalesced 16-byte stores.
+ *   - state vector order is the reference's (quad.py:146, quad_utils.py:12-16):
+ *       f = 0..2 x, 3..5 v, 6..14 vec_F(R) (column-major: b1,b2,b3), 15..17 W.
+ *     `state_f64 != 0` selects float64 storage + float64 integrator arithmetic (default;
+ *     the reference keeps a float64 state and fp32 storage cannot hold the 1e-5 /
+ *     1000-step parity bar); 0 selects float32 storage + arithmetic.
+ */
+#ifndef QUADROTOR_HIP_H
+#define QUADROTOR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QR_ABI_VERSION 1
+
+/* env kinds */
+#define QR_KIND_QUAD      0 /* QuadEnv            gym_rotor/envs/quad.py:19            */
+#define QR_KIND_COUPLED   1 /* CoupledWrapper     wrappers/coupled_yaw_wrapper.py:11   */
+#define QR_KIND_DECOUPLED 2 /* DecoupledWrapper   wrappers/decoupled_yaw_wrapper.py:12 */
+
+/* argument errors */
+#define QR_E_NULL   (-1) /* a required pointer is NULL        */
+#define QR_E_KIND   (-2) /* kind not in {0,1,2}               */
+#define QR_E_SIZE   (-3) /* num_envs < 0 or substeps < 1      */
+#define QR_E_ALIGN  (-4) /* a buffer is not 16-byte aligned   */
+
+/* flags */
+#define QR_FLAG_AUTO_RESET   1u /* re-sample a done env inside the same launch (train distribution) */
+#define QR_FLAG_EVAL_RESET   2u /* resets use env_type='eval' (quad.py:352-356) instead of 'train' */
+#define QR_FLAG_NO_UDM       4u /* resets keep nominal parameters (use_UDM False / eval)            */
+
+/* Coefficients a caller may override (args_parse.py:23-35); qr_default_coeffs() fills the
+ * reference defaults.  reward_min* are derived inside (quad.py:81-88). */
+typedef struct QrCoeffs {
+  double Cx, CIx, Cv, Cb1, CIb1, CW;  /* MONO / Quad-v0 reward (CW = Cw12, quad.py:80) */
+  double Cw12, CW3;                   /* MODUL                                         */
+  double alpha, beta;                 /* integral leak terms (quad.py:448-450)         */
+  double dt;                          /* 1/200 s (quad.py:60-61)                       */
+  double x_lim, v_lim, W_lim;         /* 1.0, 4.0, 2*pi (quad.py:104-106)              */
+  double eIx_lim, eIb1_lim;           /* 3.0, 3.0 (coupled_yaw_wrapper.py:23-24)       */
+  double euler_lim_deg;               /* 85 (quad.py:107)                              */
+  double udm_fraction;                /* UDM_percentage/100 = 0.1 (quad.py:370)        */
+} QrCoeffs;
+
+/* Per-env device buffers owned by the caller (the Python env object). */
+typedef struct QrEnv {
+  int32_t kind;        /* QR_KIND_*                                                       */
+  int32_t state_f64;   /* 1: state is double[18][N]; 0: float[18][N]                      */
+  int64_t num_envs;    /* N                                                               */
+  int64_t env_offset;  /* global id of local env 0 (multi-GPU shard offset; RNG key)      */
+  uint64_t seed;       /* RNG seed; draws depend only on (seed, global env id, episode)   */
+  void*    state;      /* [18][N]   in/out                                                */
+  float*   integ;      /* [8][N]    in/out: eIx(3), g_x prev(3), eIb1, g_b prev (quad_utils.py:38-63); NULL for QUAD */
+  float*   params;     /* [6][N]    m,d,J1(=J2),J3,c_tf,c_tw (quad.py:359-387); NULL = nominal   */
+  float*   goal;       /* [12][N]   xd,vd,b1d,Wd (quad.py:413-418); NULL = hover default  */
+  int32_t* episode;    /* [N]       episode counter (RNG stream id); required for resets  */
+  int32_t* steps;      /* [N]       steps since reset; NULL = no time-limit bookkeeping   */
+  int32_t  max_episode_steps; /* >0: truncated[i]=1 when steps reaches it (gym_rotor/__init__.py:3-7) */
+  uint32_t flags;      /* QR_FLAG_*                                                       */
+  QrCoeffs coeffs;
+} QrEnv;
+
+/* Outputs of one step, all AoS rows.  obs0 is float32 [N][18] (QUAD: the next state,
+ * quad.py:269-271), [N][23] (COUPLED) or [N][15] (DECOUPLED agent 1); obs1 is [N][3]
+ * (DECOUPLED agent 2) else NULL.  reward/done are [N][n_agents], n_agents = 2 for
+ * DECOUPLED, else 1. */
+typedef struct QrStepOut {
+  float*   obs0;        /* QUAD: may be NULL (the observation IS the state buffer)        */
+  float*   obs1;
+  float*   reward;      /* normalised to [0,1], -1 on crash (quad.py:154-166)             */
+  float*   reward_raw;  /* optional: hook output before np.interp / crash override        */
+  uint8_t* done;        /* terminated flags (done_wrapper)                                */
+  uint8_t* truncated;   /* optional [N]                                                   */
+} QrStepOut;
+
+/* Replaces QuadEnv.step(action) (quad.py:142-168) = action_wrapper -> observation_wrapper
+ * (ODE solve over dt + get_norm_error_state) -> reward_wrapper -> interp -> done_wrapper ->
+ * crash override, for all N envs in one fused launch.
+ *   action   [N][A] float32, A = 4 (QUAD, COUPLED) or 5 (DECOUPLED: agents' actions
+ *            concatenated, main.py:161).
+ *   substeps number of fixed RK4 substeps of h = dt/substeps replacing
+ *            scipy.integrate.solve_ivp(DOP853) (quad.py:265); >= 1. */
+int qr_step(const QrEnv* env, const float* action, int32_t substeps, const QrStepOut* out, void* stream);
+
+/* K env-steps in ONE launch with the state held in registers between steps:
+ *   action [K][N][A]; outputs [K][N][...] (pointers in `out` are the t=0 slices, the
+ *   per-step strides are the full [N][..] extents).  Same maths as K calls of qr_step. */
+int qr_rollout(const QrEnv* env, const float* action, int32_t n_steps, int32_t substeps,
+               const QrStepOut* out, void* stream);
+
+/* Replaces QuadEnv.get_norm_error_state(framework) (quad.py:421-466): normalised error
+ * observation of the CURRENT state; advances both trapezoid integrators (same side
+ * effect as the reference).  kind must be COUPLED or DECOUPLED. */
+int qr_error_obs(const QrEnv* env, float* obs0, float* obs1, void* stream);
+
+/* Replaces QuadEnv.reset(env_type) (quad.py:171-222, 338-404) for every env with
+ * mask[i] != 0 (mask NULL = all): draws UDM parameters (unless QR_FLAG_NO_UDM / no params
+ * buffer), the initial error state, R = Rz(yaw)Ry(pitch)Rx(roll), zeroes the integrators
+ * and step counters and bumps the episode counter.  Counter-based Philox4x32-10 keyed by
+ * (seed, env_offset+i, episode): results do not depend on sharding or launch geometry. */
+int qr_reset(const QrEnv* env, const uint8_t* mask, void* stream);
+
+/* Host-side helpers (no device work). */
+void qr_default_coeffs(QrCoeffs* c);
+int  qr_abi_version(void);
+/* Kernel name + launch geometry used for `n` envs (for profiling tools): writes
+ * grid/block into the out params, returns a static NUL-terminated kernel symbol name. */
+const char* qr_step_kernel_info(int32_t kind, int32_t state_f64, int64_t num_envs, int32_t* grid, int32_t* block);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUADROTOR_HIP_H */

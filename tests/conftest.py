@@ -1,0 +1,41 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+        return cache[name]
+
+    return load
+
+
+GROUPS = (slice(0, 3), slice(3, 6), slice(6, 15), slice(15, 18))
+
+
+def grouped_rel_err(got, ref):
+    """max over groups (x, v, R, W) of ||got-ref||_inf / max(||ref||_inf, 1), per env row;
+    returns the max over all leading axes (SURVEY §7.3 / §8d parity metric)."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    worst = 0.0
+    for sl in GROUPS:
+        num = np.abs(got[..., sl] - ref[..., sl]).max(-1)
+        den = np.maximum(np.abs(ref[..., sl]).max(-1), 1.0)
+        worst = max(worst, float((num / den).max()))
+    return worst

@@ -1,0 +1,329 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (fdcl-gwu/gym-rotor, read-only
+at /root/reference) in the build container.  The reference never travels to the GPU
+box: only the vectors written here do.  Re-run with `python tools/gen_golden.py`.
+
+Requires: /root/reference, numpy, scipy.  `gymnasium` is not installed in this image,
+so a ~40-line stand-in (tools/_gymnasium_shim) is put on sys.path first; `sys.argv` is
+set before every constructor because the reference re-parses it (quad.py:24-25).
+
+All inputs are float32-representable so the fp32 GPU path sees bit-identical inputs.
+
+Files written (see tests/golden/README.md for the field lists):
+  kat_units.npz            hat / ensure_SO3 / angle / euler / interp / mixing known answers
+  onestep_{kind}.npz       512 single-step transitions per env kind
+  traj_free_{kind}.npz     1000-step free-run (no reset) trajectories, 4 envs per kind
+  traj_reset_{kind}.npz    1000-step trajectories with reset-on-done to injected states
+  flightlog_modul.npz      first 1200 rows of results/MODUL_log_20250303_120200.dat
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, os.path.join(HERE, "_gymnasium_shim"))
+sys.path.insert(0, REF)
+sys.path.insert(0, REPO)
+
+sys.argv = ["gen_golden"]
+import gym_rotor.envs.quad as refquad  # noqa: E402
+from gym_rotor.envs import quad_utils as refutils  # noqa: E402
+from gym_rotor.envs.quad import QuadEnv  # noqa: E402
+from gym_rotor.wrappers.coupled_yaw_wrapper import CoupledWrapper  # noqa: E402
+from gym_rotor.wrappers.decoupled_yaw_wrapper import DecoupledWrapper  # noqa: E402
+
+from oracle import quad_oracle as orc  # noqa: E402  (only for the reset-state sampler)
+
+f32r = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)  # float32-representable f64
+
+
+def make_env(kind):
+    if kind == "decoupled":
+        sys.argv = ["x", "--framework", "MODUL"]
+        env = DecoupledWrapper()
+    elif kind == "coupled":
+        sys.argv = ["x", "--framework", "MONO"]
+        env = CoupledWrapper()
+    else:
+        sys.argv = ["x", "--framework", "MONO"]
+        env = QuadEnv()
+        env.alpha, env.beta, env.eIx_lim, env.eIb1_lim = 0.01, 0.05, 3.0, 3.0
+    env.reset(env_type="eval")
+    return env
+
+
+def inject_params(env, p):
+    """Let the reference itself derive hover_force/max_force/mixing from prescribed draws:
+    `set_random_parameters('train')` calls `uniform(low=, high=)` six times in the order
+    m, d, J1, J3, c_tf, c_tw (quad.py:380-387)."""
+    queue = list(p)
+    saved = refquad.uniform
+
+    def fake_uniform(low=0.0, high=1.0, size=None):
+        v = queue.pop(0)
+        assert low - 1e-12 <= v <= high + 1e-12, (low, v, high)
+        return v
+
+    refquad.uniform = fake_uniform
+    try:
+        env.set_random_parameters("train")
+    finally:
+        refquad.uniform = saved
+    assert not queue
+
+
+def inject(env, state, goal, integ):
+    env.state = np.array(state, dtype=np.float64)
+    env.set_goal_state(goal[0:3].copy(), goal[3:6].copy(), goal[6:9].copy(), np.zeros(3), goal[9:12].copy())
+    env.eIx.error, env.eIx.integrand = integ[0:3].copy(), integ[3:6].copy()
+    env.eIb1.error, env.eIb1.integrand = float(integ[6]), float(integ[7])
+
+
+def read_integ(env):
+    return np.concatenate([env.eIx.error, env.eIx.integrand, [env.eIb1.error, env.eIb1.integrand]])
+
+
+def ref_step(env, kind, action):
+    """One reference step.  Returns next_state, f, M, obs(list), reward_raw, reward, done."""
+    if kind == "quad":  # QuadEnv.step raises at HEAD (reward[0] on a scalar): call the hooks
+        env.action_wrapper(np.array(action, dtype=np.float64))
+        obs = env.observation_wrapper(env.state.copy())
+        raw = [float(env.reward_wrapper(obs))]
+        done = [bool(env.done_wrapper(obs))]
+        reward = [float(np.interp(raw[0], [env.reward_min, 0.0], [0.0, 1.0]))]
+        if done[0]:
+            reward[0] = env.reward_crash
+        obs = [np.array(obs, dtype=np.float64)]
+    else:
+        # run the hooks exactly as QuadEnv.step does, but keep the raw reward too
+        env.action_wrapper(np.array(action, dtype=np.float64))
+        obs = env.observation_wrapper(env.state.copy())
+        raw = [float(r) for r in env.reward_wrapper(obs)]
+        mins = [env.reward_min_1, env.reward_min_2] if kind == "decoupled" else [env.reward_min]
+        reward = [float(np.interp(r, [mn, 0.0], [0.0, 1.0])) for r, mn in zip(raw, mins)]
+        done = [bool(d) for d in env.done_wrapper(obs)]
+        for i, d in enumerate(done):
+            if d:
+                reward[i] = env.reward_crash
+    M = np.array(env.fM[1:4]).ravel() if kind == "decoupled" else np.array(env.M, dtype=np.float64).ravel()
+    return env.state.copy(), float(np.ravel(env.f)[0]), M, obs, raw, reward, done
+
+
+def check_step_template(kind):
+    """Confirm the hook sequence above reproduces env.step() for the two wrappers."""
+    rng = np.random.default_rng(5)
+    env_a, env_b = make_env(kind), make_env(kind)
+    st = f32r(orc.sample_reset_state(rng, 1)[0])
+    for e in (env_a, env_b):
+        inject(e, st, orc.DEFAULT_GOAL, np.zeros(8))
+    for _ in range(20):
+        a = f32r(rng.uniform(-1, 1, orc.ACTION_DIM[kind]))
+        obs, rwd, done, _, _ = env_a.step(a.copy())
+        _, _, _, obs_b, _, rwd_b, done_b = ref_step(env_b, kind, a)
+        assert all(np.array_equal(x, y) for x, y in zip(obs, obs_b))
+        assert list(map(float, rwd)) == rwd_b and list(done) == done_b
+
+
+# ------------------------------------------------------------------------------------
+def random_params(rng, n):
+    return f32r(orc.sample_params(rng, n, "train"))
+
+
+def random_goal(rng, n):
+    g = np.tile(orc.DEFAULT_GOAL, (n, 1))
+    psi = rng.uniform(-np.pi, np.pi, n)
+    g[:, 0:3] = rng.uniform(-0.3, 0.3, (n, 3))
+    g[:, 3:6] = rng.uniform(-0.5, 0.5, (n, 3))
+    g[:, 6], g[:, 7], g[:, 8] = np.cos(psi), np.sin(psi), 0.0
+    g[:, 9:12] = rng.uniform(-0.5, 0.5, (n, 3))
+    return f32r(g)
+
+
+def boundary_states(rng, n):
+    """States straddling each termination threshold (|x|~1, |v|~4, |W|~2pi, roll/pitch~85deg)."""
+    s = orc.sample_reset_state(rng, n, "train")
+    for i in range(n):
+        which = i % 5
+        eps = rng.uniform(-0.02, 0.02)
+        j = rng.integers(0, 3)
+        sgn = rng.choice([-1.0, 1.0])
+        if which == 0:
+            s[i, 0 + j] = sgn * (1.0 + eps)
+        elif which == 1:
+            s[i, 3 + j] = sgn * (4.0 + 4 * eps)
+        elif which == 2:
+            s[i, 15 + j] = sgn * (2 * np.pi + 6 * eps)
+        else:
+            ang = np.deg2rad(85.0 + 100 * eps)
+            roll, pitch = (sgn * ang, rng.uniform(-0.3, 0.3)) if which == 3 else (rng.uniform(-0.3, 0.3), sgn * ang)
+            s[i, 6:15] = orc.euler_xyz_to_R(roll, pitch, rng.uniform(-np.pi, np.pi)).reshape(9, order="F")
+            s[i, 15:18] *= 0.05
+    return s
+
+
+def gen_onestep(kind, n=512, seed=0):
+    rng = np.random.default_rng(1000 + seed + 17 * orc.KINDS.index(kind))
+    A = orc.ACTION_DIM[kind]
+    nb = n // 4
+    state = f32r(np.concatenate([orc.sample_reset_state(rng, n - nb, "train"), boundary_states(rng, nb)]))
+    action = f32r(rng.uniform(-1, 1, (n, A)))
+    action[::7] = f32r(np.sign(action[::7]))  # saturated commands
+    params = np.tile(orc.NOMINAL_PARAMS, (n, 1)); params[1::2] = random_params(rng, n)[1::2]
+    params = f32r(params)
+    goal = np.tile(orc.DEFAULT_GOAL, (n, 1)); goal[n // 2:] = random_goal(rng, n)[n // 2:]
+    integ = np.zeros((n, 8))
+    integ[:, 0:3] = rng.uniform(-1.0, 1.0, (n, 3)); integ[::5, 0:3] = rng.uniform(-4.0, 4.0, (len(integ[::5]), 3))
+    integ[:, 3:6] = rng.uniform(-1.0, 1.0, (n, 3))
+    integ[:, 6] = rng.uniform(-2.0, 2.0, n); integ[::9, 6] = rng.uniform(-4.0, 4.0, len(integ[::9]))
+    integ[:, 7] = rng.uniform(-3.0, 3.0, n)
+    integ = f32r(integ)
+    if kind == "quad":
+        integ[:] = 0.0
+    env = make_env(kind)
+    obs_dims = {"quad": [18], "coupled": [23], "decoupled": [15, 3]}[kind]
+    nag = orc.N_AGENTS[kind]
+    out = dict(state=state, action=action, params=params, goal=goal, integ=integ,
+               next_state=np.zeros((n, 18)), f=np.zeros(n), M=np.zeros((n, 3)),
+               reward_raw=np.zeros((n, nag)), reward=np.zeros((n, nag)), done=np.zeros((n, nag), bool),
+               next_integ=np.zeros((n, 8)))
+    obs_out = [np.zeros((n, d), np.float64 if kind == "quad" else np.float32) for d in obs_dims]
+    for i in range(n):
+        inject_params(env, params[i])
+        inject(env, state[i], goal[i], integ[i])
+        ns, f, M, obs, raw, rwd, done = ref_step(env, kind, action[i])
+        out["next_state"][i], out["f"][i], out["M"][i] = ns, f, M
+        out["reward_raw"][i], out["reward"][i], out["done"][i] = raw, rwd, done
+        out["next_integ"][i] = read_integ(env)
+        for k, o in enumerate(obs):
+            obs_out[k][i] = o
+    for k, o in enumerate(obs_out):
+        out[f"obs{k}"] = o
+    np.savez_compressed(os.path.join(OUT, f"onestep_{kind}.npz"), **out)
+    print(f"onestep_{kind}: n={n} done-rate={out['done'].mean():.3f}")
+
+
+def gen_traj(kind, mode, n_env=4, T=1000, seed=0):
+    """mode 'free': never reset.  mode 'reset': when any agent's done fires, the caller
+    resets that env to the next injected state, zeroes the integrators and calls
+    get_norm_error_state() once (main.py:226-230) before the next step."""
+    rng = np.random.default_rng(2000 + seed + 31 * orc.KINDS.index(kind) + (7 if mode == "reset" else 0))
+    A = orc.ACTION_DIM[kind]
+    nag = orc.N_AGENTS[kind]
+    obs_dims = {"quad": [18], "coupled": [23], "decoupled": [15, 3]}[kind]
+    params = np.tile(orc.NOMINAL_PARAMS, (n_env, 1)); params[n_env // 2:] = random_params(rng, n_env)[n_env // 2:]
+    params = f32r(params)
+    goal = np.tile(orc.DEFAULT_GOAL, (n_env, 1)); goal[1::2] = random_goal(rng, n_env)[1::2]
+    init = f32r(orc.sample_reset_state(rng, n_env, "train"))
+    pool = f32r(orc.sample_reset_state(rng, 64 * n_env, "train")).reshape(n_env, 64, 18)
+    actions = f32r(rng.uniform(-1, 1, (T, n_env, A)))
+    states = np.zeros((T + 1, n_env, 18)); integs = np.zeros((T + 1, n_env, 8))
+    rewards = np.zeros((T, n_env, nag)); raws = np.zeros((T, n_env, nag)); dones = np.zeros((T, n_env, nag), bool)
+    obs_out = [np.zeros((T, n_env, d), np.float64 if kind == "quad" else np.float32) for d in obs_dims]
+    reset_at = np.zeros((T + 1, n_env), bool)   # reset applied BEFORE step t
+    n_resets = np.zeros(n_env, int)
+    for e in range(n_env):
+        env = make_env(kind)
+        inject_params(env, params[e])
+        inject(env, init[e], goal[e], np.zeros(8))
+        if kind != "quad":
+            env.get_norm_error_state(env.framework)  # first obs after reset (main.py:129)
+        for t in range(T):
+            states[t, e], integs[t, e] = env.state, read_integ(env)
+            ns, f, M, obs, raw, rwd, done = ref_step(env, kind, actions[t, e])
+            rewards[t, e], raws[t, e], dones[t, e] = rwd, raw, done
+            for k, o in enumerate(obs):
+                obs_out[k][t, e] = o
+            if mode == "reset" and any(done):
+                inject(env, pool[e, n_resets[e] % 64], goal[e], np.zeros(8))
+                n_resets[e] += 1
+                reset_at[t + 1, e] = True
+                if kind != "quad":
+                    env.get_norm_error_state(env.framework)
+        states[T, e], integs[T, e] = env.state, read_integ(env)
+    out = dict(params=params, goal=goal, init_state=init, reset_pool=pool, actions=actions.astype(np.float32),
+               states=states, integs=integs, rewards=rewards, rewards_raw=raws, dones=dones, reset_at=reset_at)
+    for k, o in enumerate(obs_out):
+        out[f"obs{k}"] = o
+    np.savez_compressed(os.path.join(OUT, f"traj_{mode}_{kind}.npz"), **out)
+    print(f"traj_{mode}_{kind}: resets={n_resets.tolist()} max|x|={np.abs(states[:, :, 0:3]).max():.2f} "
+          f"max|W|={np.abs(states[:, :, 15:18]).max():.2f}")
+
+
+def gen_kats():
+    rng = np.random.default_rng(7)
+    k = {}
+    v = rng.normal(size=(16, 3))
+    k["hat_in"], k["hat_out"] = v, np.stack([refutils.hat(x) for x in v])
+    # ensure_SO3: both branches
+    Rs, outs = [], []
+    for i, eps in enumerate([0.0, 1e-7, 1e-6, 5e-6, 9e-6, 2e-5, 1e-4, 1e-3, 1e-2, 5e-2] * 3):
+        R = orc.euler_xyz_to_R(*rng.uniform(-1.2, 1.2, 3)) + eps * rng.normal(size=(3, 3))
+        Rs.append(R); outs.append(refutils.ensure_SO3(R.copy()))
+    k["so3_in"], k["so3_out"] = np.stack(Rs), np.stack(outs)
+    # heading angle helpers
+    a = rng.normal(size=(64, 3)); b = rng.normal(size=(64, 3)); a[:, 2] = 0; b[:, 2] = 0
+    k["ang_a"], k["ang_b"] = a, b
+    k["ang_out"] = np.array([refutils.norm_ang_btw_two_vectors(x, y) for x, y in zip(a, b)])
+    Rr = np.stack([orc.euler_xyz_to_R(*rng.uniform(-np.pi / 2.2, np.pi / 2.2, 2), rng.uniform(-np.pi, np.pi))
+                   for _ in range(64)])
+    k["b1_R"] = Rr
+    k["b1_out"] = np.stack([refutils.get_current_b1(R) for R in Rr])
+    # euler conventions (scipy)
+    from scipy.spatial.transform import Rotation
+    eul = rng.uniform(-1.4, 1.4, (64, 3)); eul[:, 2] = rng.uniform(-np.pi, np.pi, 64)
+    k["euler_in"] = eul
+    k["euler_R"] = np.stack([Rotation.from_euler("xyz", e).as_matrix() for e in eul])
+    k["euler_back_deg"] = np.stack([Rotation.from_matrix(R).as_euler("xyz", degrees=True) for R in k["euler_R"]])
+    # np.interp reward normalisation incl. both clip ends
+    r = np.concatenate([np.linspace(-20, 2, 45), [-14.0, -8.0, -7.0, 0.0]])
+    k["interp_in"] = r
+    for mn in (-14.0, -8.0, -7.0):
+        k[f"interp_out_{int(-mn)}"] = np.array([np.interp(x, [mn, 0.0], [0.0, 1.0]) for x in r])
+    # motor mixing / action maps for the three kinds, nominal + random params
+    for kind in orc.KINDS:
+        env = make_env(kind)
+        n = 64
+        P = np.tile(orc.NOMINAL_PARAMS, (n, 1)); P[1::2] = random_params(rng, n)[1::2]
+        P = f32r(P)
+        Aa = f32r(rng.uniform(-1.3, 1.3, (n, orc.ACTION_DIM[kind])))
+        S = f32r(orc.sample_reset_state(rng, n))
+        F, Mo, der = np.zeros(n), np.zeros((n, 3)), np.zeros((n, 4))
+        for i in range(n):
+            inject_params(env, P[i]); inject(env, S[i], orc.DEFAULT_GOAL, np.zeros(8))
+            env.action_wrapper(Aa[i].copy())
+            if kind == "decoupled":  # M1, M2 are formed inside observation_wrapper (decoupled:68-73)
+                env.observation_wrapper(env.state.copy())
+                Mo[i] = np.array(env.fM[1:4]).ravel()
+            else:
+                Mo[i] = np.ravel(env.M)
+            F[i] = float(np.ravel(env.f)[0])
+            der[i] = [env.hover_force, env.max_force, env.avrg_act, env.scale_act]
+        k[f"act_{kind}_params"], k[f"act_{kind}_a"], k[f"act_{kind}_state"] = P, Aa, S
+        k[f"act_{kind}_f"], k[f"act_{kind}_M"], k[f"act_{kind}_derived"] = F, Mo, der
+    k["constants"] = np.array([env.reward_min, make_env("decoupled").reward_min_1, make_env("decoupled").reward_min_2,
+                               env.dt, env.x_lim, env.v_lim, env.W_lim, env.euler_lim])
+    np.savez_compressed(os.path.join(OUT, "kat_units.npz"), **k)
+    print("kat_units written")
+
+
+def gen_flightlog(rows=1200):
+    log = np.loadtxt(os.path.join(REF, "results", "MODUL_log_20250303_120200.dat"))
+    np.savez_compressed(os.path.join(OUT, "flightlog_modul.npz"), log=log[:rows])
+    print("flightlog rows", rows, "of", log.shape)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    for kind in ("coupled", "decoupled"):
+        check_step_template(kind)
+    gen_kats()
+    gen_flightlog()
+    for kind in orc.KINDS:
+        gen_onestep(kind)
+    for kind in orc.KINDS:
+        gen_traj(kind, "free")
+        gen_traj(kind, "reset")
