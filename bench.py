@@ -43,8 +43,8 @@ def parse():
     p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--envs", type=int, default=65536, help="envs PER GPU")
     p.add_argument("--kind", default="quad", choices=["quad", "coupled", "decoupled"])
-    p.add_argument("--substeps", type=int, default=2)
-    p.add_argument("--state-dtype", default="f64", choices=["f64", "f32"])
+    p.add_argument("--substeps", type=int, default=1)
+    p.add_argument("--layout", default="mixed", choices=["mixed", "f64", "f32"])
     p.add_argument("--mode", default="graph", choices=["graph", "eager"])
     p.add_argument("--no-auto-reset", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
@@ -101,8 +101,7 @@ def main():
     from gym_rotor_amd import ALGO_BYTES, QuadVecEnv
     from gym_rotor_amd.constants import ALGO_BYTES_PARAMS
     N = a.envs
-    sdt = torch.float64 if a.state_dtype == "f64" else torch.float32
-    env = QuadVecEnv(a.kind, N, device=dev, seed=0, substeps=a.substeps, state_dtype=sdt, use_UDM=True,
+    env = QuadVecEnv(a.kind, N, device=dev, seed=0, substeps=a.substeps, layout=a.layout, use_UDM=True,
                      auto_reset=not a.no_auto_reset, env_offset=rank * N)
     env.reset("train")
     if a.kind != "quad":
@@ -154,22 +153,22 @@ def main():
         ms_per_step = wall * 1e3 / a.steps
         launch_us = dev_ms * 1e3 / a.steps
         algo = ALGO_BYTES[a.kind] + ALGO_BYTES_PARAMS
-        layout = {"quad": 18 * 8 * 2 + 16 + 4 + 1 + 18 * 4 + 24 + 4 * 2 + 1,  # f64 state r/w, action, reward, done, obs rows, params, steps, trunc
-                  "coupled": 18 * 8 * 2 + 16 + 64 + 92 + 4 + 1 + 24 + 8 + 1,
-                  "decoupled": 18 * 8 * 2 + 20 + 64 + 72 + 8 + 2 + 24 + 8 + 1}[a.kind]
-        if a.state_dtype == "f32":
-            layout -= 18 * 4 * 2
+        # bytes this layout really moves per env-step: 13-word state r/w, action, [integ r/w, obs rows],
+        # reward, done, params
+        state_b = {"mixed": 6 * 4 + 7 * 8, "f64": 13 * 8, "f32": 13 * 4}[a.layout] * 2
+        layout = state_b + {"quad": 16 + 4 + 1 + 24, "coupled": 16 + 64 + 92 + 4 + 1 + 24,
+                            "decoupled": 20 + 64 + 72 + 8 + 2 + 24}[a.kind]
         achieved = algo * N / (launch_us * 1e-6) / 1e9
         kname, grid, block = env.kernel_info()
         out = {
             "metric": "quadrotor env-steps/sec at 65 536 envs; 1/2/4/8 MI355X + CPU ref",
             "value": N * n_gpus * a.steps / wall, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": a.state_dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if a.layout == "f32" else "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[1]: Quad-v0 batched {N} envs per GPU, random actions, fp32 I/O"
                        if a.kind == "quad" else f"{a.kind} {N} envs per GPU",
                        "kind": a.kind, "envs_per_gpu": N, "global_envs": N * n_gpus, "substeps": a.substeps,
-                       "integrator": "RK4 fixed-step", "state_dtype": a.state_dtype, "io_dtype": "f32",
+                       "integrator": "RK4 fixed-step on (v, unit quaternion, W)", "state_layout": a.layout, "io_dtype": "f32",
                        "auto_reset": not a.no_auto_reset, "launch_mode": a.mode, "parallelism": f"env-shard x{n_gpus}, no collective",
                        "state_finite": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -177,8 +176,9 @@ def main():
                          "kernel": kname, "grid": grid, "block": block, "avg_launch_us": launch_us,
                          "algorithmic_bytes_per_env_step": algo, "layout_bytes_per_env_step": layout,
                          "achieved_layout_GBs": layout * N / (launch_us * 1e-6) / 1e9,
-                         "note": "65 536-env working set (~25 MB) is L2/MALL-resident and launch-latency-bound; "
-                                 "avg_launch_us includes the inter-kernel gap of back-to-back launches"},
+                         "note": "algorithmic bytes = SURVEY.md 8(d) (165 B + 24 B per-env params for Quad-v0); "
+                                 "avg_launch_us = HIP-event time of the K back-to-back launches / K (includes the "
+                                 "~1.7 us launch floor of an empty kernel of this grid)"},
         }
         if n_gpus == 1 and a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(a.kind, a.cpu_seconds)

@@ -10,19 +10,21 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libquadrotor_hip.so")
+# QR_LIB overrides the path for measurement builds (tools/microbench.py ablations) only.
+LIB_PATH = os.environ.get("QR_LIB", os.path.join(_HERE, "libquadrotor_hip.so"))
 
 KIND_QUAD, KIND_COUPLED, KIND_DECOUPLED = 0, 1, 2
 KIND_ID = {"quad": KIND_QUAD, "coupled": KIND_COUPLED, "decoupled": KIND_DECOUPLED}
 FLAG_AUTO_RESET, FLAG_EVAL_RESET, FLAG_NO_UDM = 1, 2, 4
-ABI_VERSION = 1
+ABI_VERSION = 2
+LAYOUT_ID = {"mixed": 0, "f64": 1, "f32": 2}
 
 ERRORS = {-1: "QR_E_NULL: a required pointer is NULL", -2: "QR_E_KIND: bad env kind",
           -3: "QR_E_SIZE: bad num_envs / substeps / n_steps", -4: "QR_E_ALIGN: buffer not 16-byte aligned"}
 
 # every symbol include/quadrotor_hip.h declares
-SYMBOLS = ("qr_step", "qr_rollout", "qr_error_obs", "qr_reset", "qr_default_coeffs", "qr_abi_version",
-           "qr_step_kernel_info")
+SYMBOLS = ("qr_step", "qr_rollout", "qr_error_obs", "qr_reset", "qr_get_state", "qr_set_state",
+           "qr_default_coeffs", "qr_abi_version", "qr_step_kernel_info")
 
 
 class QrCoeffs(C.Structure):
@@ -32,9 +34,10 @@ class QrCoeffs(C.Structure):
 
 
 class QrEnv(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("state_f64", C.c_int32), ("num_envs", C.c_int64),
+    _fields_ = [("kind", C.c_int32), ("layout", C.c_int32), ("num_envs", C.c_int64),
                 ("env_offset", C.c_int64), ("seed", C.c_uint64),
-                ("state", C.c_void_p), ("integ", C.c_void_p), ("params", C.c_void_p), ("goal", C.c_void_p),
+                ("pos_vel", C.c_void_p), ("att_rate", C.c_void_p),
+                ("integ", C.c_void_p), ("params", C.c_void_p), ("goal", C.c_void_p),
                 ("episode", C.c_void_p), ("steps", C.c_void_p),
                 ("max_episode_steps", C.c_int32), ("flags", C.c_uint32), ("coeffs", QrCoeffs)]
 
@@ -77,6 +80,10 @@ def load():
     lib.qr_error_obs.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p, C.c_void_p]
     lib.qr_reset.restype = C.c_int
     lib.qr_reset.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p]
+    lib.qr_get_state.restype = C.c_int
+    lib.qr_get_state.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p]
+    lib.qr_set_state.restype = C.c_int
+    lib.qr_set_state.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p, C.c_void_p]
     lib.qr_step_kernel_info.restype = C.c_char_p
     lib.qr_step_kernel_info.argtypes = [C.c_int32, C.c_int32, C.c_int64, P(C.c_int32), P(C.c_int32)]
     if lib.qr_abi_version() != ABI_VERSION:

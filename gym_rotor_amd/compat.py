@@ -21,7 +21,8 @@ class _SingleEnv:
     _kind = "quad"
 
     def __init__(self, render_mode: Optional[str] = None, **kwargs):
-        kwargs.setdefault("substeps", 2)
+        if self._kind == "quad":
+            kwargs.setdefault("obs_rows", True)
         self.vec = QuadVecEnv(kind=self._kind, num_envs=1, **kwargs)
         v = self.vec
         for name in ("dt", "freq", "g", "x_lim", "v_lim", "W_lim", "euler_lim", "eIx_lim", "eIb1_lim", "sat_sigma",

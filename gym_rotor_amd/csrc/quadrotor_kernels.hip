@@ -2,28 +2,41 @@
 //
 // One lane = one quadrotor.  A launch does, per env and per env-step, everything the
 // reference's QuadEnv.step template does (gym_rotor/envs/quad.py:142-168):
-//   action map / motor mixing -> S fixed RK4 substeps of the 18-dim rigid-body ODE on
-//   R^3 x R^3 x SO(3) x R^3 (quad.py:321-335) with zero-order-hold (f, M) -> SO(3)
-//   re-orthonormalisation -> error observation + trapezoid integrators (quad.py:421-466)
-//   -> reward -> np.interp normalisation -> done -> crash override [-> auto-reset].
-// The whole working set (18 state words, 8 integrator words, goal, parameters) lives in
-// VGPRs across all substeps and, in qr_rollout, across env-steps: HBM is touched once in
-// and once out.  Per-env SoA buffers are read/written with lane-contiguous accesses;
-// caller-facing AoS rows (actions, observations) go through LDS so that global traffic
-// is issued as linear 16-byte-per-lane stores.  There is no contraction larger than
-// 3x3 * 3x3 anywhere, so no MFMA; the kernel is bound by HBM / launch latency.
+//   action map / motor mixing -> S fixed RK4 substeps of the rigid-body ODE on
+//   R^3 x R^3 x SO(3) x R^3 (quad.py:321-335) with zero-order-hold (f, M) -> error
+//   observation + trapezoid integrators (quad.py:421-466) -> reward -> np.interp
+//   normalisation -> done -> crash override [-> auto-reset].
 //
-// Written directly for CDNA4: 64-lane wavefronts, one wavefront per workgroup so that
-// N = 65 536 envs still gives 1024 workgroups (4 per CU, one per SIMD) and the LDS
-// transposes need no cross-wave barrier traffic.
+// What bounds it: measured on MI355X the step moves its working set through the fabric at
+// the HBM rate even at N = 65 536 (dirty L2 lines are written back at every kernel
+// boundary), and all arithmetic fits under that, so the design minimises BYTES per env:
+//   * attitude is a unit quaternion (4 words) integrated directly — q' = q (0,W)/2 is the
+//     same flow as R' = R hat(W) — so the state is 13 words, not 18; R(q) is rebuilt in
+//     registers only where the observation / reward needs it;
+//   * x, v are stored as float32 and q, W as float64 in the default (mixed) layout: fp32
+//     rounding of W and R is what breaks the 1e-5 / 1000-step parity bar, x and v do not
+//     feed back into the rotation;
+//   * the whole working set stays in VGPRs across substeps and, in qr_rollout, across
+//     env-steps: HBM is touched once in and once out.
+// Per-env SoA buffers are read/written with lane-contiguous accesses; caller-facing AoS
+// rows (actions, observations) go through LDS so global traffic is linear 16-byte-per-lane
+// stores.  There is no contraction larger than 3x3 anywhere, so no MFMA.
+//
+// Written directly for CDNA4 (64-lane wavefronts).  Small batches use one wavefront per
+// workgroup (N = 65 536 -> 1024 workgroups, one per SIMD, no cross-wave barriers); large
+// batches use 256-thread workgroups to stay under the workgroup dispatch rate.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "quadrotor_hip.h"
 
-namespace qr {
+#ifndef QR_ABLATE
+#define QR_ABLATE 0  // 0 = product build; 1/2 = measurement-only builds (tools/microbench.py)
+#endif
 
-constexpr int kBlock = 64;  // one wavefront per workgroup
+namespace qr {
 
 // ------------------------------------------------------------------------------------
 // Kernel argument block (passed by value in kernarg memory)
@@ -33,11 +46,14 @@ struct Coeffs {  // double-precision copy of QrCoeffs + derived reward floors
   double x_lim, v_lim, W_lim, eIx_lim, eIb1_lim;
   double sin_euler_lim, tan_euler_lim, udm;
   double rmin_mono, rmin_1, rmin_2;
+  // reciprocals formed once on the host (an f64 division costs ~35 VALU slots on the device)
+  double inv_x_lim, inv_v_lim, inv_W_lim, inv_eIx_lim, inv_eIb1_lim, inv_nrmin_mono, inv_nrmin_1, inv_nrmin_2;
 };
 
 struct Args {
   // per-env buffers
-  void* state;
+  void* pos_vel;
+  void* att_rate;
   float* integ;
   float* params;
   float* goal;
@@ -52,6 +68,8 @@ struct Args {
   uint8_t* done;
   uint8_t* truncated;
   const uint8_t* mask;
+  double* rows_out;       // qr_get_state
+  const double* rows_in;  // qr_set_state
   int64_t n;
   int64_t env_offset;
   uint64_t seed;
@@ -67,19 +85,46 @@ constexpr double kMnom = 2.15, kDnom = 0.23, kJ1nom = 0.022, kJ3nom = 0.035, kCt
                  kCtwNom = 2.2, kG = 9.81, kMinForce = 0.5;
 constexpr double kPi = 3.14159265358979323846;
 
+template <typename T> __device__ __forceinline__ T clampT(T v, T lo, T hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// 1/a for well-scaled positive a (masses, inertias): hardware seed + Newton steps instead of
+// the ~35-instruction IEEE f64 division expansion.  Relative error <= 2 ulp.
+__device__ __forceinline__ double recip(double a) {
+  double x = __builtin_amdgcn_rcp(a);
+  x = fma(fma(-a, x, 1.0), x, x);
+  x = fma(fma(-a, x, 1.0), x, x);
+  return x;
+}
+__device__ __forceinline__ float recip(float a) {
+  float x = __builtin_amdgcn_rcpf(a);
+  return fmaf(fmaf(-a, x, 1.0f), x, x);
+}
+
 template <typename T>
 struct Phys {  // per-env physical parameters + what set_random_parameters derives (quad.py:389-404)
   T m, d, J1, J3, ctf, ctw;
   T max_force, avrg_act, scale_act;
+  __device__ __forceinline__ void nominal() {
+    m = T(kMnom); d = T(kDnom); J1 = T(kJ1nom); J3 = T(kJ3nom); ctf = T(kCtfNom); ctw = T(kCtwNom);
+  }
   __device__ __forceinline__ void derive() {
-    const T hover = m * T(kG) / T(4);
+    const T hover = m * T(kG * 0.25);
     max_force = ctw * hover;
-    avrg_act = (T(kMinForce) + max_force) / T(2);
+    avrg_act = (T(kMinForce) + max_force) * T(0.5);
     scale_act = max_force - avrg_act;
   }
 };
 
-template <typename T> __device__ __forceinline__ T clampT(T v, T lo, T hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// Per-env working set.  y = (v[0..2], q[3..6] = w,x,y,z, W[7..9]) is the RK4 vector; x' = v is
+// integrated from the stage velocities.
+template <typename T>
+struct Work {
+  T x[3];
+  T y[10];
+  Phys<T> ph;
+  T goal[12];   // xd, vd, b1d, Wd
+  T integ[8];   // eIx, g_x prev, eIb1, g_b prev
+};
 
 // ------------------------------------------------------------------------------------
 // Philox4x32-10 counter-based RNG (Salmon et al., SC'11): stateless, keyed by
@@ -99,7 +144,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&ctr)[4], uint32_t k0, u
   }
 }
 
-struct Draws {  // 20 uniforms in (-1, 1) / (0, 1)
+struct Draws {  // 20 uniforms
   uint32_t r[20];
   __device__ __forceinline__ double u01(int i) const { return ((double)r[i] + 0.5) * (1.0 / 4294967296.0); }
   __device__ __forceinline__ double sym(int i) const { return 2.0 * u01(i) - 1.0; }
@@ -115,15 +160,30 @@ __device__ __forceinline__ void draw20(Draws& d, uint64_t seed, uint64_t gid, ui
   }
 }
 
+// sin/cos of a random angle: float evaluation re-normalised in f64, so every factor (hence
+// q) has unit norm to f64 round-off.
+__device__ __forceinline__ void unit_sincos(double ang, double& s, double& c) {
+  float sf, cf;
+  sincosf((float)ang, &sf, &cf);
+  s = sf; c = cf;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {  // r = 1/sqrt(n2) to first order around 1: 1e-7 -> 1e-14 -> 1e-28
+    const double r = 1.5 - 0.5 * (s * s + c * c);
+    s *= r; c *= r;
+  }
+}
+
 // QuadEnv.reset + sample_init_error + set_random_parameters (quad.py:171-222, 338-404).
 // Draw order: 0..5 m,d,J1,J3,c_tf,c_tw; 6 yaw; 7 zero-error branch; 8..10 x; 11..13 v;
-// 14..16 W; 17,18 roll,pitch.
+// 14..16 W; 17,18 roll,pitch.  R = Rz(yaw) Ry(pitch) Rx(roll) (scipy 'xyz' extrinsic,
+// quad.py:199)  <=>  q = qz(yaw) qy(pitch) qx(roll).
 template <typename T>
-__device__ void sample_reset(T (&y)[18], Phys<T>& ph, bool randomise, bool eval, const Coeffs& c,
-                             uint64_t seed, uint64_t gid, uint32_t episode) {
+__device__ void sample_reset(Work<T>& w, bool randomise, bool eval, const Coeffs& c, uint64_t seed, uint64_t gid,
+                             uint32_t episode) {
   Draws d;
   draw20(d, seed, gid, episode);
-  if (randomise) {
+  Phys<T>& ph = w.ph;
+  if (randomise) {  // values are rounded to float32: that is how the params buffer stores them
     const double p = c.udm;
     ph.m = T((float)(kMnom * (1.0 + p * d.sym(0))));
     ph.d = T((float)(kDnom * (1.0 + p * d.sym(1))));
@@ -132,7 +192,7 @@ __device__ void sample_reset(T (&y)[18], Phys<T>& ph, bool randomise, bool eval,
     ph.ctf = T((float)(kCtfNom * (1.0 + p * d.sym(4))));
     ph.ctw = T((float)(kCtwNom * (1.0 + 0.5 * p * d.sym(5))));
   } else {
-    ph.m = T(kMnom); ph.d = T(kDnom); ph.J1 = T(kJ1nom); ph.J3 = T(kJ3nom); ph.ctf = T(kCtfNom); ph.ctw = T(kCtwNom);
+    ph.nominal();
   }
   ph.derive();
   const double yaw = kPi * d.sym(6);
@@ -146,70 +206,47 @@ __device__ void sample_reset(T (&y)[18], Phys<T>& ph, bool randomise, bool eval,
   }
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    y[j] = T(ix * d.sym(8 + j));
-    y[3 + j] = T(iv * d.sym(11 + j));
-    y[15 + j] = T(iW * d.sym(14 + j));
+    w.x[j] = T((float)(ix * d.sym(8 + j)));
+    w.y[j] = T((float)(iv * d.sym(11 + j)));
+    w.y[7 + j] = T(iW * d.sym(14 + j));
   }
-  const double roll = iR * d.sym(17), pitch = iR * d.sym(18);
   double sr, cr, sp, cp, sy, cy;
-  sincos(roll, &sr, &cr); sincos(pitch, &sp, &cp); sincos(yaw, &sy, &cy);
-  // R = Rz(yaw) Ry(pitch) Rx(roll)  (scipy 'xyz' extrinsic, quad.py:199), column-major
-  y[6] = T(cy * cp);                y[7] = T(sy * cp);                y[8] = T(-sp);
-  y[9] = T(cy * sp * sr - sy * cr); y[10] = T(sy * sp * sr + cy * cr); y[11] = T(cp * sr);
-  y[12] = T(cy * sp * cr + sy * sr); y[13] = T(sy * sp * cr - cy * sr); y[14] = T(cp * cr);
+  unit_sincos(0.5 * iR * d.sym(17), sr, cr);
+  unit_sincos(0.5 * iR * d.sym(18), sp, cp);
+  unit_sincos(0.5 * yaw, sy, cy);
+  w.y[3] = T(cr * cp * cy + sr * sp * sy);
+  w.y[4] = T(sr * cp * cy - cr * sp * sy);
+  w.y[5] = T(cr * sp * cy + sr * cp * sy);
+  w.y[6] = T(cr * cp * sy - sr * sp * cy);
 }
 
 // ------------------------------------------------------------------------------------
-// SO(3) helpers
+// Attitude helpers
 // ------------------------------------------------------------------------------------
-// One Newton-Schulz step R <- R (3I - R^T R)/2: removes first-order orthogonality drift.
+// R(q), column-major like the reference's vec_F(R): R[3c + r].
 template <typename T>
-__device__ __forceinline__ void newton_schulz(T* R /* column-major 9 */) {
-  const T g00 = R[0] * R[0] + R[1] * R[1] + R[2] * R[2];
-  const T g11 = R[3] * R[3] + R[4] * R[4] + R[5] * R[5];
-  const T g22 = R[6] * R[6] + R[7] * R[7] + R[8] * R[8];
-  const T g01 = R[0] * R[3] + R[1] * R[4] + R[2] * R[5];
-  const T g02 = R[0] * R[6] + R[1] * R[7] + R[2] * R[8];
-  const T g12 = R[3] * R[6] + R[4] * R[7] + R[5] * R[8];
-  const T h = T(0.5);
-  const T s00 = h * (T(3) - g00), s11 = h * (T(3) - g11), s22 = h * (T(3) - g22);
-  const T s01 = -h * g01, s02 = -h * g02, s12 = -h * g12;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const T a = R[i], b = R[3 + i], cc = R[6 + i];
-    R[i] = a * s00 + b * s01 + cc * s02;
-    R[3 + i] = a * s01 + b * s11 + cc * s12;
-    R[6 + i] = a * s02 + b * s12 + cc * s22;
-  }
+__device__ __forceinline__ void quat_to_R(const T* q, T (&R)[9]) {
+  const T w = q[0], x = q[1], y = q[2], z = q[3];
+  const T xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+  R[0] = T(1) - T(2) * (yy + zz); R[1] = T(2) * (xy + wz);        R[2] = T(2) * (xz - wy);
+  R[3] = T(2) * (xy - wz);        R[4] = T(1) - T(2) * (xx + zz); R[5] = T(2) * (yz + wx);
+  R[6] = T(2) * (xz + wy);        R[7] = T(2) * (yz - wx);        R[8] = T(1) - T(2) * (xx + yy);
 }
 
-// ensure_SO3 (quad_utils.py:123-142): if R^T R or det R is off by more than 1e-5, replace R
-// by the nearest rotation (the polar factor U V^T the reference gets from an SVD).  The
-// polar factor is computed with the scaled Newton iteration X <- (X + X^-T)/2, which
-// converges quadratically to the same matrix for det R > 0.
-template <typename T>
-__device__ void so3_guard(T* R) {
-  const T tol = T(1e-5);
-  const T g00 = R[0] * R[0] + R[1] * R[1] + R[2] * R[2];
-  const T g11 = R[3] * R[3] + R[4] * R[4] + R[5] * R[5];
-  const T g22 = R[6] * R[6] + R[7] * R[7] + R[8] * R[8];
-  const T g01 = R[0] * R[3] + R[1] * R[4] + R[2] * R[5];
-  const T g02 = R[0] * R[6] + R[1] * R[7] + R[2] * R[8];
-  const T g12 = R[3] * R[6] + R[4] * R[7] + R[5] * R[8];
-  const T det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[3] * (R[1] * R[8] - R[2] * R[7]) + R[6] * (R[1] * R[5] - R[2] * R[4]);
-  // np.allclose(R^T R, I, rtol=atol=1e-5): |a-b| <= atol + rtol*|b|
-  const bool ok = fabs(g00 - T(1)) <= T(2) * tol && fabs(g11 - T(1)) <= T(2) * tol && fabs(g22 - T(1)) <= T(2) * tol &&
-                  fabs(g01) <= tol && fabs(g02) <= tol && fabs(g12) <= tol && fabs(det - T(1)) <= T(1e-8) + tol;
-  if (ok) return;
+// ensure_SO3 (quad_utils.py:123-142) + attitude import.  The reference replaces R by the
+// nearest rotation U V^T (SVD) when R^T R or det R is off by more than 1e-5; since the
+// internal attitude is a unit quaternion, the nearest rotation is taken always (for an R
+// that is orthonormal to round-off this changes nothing).  The polar factor is computed by
+// the Newton iteration X <- (X + X^-T)/2, which converges quadratically to U V^T (det R > 0).
+__device__ void R_to_quat(const double* Rin, double (&q)[4]) {
   double X[9];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) X[i] = (double)R[i];
-  for (int it = 0; it < 30; ++it) {
-    double C[9];
+  for (int i = 0; i < 9; ++i) X[i] = Rin[i];
+  for (int it = 0; it < 40; ++it) {
+    double C[9];  // C = cof(X), column-major like X; X^-T = C / det X
     C[0] = X[4] * X[8] - X[5] * X[7]; C[1] = X[5] * X[6] - X[3] * X[8]; C[2] = X[3] * X[7] - X[4] * X[6];
     C[3] = X[2] * X[7] - X[1] * X[8]; C[4] = X[0] * X[8] - X[2] * X[6]; C[5] = X[1] * X[6] - X[0] * X[7];
     C[6] = X[1] * X[5] - X[2] * X[4]; C[7] = X[2] * X[3] - X[0] * X[5]; C[8] = X[0] * X[4] - X[1] * X[3];
-    // C = cof(X), column-major like X; X^-T = C / det X
     const double dd = X[0] * C[0] + X[1] * C[1] + X[2] * C[2];
     if (!(fabs(dd) > 1e-300)) break;
     const double inv = 1.0 / dd;
@@ -220,126 +257,129 @@ __device__ void so3_guard(T* R) {
       delta = fmax(delta, fabs(xn - X[i]));
       X[i] = xn;
     }
-    if (delta < 1e-15) break;
+    if (delta < 4e-16) break;
   }
-#pragma unroll
-  for (int i = 0; i < 9; ++i) R[i] = (T)X[i];
+  // Shepperd's method on the (now orthonormal) X; X[3c + r] = R(r, c)
+  const double r00 = X[0], r11 = X[4], r22 = X[8];
+  const double tr = r00 + r11 + r22;
+  double w, x, y, z;
+  if (tr >= r00 && tr >= r11 && tr >= r22) {
+    w = 1.0 + tr; x = X[5] - X[7]; y = X[6] - X[2]; z = X[1] - X[3];
+  } else if (r00 >= r11 && r00 >= r22) {
+    w = X[5] - X[7]; x = 1.0 + r00 - r11 - r22; y = X[3] + X[1]; z = X[6] + X[2];
+  } else if (r11 >= r22) {
+    w = X[6] - X[2]; x = X[3] + X[1]; y = 1.0 - r00 + r11 - r22; z = X[7] + X[5];
+  } else {
+    w = X[1] - X[3]; x = X[6] + X[2]; y = X[7] + X[5]; z = 1.0 - r00 - r11 + r22;
+  }
+  const double inv = 1.0 / sqrt(w * w + x * x + y * y + z * z);
+  q[0] = w * inv; q[1] = x * inv; q[2] = y * inv; q[3] = z * inv;
 }
 
 // ------------------------------------------------------------------------------------
-// Dynamics (quad.py:321-335): z = (v[3], R[9] column-major, W[3]); x' = v is integrated
-// from the stage velocities.  dz depends on (R, W) only.
+// Dynamics (quad.py:321-335) in quaternion form.
 // ------------------------------------------------------------------------------------
 template <typename T>
 struct Dyn {
   T c;           // f/m
-  T A1, A2, A3;  // (J2-J3)/J1, (J3-J1)/J2, (J1-J2)/J3
+  T A1;          // (J2-J3)/J1 with J2 = J1; the W2' coefficient (J3-J1)/J2 is -A1
   T U1, U2, U3;  // M_i / J_i
 };
 
 template <typename T>
-__device__ __forceinline__ void rhs(const T* __restrict__ z, T* __restrict__ k, const Dyn<T>& p) {
-  const T W1 = z[12], W2 = z[13], W3 = z[14];
-  // v' = g e3 - (f/m) b3
-  k[0] = -p.c * z[9];
-  k[1] = -p.c * z[10];
-  k[2] = T(kG) - p.c * z[11];
-  // R' = R hat(W): b1' = W3 b2 - W2 b3 ; b2' = -W3 b1 + W1 b3 ; b3' = W2 b1 - W1 b2
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const T b1 = z[3 + i], b2 = z[6 + i], b3 = z[9 + i];
-    k[3 + i] = W3 * b2 - W2 * b3;
-    k[6 + i] = W1 * b3 - W3 * b1;
-    k[9 + i] = W2 * b1 - W1 * b2;
-  }
-  // W' = J^-1 (-W x JW + M), J diagonal
-  k[12] = p.A1 * W2 * W3 + p.U1;
-  k[13] = p.A2 * W3 * W1 + p.U2;
-  k[14] = p.A3 * W1 * W2 + p.U3;
+__device__ __forceinline__ void rhs(const T* __restrict__ y, T* __restrict__ k, const Dyn<T>& p) {
+  const T qw = y[3], qx = y[4], qy = y[5], qz = y[6];
+  const T W1 = y[7], W2 = y[8], W3 = y[9];
+  // v' = g e3 - (f/m) R e3,  R e3 = (2(xz + wy), 2(yz - wx), 1 - 2(xx + yy))
+  const T c2 = T(2) * p.c;
+  k[0] = -c2 * (qx * qz + qw * qy);
+  k[1] = -c2 * (qy * qz - qw * qx);
+  k[2] = (T(kG) - p.c) + c2 * (qx * qx + qy * qy);
+  // q' = q (0, W) / 2   (<=> R' = R hat(W))
+  const T h = T(0.5);
+  k[3] = -h * (qx * W1 + qy * W2 + qz * W3);
+  k[4] = h * (qw * W1 + qy * W3 - qz * W2);
+  k[5] = h * (qw * W2 + qz * W1 - qx * W3);
+  k[6] = h * (qw * W3 + qx * W2 - qy * W1);
+  // W' = J^-1 (-W x JW + M), J = diag(J1, J1, J3): the (J1 - J2) W1 W2 term of W3' vanishes
+  k[7] = p.A1 * W2 * W3 + p.U1;
+  k[8] = p.U2 - p.A1 * W3 * W1;
+  k[9] = p.U3;
 }
 
 template <typename T>
-__device__ __forceinline__ void rk4_step(T (&y)[18], T h, const Dyn<T>& p) {
-  T* z = &y[3];
-  T k[15], acc[15], zt[15], xs[3];
-  const T h2 = T(0.5) * h, h6 = h / T(6);
-  rhs(z, k, p);
+__device__ __forceinline__ void rk4_step(T (&x)[3], T (&y)[10], T h, const Dyn<T>& p) {
+  T k[10], acc[10], yt[10], xs[3];
+  const T h2 = T(0.5) * h, h6 = h * T(1.0 / 6.0);
+  rhs(y, k, p);
 #pragma unroll
-  for (int i = 0; i < 15; ++i) { acc[i] = k[i]; zt[i] = z[i] + h2 * k[i]; }
+  for (int i = 0; i < 10; ++i) { acc[i] = k[i]; yt[i] = y[i] + h2 * k[i]; }
 #pragma unroll
-  for (int i = 0; i < 3; ++i) xs[i] = z[i];
-  rhs(zt, k, p);
+  for (int i = 0; i < 3; ++i) xs[i] = y[i];
+  rhs(yt, k, p);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) xs[i] += T(2) * zt[i];
+  for (int i = 0; i < 3; ++i) xs[i] += T(2) * yt[i];
 #pragma unroll
-  for (int i = 0; i < 15; ++i) { acc[i] += T(2) * k[i]; zt[i] = z[i] + h2 * k[i]; }
-  rhs(zt, k, p);
+  for (int i = 0; i < 10; ++i) { acc[i] += T(2) * k[i]; yt[i] = y[i] + h2 * k[i]; }
+  rhs(yt, k, p);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) xs[i] += T(2) * zt[i];
+  for (int i = 0; i < 3; ++i) xs[i] += T(2) * yt[i];
 #pragma unroll
-  for (int i = 0; i < 15; ++i) { acc[i] += T(2) * k[i]; zt[i] = z[i] + h * k[i]; }
-  rhs(zt, k, p);
+  for (int i = 0; i < 10; ++i) { acc[i] += T(2) * k[i]; yt[i] = y[i] + h * k[i]; }
+  rhs(yt, k, p);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) y[i] += h6 * (xs[i] + zt[i]);
+  for (int i = 0; i < 3; ++i) x[i] += h6 * (xs[i] + yt[i]);
 #pragma unroll
-  for (int i = 0; i < 15; ++i) z[i] += h6 * (acc[i] + k[i]);
+  for (int i = 0; i < 10; ++i) y[i] += h6 * (acc[i] + k[i]);
+}
+
+// The flow keeps |q| = 1; RK4 only to truncation order.  Restore it to first order.
+template <typename T>
+__device__ __forceinline__ void renorm_quat(T* q) {
+  const T r = T(1.5) - T(0.5) * (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] *= r;
 }
 
 // ------------------------------------------------------------------------------------
 // LDS transposes between lane-per-env registers and AoS rows in global memory.
 // The workgroup's rows [first, first+rows) x D floats are contiguous in global memory.
 // ------------------------------------------------------------------------------------
-template <int D>
+template <int B, int D>
 __device__ __forceinline__ void store_rows(float* __restrict__ gbase, const float (&vals)[D], float* smem, int tid, int rows) {
 #pragma unroll
   for (int j = 0; j < D; ++j) smem[tid * D + j] = vals[j];
   __syncthreads();
-  const int total = rows * D;
-  if (rows == kBlock && (reinterpret_cast<uintptr_t>(gbase) & 15u) == 0) {
-    constexpr int nvec = kBlock * D / 4;  // kBlock is a multiple of 4
+  if (rows == B && (reinterpret_cast<uintptr_t>(gbase) & 15u) == 0) {
+    constexpr int nvec = B * D / 4;  // B is a multiple of 4
     const float4* s4 = reinterpret_cast<const float4*>(smem);
     float4* g4 = reinterpret_cast<float4*>(gbase);
 #pragma unroll
-    for (int idx = tid; idx < nvec; idx += kBlock) g4[idx] = s4[idx];
+    for (int idx = tid; idx < nvec; idx += B) g4[idx] = s4[idx];
   } else {
-    for (int idx = tid; idx < total; idx += kBlock) gbase[idx] = smem[idx];
+    const int total = rows * D;
+    for (int idx = tid; idx < total; idx += B) gbase[idx] = smem[idx];
   }
   __syncthreads();
 }
 
-template <int D>
+template <int B, int D>
 __device__ __forceinline__ void load_rows(const float* __restrict__ gbase, float (&vals)[D], float* smem, int tid, int rows) {
-  const int total = rows * D;
-  if (rows == kBlock && (reinterpret_cast<uintptr_t>(gbase) & 15u) == 0) {
-    constexpr int nvec = kBlock * D / 4;
+  if (rows == B && (reinterpret_cast<uintptr_t>(gbase) & 15u) == 0) {
+    constexpr int nvec = B * D / 4;
     float4* s4 = reinterpret_cast<float4*>(smem);
     const float4* g4 = reinterpret_cast<const float4*>(gbase);
 #pragma unroll
-    for (int idx = tid; idx < nvec; idx += kBlock) s4[idx] = g4[idx];
+    for (int idx = tid; idx < nvec; idx += B) s4[idx] = g4[idx];
   } else {
-    for (int idx = tid; idx < total; idx += kBlock) smem[idx] = gbase[idx];
+    const int total = rows * D;
+    for (int idx = tid; idx < total; idx += B) smem[idx] = gbase[idx];
   }
   __syncthreads();
-  if (tid < rows) {
 #pragma unroll
-    for (int j = 0; j < D; ++j) vals[j] = smem[tid * D + j];
-  } else {
-#pragma unroll
-    for (int j = 0; j < D; ++j) vals[j] = 0.f;
-  }
+  for (int j = 0; j < D; ++j) vals[j] = tid < rows ? smem[tid * D + j] : 0.f;
   __syncthreads();
 }
-
-// ------------------------------------------------------------------------------------
-// Per-env working set
-// ------------------------------------------------------------------------------------
-template <typename T>
-struct Work {
-  T y[18];
-  Phys<T> ph;
-  T goal[12];   // xd, vd, b1d, Wd
-  T integ[8];   // eIx, g_x prev, eIb1, g_b prev
-};
 
 template <int KIND> struct KindTraits;
 template <> struct KindTraits<QR_KIND_QUAD>      { static constexpr int A = 4, D0 = 18, D1 = 0, NAG = 1; };
@@ -363,35 +403,35 @@ __device__ __forceinline__ void action_map(const float* a, const Work<T>& w, Dyn
     f = clampT(T(4) * (ph.scale_act * T(a[0]) + ph.avrg_act), T(4) * T(kMinForce), T(4) * ph.max_force);
     if constexpr (KIND == QR_KIND_COUPLED) {
       M1 = T(a[1]); M2 = T(a[2]); M3 = T(a[3]);
-    } else {
+    } else {  // M1 = b1.tau + J3 W3 W2, M2 = b2.tau - J3 W3 W1 from (R, W) at step start
       const T t1 = T(a[1]), t2 = T(a[2]), t3 = T(a[3]);
-      const T* y = w.y;
-      M1 = (y[6] * t1 + y[7] * t2 + y[8] * t3) + ph.J3 * y[17] * y[16];
-      M2 = (y[9] * t1 + y[10] * t2 + y[11] * t3) - ph.J3 * y[17] * y[15];
+      T R[9];
+      quat_to_R(&w.y[3], R);
+      M1 = (R[0] * t1 + R[1] * t2 + R[2] * t3) + ph.J3 * w.y[9] * w.y[8];
+      M2 = (R[3] * t1 + R[4] * t2 + R[5] * t3) - ph.J3 * w.y[9] * w.y[7];
       M3 = T(a[4]);
     }
   }
-  const T J1 = ph.J1, J2 = ph.J1, J3 = ph.J3;  // J2 = J1 (quad.py:383)
-  p.c = f / ph.m;
-  p.A1 = (J2 - J3) / J1; p.A2 = (J3 - J1) / J2; p.A3 = (J1 - J2) / J3;
-  p.U1 = M1 / J1; p.U2 = M2 / J2; p.U3 = M3 / J3;
+  const T iJ1 = recip(ph.J1), iJ3 = recip(ph.J3);
+  p.c = f * recip(ph.m);
+  p.A1 = (ph.J1 - ph.J3) * iJ1;
+  p.U1 = M1 * iJ1; p.U2 = M2 * iJ1; p.U3 = M3 * iJ3;
 }
 
 // get_norm_error_state (quad.py:421-466): fills the float32 observation rows and advances
 // the trapezoid integrators (quad_utils.py:38-63).
 template <int KIND, typename T>
-__device__ __forceinline__ void error_obs(Work<T>& w, const Coeffs& c, float (&o0)[KindTraits<KIND>::D0],
+__device__ __forceinline__ void error_obs(Work<T>& w, const T (&R)[9], const Coeffs& c, float (&o0)[KindTraits<KIND>::D0],
                                           float (&o1)[KindTraits<KIND>::D1 ? KindTraits<KIND>::D1 : 1]) {
-  const T* y = w.y;
-  const T xl = T(c.x_lim), vl = T(c.v_lim), Wl = T(c.W_lim);
+  const T xl = T(c.x_lim), ixl = T(c.inv_x_lim), ivl = T(c.inv_v_lim), iWl = T(c.inv_W_lim);
   T ex[3], ev[3], eW[3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    ex[j] = y[j] / xl - w.goal[j] / xl;
-    ev[j] = y[3 + j] / vl - w.goal[3 + j] / vl;
-    eW[j] = y[15 + j] / Wl - w.goal[9 + j] / Wl;
+  for (int j = 0; j < 3; ++j) {  // x/x_lim - xd/x_lim etc. (quad.py:423-434)
+    ex[j] = w.x[j] * ixl - w.goal[j] * ixl;
+    ev[j] = w.y[j] * ivl - w.goal[3 + j] * ivl;
+    eW[j] = w.y[7 + j] * iWl - w.goal[9 + j] * iWl;
   }
-  const T* b1 = &y[6]; const T* b2 = &y[9]; const T* b3 = &y[12];
+  const T* b1 = &R[0]; const T* b2 = &R[3]; const T* b3 = &R[6];
   const T* b1d = &w.goal[6];
   const T db3 = b1d[0] * b3[0] + b1d[1] * b3[1] + b1d[2] * b3[2];
   T b1c[3];
@@ -400,26 +440,26 @@ __device__ __forceinline__ void error_obs(Work<T>& w, const Coeffs& c, float (&o
   const T sn = -(b1c[0] * b2[0] + b1c[1] * b2[1] + b1c[2] * b2[2]);
   const T cs = b1c[0] * b1[0] + b1c[1] * b1[1] + b1c[2] * b1[2];
   const T eb1 = T(atan2f((float)sn, (float)cs));  // [rad]
-  const T eb1n = eb1 / T(kPi);
+  const T eb1n = eb1 * T(1.0 / kPi);
   // integrators: I += (g_prev + g) dt/2 ; g uses I before the update
-  const T hdt = T(c.dt) / T(2);
+  const T hdt = T(c.dt) * T(0.5);
   T eIxn[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const T g = -T(c.alpha) * w.integ[j] + ex[j] * xl;
     w.integ[j] += (w.integ[3 + j] + g) * hdt;
     w.integ[3 + j] = g;
-    eIxn[j] = clampT(w.integ[j] / T(c.eIx_lim), T(-1), T(1));
+    eIxn[j] = clampT(w.integ[j] * T(c.inv_eIx_lim), T(-1), T(1));
   }
   const T gb = -T(c.beta) * w.integ[6] + eb1n * T(kPi);
   w.integ[6] += (w.integ[7] + gb) * hdt;
   w.integ[7] = gb;
-  const T eIb1n = clampT(w.integ[6] / T(c.eIb1_lim), T(-1), T(1));
+  const T eIb1n = clampT(w.integ[6] * T(c.inv_eIb1_lim), T(-1), T(1));
   if constexpr (KIND == QR_KIND_COUPLED) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) { o0[j] = (float)ex[j]; o0[3 + j] = (float)eIxn[j]; o0[6 + j] = (float)ev[j]; o0[20 + j] = (float)eW[j]; }
 #pragma unroll
-    for (int j = 0; j < 9; ++j) o0[9 + j] = (float)y[6 + j];
+    for (int j = 0; j < 9; ++j) o0[9 + j] = (float)R[j];
     o0[18] = (float)eb1n; o0[19] = (float)eIb1n;
   } else {
 #pragma unroll
@@ -433,35 +473,73 @@ __device__ __forceinline__ void error_obs(Work<T>& w, const Coeffs& c, float (&o
 
 __device__ __forceinline__ float sq3(const float* v) { return v[0] * v[0] + v[1] * v[1] + v[2] * v[2]; }
 __device__ __forceinline__ bool out3(const float* v) { return !(fabsf(v[0]) < 1.0f) || !(fabsf(v[1]) < 1.0f) || !(fabsf(v[2]) < 1.0f); }
-__device__ __forceinline__ float interp01(float r, float rmin) { return clampT((r - rmin) / (-rmin), 0.0f, 1.0f); }
+__device__ __forceinline__ float interp01(float r, float rmin, float inv_nrmin) { return clampT((r - rmin) * inv_nrmin, 0.0f, 1.0f); }
+
+// ---- SoA load / store of the 13-word state ----
+template <typename XV, typename QW, typename T>
+__device__ __forceinline__ void load_state(const Args& a, int64_t i, Work<T>& w) {
+  const XV* pv = reinterpret_cast<const XV*>(a.pos_vel);
+  const QW* ar = reinterpret_cast<const QW*>(a.att_rate);
+  const int64_t N = a.n;
+#pragma unroll
+  for (int f = 0; f < 3; ++f) { w.x[f] = T(pv[(int64_t)f * N + i]); w.y[f] = T(pv[(int64_t)(3 + f) * N + i]); }
+#pragma unroll
+  for (int f = 0; f < 7; ++f) w.y[3 + f] = T(ar[(int64_t)f * N + i]);
+}
+
+template <typename XV, typename QW, typename T>
+__device__ __forceinline__ void store_state(const Args& a, int64_t i, const Work<T>& w) {
+  XV* pv = reinterpret_cast<XV*>(a.pos_vel);
+  QW* ar = reinterpret_cast<QW*>(a.att_rate);
+  const int64_t N = a.n;
+#pragma unroll
+  for (int f = 0; f < 3; ++f) { pv[(int64_t)f * N + i] = (XV)w.x[f]; pv[(int64_t)(3 + f) * N + i] = (XV)w.y[f]; }
+#pragma unroll
+  for (int f = 0; f < 7; ++f) ar[(int64_t)f * N + i] = (QW)w.y[3 + f];
+}
+
+template <typename T>
+__device__ __forceinline__ void idle_work(Work<T>& w) {  // lanes past the ragged tail
+#pragma unroll
+  for (int f = 0; f < 3; ++f) w.x[f] = T(0);
+#pragma unroll
+  for (int f = 0; f < 10; ++f) w.y[f] = T(f == 3 ? 1 : 0);
+#pragma unroll
+  for (int f = 0; f < 12; ++f) w.goal[f] = T(f == 6 ? 1 : 0);
+#pragma unroll
+  for (int f = 0; f < 8; ++f) w.integ[f] = T(0);
+  w.ph.nominal();
+}
 
 // ------------------------------------------------------------------------------------
 // The fused step / rollout kernel
 // ------------------------------------------------------------------------------------
-template <int KIND, typename T>
-__global__ __launch_bounds__(kBlock) void step_kernel(const Args a) {
+template <int KIND, typename XV, typename QW, int B>
+__global__ __launch_bounds__(B) void step_kernel(const Args a) {
+  using T = QW;  // arithmetic type
   using KT = KindTraits<KIND>;
   constexpr int A = KT::A, D0 = KT::D0, D1 = KT::D1 ? KT::D1 : 1, NAG = KT::NAG;
-  __shared__ __attribute__((aligned(16))) float smem[kBlock * (D0 > A ? D0 : A)];
+  __shared__ __attribute__((aligned(16))) float smem[B * (D0 > A ? D0 : A)];
   const int tid = threadIdx.x;
-  const int64_t first = (int64_t)blockIdx.x * kBlock;
+  const int64_t first = (int64_t)blockIdx.x * B;
   const int64_t i = first + tid;
   const int64_t N = a.n;
-  const int rows = (int)((N - first) < kBlock ? (N - first) : kBlock);
+  const int rows = (int)((N - first) < B ? (N - first) : B);
   const bool active = tid < rows;
   const Coeffs& c = a.c;
+#if QR_ABLATE == 1  // measurement build: launch floor only
+  return;
+#endif
 
   Work<T> w;
   // ---- load the env's working set (SoA, lane-contiguous) ----
-  const T* st = reinterpret_cast<const T*>(a.state);
   if (active) {
-#pragma unroll
-    for (int f = 0; f < 18; ++f) w.y[f] = st[(int64_t)f * N + i];
+    load_state<XV, QW, T>(a, i, w);
     if (a.params) {
       w.ph.m = T(a.params[i]); w.ph.d = T(a.params[N + i]); w.ph.J1 = T(a.params[2 * N + i]);
       w.ph.J3 = T(a.params[3 * N + i]); w.ph.ctf = T(a.params[4 * N + i]); w.ph.ctw = T(a.params[5 * N + i]);
     } else {
-      w.ph.m = T(kMnom); w.ph.d = T(kDnom); w.ph.J1 = T(kJ1nom); w.ph.J3 = T(kJ3nom); w.ph.ctf = T(kCtfNom); w.ph.ctw = T(kCtwNom);
+      w.ph.nominal();
     }
     if (a.goal) {
 #pragma unroll
@@ -475,17 +553,10 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Args a) {
       for (int f = 0; f < 8; ++f) w.integ[f] = T(a.integ[(int64_t)f * N + i]);
     }
   } else {
-#pragma unroll
-    for (int f = 0; f < 18; ++f) w.y[f] = T((f == 6 || f == 10 || f == 14) ? 1 : 0);
-    w.ph.m = T(kMnom); w.ph.d = T(kDnom); w.ph.J1 = T(kJ1nom); w.ph.J3 = T(kJ3nom); w.ph.ctf = T(kCtfNom); w.ph.ctw = T(kCtwNom);
-#pragma unroll
-    for (int f = 0; f < 12; ++f) w.goal[f] = T(f == 6 ? 1 : 0);
-#pragma unroll
-    for (int f = 0; f < 8; ++f) w.integ[f] = T(0);
+    idle_work(w);
   }
   w.ph.derive();
   int32_t steps = (a.steps && active) ? a.steps[i] : 0;
-  int32_t episode = (a.episode && active) ? a.episode[i] : 0;
   bool params_dirty = false;
 
   for (int t = 0; t < a.n_steps; ++t) {
@@ -500,73 +571,79 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Args a) {
         act[0] = act[1] = act[2] = act[3] = 0.f;
       }
     } else {
-      load_rows<A>(abase, act, smem, tid, rows);
+      load_rows<B, A>(abase, act, smem, tid, rows);
     }
 
-    // ---- state_decomposition at step start: ensure_SO3 (quad_utils.py:12-16) ----
-    so3_guard(&w.y[6]);
-
+#if QR_ABLATE == 2  // measurement build: memory traffic only (no integration)
+    w.x[0] += T(act[0]);
+#else
     // ---- action_wrapper ----
     Dyn<T> dyn;
     action_map<KIND, T>(act, w, dyn);
-
     // ---- observation_wrapper: integrate over dt with zero-order-hold (f, M) ----
-    const T h = T(c.dt) / T(a.substeps);
-    for (int s = 0; s < a.substeps; ++s) rk4_step(w.y, h, dyn);
-    newton_schulz(&w.y[6]);
+    const T h = T(c.dt / (double)a.substeps);
+    for (int s = 0; s < a.substeps; ++s) rk4_step(w.x, w.y, h, dyn);
+    renorm_quat(&w.y[3]);
+    // x, v take their storage precision at every env-step boundary, so that a K-step rollout
+    // (state kept in registers) is bit-identical to K single-step launches
+    if constexpr (!std::is_same<XV, T>::value) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { w.x[j] = T((XV)w.x[j]); w.y[j] = T((XV)w.y[j]); }
+    }
+#endif
 
     // ---- obs / reward / done ----
+    T R[9];
+    quat_to_R(&w.y[3], R);
     float o0[D0];
     float o1[D1];
     float rraw[NAG], rwd[NAG];
     bool dn[NAG];
     if constexpr (KIND == QR_KIND_QUAD) {
-      const T* y = w.y;
       // reward_wrapper (quad.py:274-298)
       T eX2 = 0, eV2 = 0, W2 = 0;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const T dx = y[j] - w.goal[j], dv = y[3 + j] - w.goal[3 + j];
-        eX2 += dx * dx; eV2 += dv * dv; W2 += y[15 + j] * y[15 + j];
+        const T dx = w.x[j] - w.goal[j], dv = w.y[j] - w.goal[3 + j];
+        eX2 += dx * dx; eV2 += dv * dv; W2 += w.y[7 + j] * w.y[7 + j];
       }
-      // eb1 = signed angle from b1d to b1_proj = (R00, R10, 0)/hypot  (quad_utils.py:97-101,157-177)
-      const T hy = sqrt(y[6] * y[6] + y[7] * y[7]);
-      const T cux = hy > T(0) ? y[6] / hy : T(1), cuy = hy > T(0) ? y[7] / hy : T(0);
-      const T dn_ = sqrt(w.goal[6] * w.goal[6] + w.goal[7] * w.goal[7] + w.goal[8] * w.goal[8]);
-      const T dux = w.goal[6] / dn_, duy = w.goal[7] / dn_, duz = w.goal[8] / dn_;
-      const T dot = dux * cux + duy * cuy;
-      const T cz = dux * cuy - duy * cux;
-      const T sabs = sqrt(duz * duz + cz * cz);  // |du x cu|
-      float ang = atan2f((float)sabs, (float)dot);  // = acos(clip(dot)) for unit vectors
+      // eb1 = signed angle from b1d to b1_proj ~ (R00, R10, 0) (quad_utils.py:97-101,157-177).
+      // acos(du.cu) with the sign of (du x cu)_z == atan2(|du x cu|, du.cu), which is invariant
+      // to the lengths of both vectors, so neither is normalised.
+      const T dot = w.goal[6] * R[0] + w.goal[7] * R[1];
+      const T cz = w.goal[6] * R[1] - w.goal[7] * R[0];
+      const T hy2 = R[0] * R[0] + R[1] * R[1];
+      const float sabs = sqrtf((float)(w.goal[8] * w.goal[8] * hy2 + cz * cz));
+      float ang = atan2f(sabs, (float)dot);
       if (cz < T(0)) ang = -ang;
-      const T eb1 = T(ang) / T(kPi);
+      const T eb1 = T(ang) * T(1.0 / kPi);
       const T r = -T(c.Cx) * eX2 - T(c.Cb1) * fabs(eb1) - T(c.Cv) * eV2 - T(c.CW) * W2;
       rraw[0] = (float)r;
-      rwd[0] = (float)clampT((r - T(c.rmin_mono)) / (-T(c.rmin_mono)), T(0), T(1));
+      rwd[0] = (float)clampT((r - T(c.rmin_mono)) * T(c.inv_nrmin_mono), T(0), T(1));
       // done_wrapper (quad.py:301-318): roll = atan2(R21,R22), pitch = -asin(R20)
       bool d = false;
 #pragma unroll
       for (int j = 0; j < 3; ++j)
-        d = d || !(fabs(y[j]) < T(c.x_lim)) || !(fabs(y[3 + j]) < T(c.v_lim)) || !(fabs(y[15 + j]) < T(c.W_lim));
-      d = d || !(fabs(y[8]) < T(c.sin_euler_lim));               // |pitch| >= lim
-      d = d || !(fabs(y[11]) < T(c.tan_euler_lim) * y[14]);      // |atan2(R21,R22)| >= lim
+        d = d || !(fabs(w.x[j]) < T(c.x_lim)) || !(fabs(w.y[j]) < T(c.v_lim)) || !(fabs(w.y[7 + j]) < T(c.W_lim));
+      d = d || !(fabs(R[2]) < T(c.sin_euler_lim));           // |pitch| >= lim
+      d = d || !(fabs(R[5]) < T(c.tan_euler_lim) * R[8]);    // |atan2(R21,R22)| >= lim
       dn[0] = d;
-#pragma unroll
-      for (int j = 0; j < 18; ++j) o0[j] = (float)y[j];
     } else {
-      error_obs<KIND, T>(w, c, o0, o1);
+      error_obs<KIND, T>(w, R, c, o0, o1);
+#pragma unroll
+      for (int f = 0; f < 8; ++f) w.integ[f] = T((float)w.integ[f]);  // storage precision (see x, v above)
       if constexpr (KIND == QR_KIND_COUPLED) {  // coupled:78-110, float32 arithmetic on the float32 obs
         const float r = -(float)c.Cx * sq3(&o0[0]) + -(float)c.CIx * sq3(&o0[3]) + -(float)c.Cv * sq3(&o0[6]) +
                         -(float)c.Cb1 * fabsf(o0[18]) + -(float)c.CIb1 * (o0[19] * o0[19]) + -(float)c.CW * sq3(&o0[20]);
         rraw[0] = r;
-        rwd[0] = interp01(r, (float)c.rmin_mono);
+        rwd[0] = interp01(r, (float)c.rmin_mono, (float)c.inv_nrmin_mono);
         dn[0] = out3(&o0[0]) || out3(&o0[6]) || out3(&o0[20]);
       } else {  // decoupled:92-140
         const float r1 = -(float)c.Cx * sq3(&o0[0]) + -(float)c.CIx * sq3(&o0[3]) + -(float)c.Cv * sq3(&o0[6]) +
                          -(float)c.Cw12 * sq3(&o0[12]);
         const float r2 = -(float)c.Cb1 * fabsf(o1[0]) + -(float)c.CIb1 * (o1[1] * o1[1]) + -(float)c.CW3 * (o1[2] * o1[2]);
-        rraw[0] = r1; rraw[1] = r2;
-        rwd[0] = interp01(r1, (float)c.rmin_1); rwd[1] = interp01(r2, (float)c.rmin_2);
+        rraw[0] = r1; rraw[NAG - 1] = r2;
+        rwd[0] = interp01(r1, (float)c.rmin_1, (float)c.inv_nrmin_1); rwd[NAG - 1] = interp01(r2, (float)c.rmin_2, (float)c.inv_nrmin_2);
         dn[0] = out3(&o0[0]) || out3(&o0[6]) || out3(&o0[12]);
         dn[NAG - 1] = !(fabsf(o1[2]) < 1.0f);
       }
@@ -578,45 +655,51 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Args a) {
 
     // ---- time limit + auto-reset ----
     steps += 1;
-    bool trunc = a.max_episode_steps > 0 && steps >= a.max_episode_steps;
+    const bool trunc = a.max_episode_steps > 0 && steps >= a.max_episode_steps;
     bool any_done = trunc;
 #pragma unroll
     for (int g = 0; g < NAG; ++g) any_done = any_done || dn[g];
     if ((a.flags & QR_FLAG_AUTO_RESET) && any_done && active) {
-      episode += 1;
+      const int32_t episode = a.episode[i] + 1;  // touched only by the (rare) resetting lanes
+      a.episode[i] = episode;
       const bool eval = (a.flags & QR_FLAG_EVAL_RESET) != 0;
       const bool randomise = !eval && !(a.flags & QR_FLAG_NO_UDM) && a.params != nullptr;
-      if (a.params != nullptr) {
-        sample_reset(w.y, w.ph, randomise, eval, c, a.seed, (uint64_t)(a.env_offset + i), (uint32_t)episode);
-        params_dirty = true;
-      } else {
-        Phys<T> keep = w.ph;
-        sample_reset(w.y, w.ph, false, eval, c, a.seed, (uint64_t)(a.env_offset + i), (uint32_t)episode);
-        w.ph = keep;
-      }
+      const Phys<T> keep = w.ph;
+      sample_reset(w, randomise, eval, c, a.seed, (uint64_t)(a.env_offset + i), (uint32_t)episode);
+      if (a.params != nullptr) params_dirty = true; else w.ph = keep;
       steps = 0;
-      if constexpr (KIND == QR_KIND_QUAD) {
-#pragma unroll
-        for (int j = 0; j < 18; ++j) o0[j] = (float)w.y[j];
-      } else {
+      quat_to_R(&w.y[3], R);
+      if constexpr (KIND != QR_KIND_QUAD) {
 #pragma unroll
         for (int f = 0; f < 8; ++f) w.integ[f] = T(0);
-        error_obs<KIND, T>(w, c, o0, o1);  // first observation of the new episode (main.py:226-230)
+        error_obs<KIND, T>(w, R, c, o0, o1);  // first observation of the new episode (main.py:226-230)
+#pragma unroll
+        for (int f = 0; f < 8; ++f) w.integ[f] = T((float)w.integ[f]);
       }
     }
 
     // ---- outputs of step t ----
     const int64_t row0 = (int64_t)t * N + first;
-    if (KIND != QR_KIND_QUAD || a.obs0 != nullptr) store_rows<D0>(a.obs0 + row0 * D0, o0, smem, tid, rows);
-    if constexpr (KT::D1 > 0) store_rows<D1>(a.obs1 + row0 * D1, o1, smem, tid, rows);
+    if constexpr (KIND == QR_KIND_QUAD) {
+      if (a.obs0 != nullptr) {  // next state in the reference's order (x, v, vec_F(R), W)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { o0[j] = (float)w.x[j]; o0[3 + j] = (float)w.y[j]; o0[15 + j] = (float)w.y[7 + j]; }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) o0[6 + j] = (float)R[j];
+        store_rows<B, D0>(a.obs0 + row0 * D0, o0, smem, tid, rows);
+      }
+    } else {
+      store_rows<B, D0>(a.obs0 + row0 * D0, o0, smem, tid, rows);
+    }
+    if constexpr (KT::D1 > 0) store_rows<B, D1>(a.obs1 + row0 * D1, o1, smem, tid, rows);
     if (active) {
       if constexpr (NAG == 1) {
         a.reward[row0 + tid] = rwd[0];
         if (a.reward_raw) a.reward_raw[row0 + tid] = rraw[0];
         a.done[row0 + tid] = dn[0] ? 1 : 0;
       } else {
-        reinterpret_cast<float2*>(a.reward)[row0 + tid] = make_float2(rwd[0], rwd[1]);
-        if (a.reward_raw) reinterpret_cast<float2*>(a.reward_raw)[row0 + tid] = make_float2(rraw[0], rraw[1]);
+        reinterpret_cast<float2*>(a.reward)[row0 + tid] = make_float2(rwd[0], rwd[NAG - 1]);
+        if (a.reward_raw) reinterpret_cast<float2*>(a.reward_raw)[row0 + tid] = make_float2(rraw[0], rraw[NAG - 1]);
         reinterpret_cast<uchar2*>(a.done)[row0 + tid] = make_uchar2(dn[0] ? 1 : 0, dn[NAG - 1] ? 1 : 0);
       }
       if (a.truncated) a.truncated[row0 + tid] = trunc ? 1 : 0;
@@ -625,50 +708,50 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Args a) {
 
   // ---- write the working set back ----
   if (active) {
-    T* sto = reinterpret_cast<T*>(a.state);
-#pragma unroll
-    for (int f = 0; f < 18; ++f) sto[(int64_t)f * N + i] = w.y[f];
+    store_state<XV, QW, T>(a, i, w);
     if (KIND != QR_KIND_QUAD) {
 #pragma unroll
       for (int f = 0; f < 8; ++f) a.integ[(int64_t)f * N + i] = (float)w.integ[f];
     }
     if (a.steps) a.steps[i] = steps;
-    if (a.flags & QR_FLAG_AUTO_RESET) {
-      if (a.episode) a.episode[i] = episode;
-      if (params_dirty) {
-        a.params[i] = (float)w.ph.m; a.params[N + i] = (float)w.ph.d; a.params[2 * N + i] = (float)w.ph.J1;
-        a.params[3 * N + i] = (float)w.ph.J3; a.params[4 * N + i] = (float)w.ph.ctf; a.params[5 * N + i] = (float)w.ph.ctw;
-      }
+    if (params_dirty) {
+      a.params[i] = (float)w.ph.m; a.params[N + i] = (float)w.ph.d; a.params[2 * N + i] = (float)w.ph.J1;
+      a.params[3 * N + i] = (float)w.ph.J3; a.params[4 * N + i] = (float)w.ph.ctf; a.params[5 * N + i] = (float)w.ph.ctw;
     }
   }
 }
 
 // get_norm_error_state on the current state (quad.py:421-466)
-template <int KIND, typename T>
-__global__ __launch_bounds__(kBlock) void error_obs_kernel(const Args a) {
+template <int KIND, typename XV, typename QW>
+__global__ __launch_bounds__(64) void error_obs_kernel(const Args a) {
+  using T = QW;
   using KT = KindTraits<KIND>;
-  constexpr int D0 = KT::D0, D1 = KT::D1 ? KT::D1 : 1;
-  __shared__ __attribute__((aligned(16))) float smem[kBlock * D0];
+  constexpr int B = 64, D0 = KT::D0, D1 = KT::D1 ? KT::D1 : 1;
+  __shared__ __attribute__((aligned(16))) float smem[B * D0];
   const int tid = threadIdx.x;
-  const int64_t first = (int64_t)blockIdx.x * kBlock;
+  const int64_t first = (int64_t)blockIdx.x * B;
   const int64_t i = first + tid;
   const int64_t N = a.n;
-  const int rows = (int)((N - first) < kBlock ? (N - first) : kBlock);
+  const int rows = (int)((N - first) < B ? (N - first) : B);
   const bool active = tid < rows;
   Work<T> w;
-  const T* st = reinterpret_cast<const T*>(a.state);
+  idle_work(w);
+  if (active) {
+    load_state<XV, QW, T>(a, i, w);
+    if (a.goal) {
 #pragma unroll
-  for (int f = 0; f < 18; ++f) w.y[f] = active ? st[(int64_t)f * N + i] : T((f == 6 || f == 10 || f == 14) ? 1 : 0);
+      for (int f = 0; f < 12; ++f) w.goal[f] = T(a.goal[(int64_t)f * N + i]);
+    }
 #pragma unroll
-  for (int f = 0; f < 12; ++f) w.goal[f] = (active && a.goal) ? T(a.goal[(int64_t)f * N + i]) : T(f == 6 ? 1 : 0);
-#pragma unroll
-  for (int f = 0; f < 8; ++f) w.integ[f] = active ? T(a.integ[(int64_t)f * N + i]) : T(0);
-  so3_guard(&w.y[6]);  // state_normalization -> ensure_SO3 (quad_utils.py:20-26)
+    for (int f = 0; f < 8; ++f) w.integ[f] = T(a.integ[(int64_t)f * N + i]);
+  }
+  T R[9];
+  quat_to_R(&w.y[3], R);
   float o0[D0];
   float o1[D1];
-  error_obs<KIND, T>(w, a.c, o0, o1);
-  store_rows<D0>(a.obs0 + first * D0, o0, smem, tid, rows);
-  if constexpr (KT::D1 > 0) store_rows<D1>(a.obs1 + first * D1, o1, smem, tid, rows);
+  error_obs<KIND, T>(w, R, a.c, o0, o1);
+  store_rows<B, D0>(a.obs0 + first * D0, o0, smem, tid, rows);
+  if constexpr (KT::D1 > 0) store_rows<B, D1>(a.obs1 + first * D1, o1, smem, tid, rows);
   if (active) {
 #pragma unroll
     for (int f = 0; f < 8; ++f) a.integ[(int64_t)f * N + i] = (float)w.integ[f];
@@ -676,24 +759,22 @@ __global__ __launch_bounds__(kBlock) void error_obs_kernel(const Args a) {
 }
 
 // QuadEnv.reset for masked envs
-template <typename T>
-__global__ __launch_bounds__(kBlock) void reset_kernel(const Args a) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+template <typename XV, typename QW>
+__global__ __launch_bounds__(64) void reset_kernel(const Args a) {
+  using T = QW;
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const int64_t N = a.n;
   if (i >= N) return;
   if (a.mask && !a.mask[i]) return;
   const int32_t episode = a.episode[i] + 1;
   const bool eval = (a.flags & QR_FLAG_EVAL_RESET) != 0;
   const bool randomise = !eval && !(a.flags & QR_FLAG_NO_UDM);
-  T y[18];
-  Phys<T> ph;
-  sample_reset(y, ph, randomise, eval, a.c, a.seed, (uint64_t)(a.env_offset + i), (uint32_t)episode);
-  T* sto = reinterpret_cast<T*>(a.state);
-#pragma unroll
-  for (int f = 0; f < 18; ++f) sto[(int64_t)f * N + i] = y[f];
+  Work<T> w;
+  sample_reset(w, randomise, eval, a.c, a.seed, (uint64_t)(a.env_offset + i), (uint32_t)episode);
+  store_state<XV, QW, T>(a, i, w);
   if (a.params) {
-    a.params[i] = (float)ph.m; a.params[N + i] = (float)ph.d; a.params[2 * N + i] = (float)ph.J1;
-    a.params[3 * N + i] = (float)ph.J3; a.params[4 * N + i] = (float)ph.ctf; a.params[5 * N + i] = (float)ph.ctw;
+    a.params[i] = (float)w.ph.m; a.params[N + i] = (float)w.ph.d; a.params[2 * N + i] = (float)w.ph.J1;
+    a.params[3 * N + i] = (float)w.ph.J3; a.params[4 * N + i] = (float)w.ph.ctf; a.params[5 * N + i] = (float)w.ph.ctw;
   }
   if (a.integ) {
 #pragma unroll
@@ -701,6 +782,39 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const Args a) {
   }
   if (a.steps) a.steps[i] = 0;
   a.episode[i] = episode;
+}
+
+// get_current_state: 13-word internal state -> the reference's float64 18-vector rows
+template <typename XV, typename QW>
+__global__ __launch_bounds__(64) void get_state_kernel(const Args a) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= a.n) return;
+  Work<double> w;
+  load_state<XV, QW, double>(a, i, w);
+  double R[9];
+  quat_to_R(&w.y[3], R);
+  double* o = a.rows_out + i * 18;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { o[j] = w.x[j]; o[3 + j] = w.y[j]; o[15 + j] = w.y[7 + j]; }
+#pragma unroll
+  for (int j = 0; j < 9; ++j) o[6 + j] = R[j];
+}
+
+// state injection: float64 18-vector rows -> 13-word internal state (R -> nearest rotation -> q)
+template <typename XV, typename QW>
+__global__ __launch_bounds__(64) void set_state_kernel(const Args a) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= a.n) return;
+  if (a.mask && !a.mask[i]) return;
+  const double* r = a.rows_in + i * 18;
+  Work<double> w;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { w.x[j] = r[j]; w.y[j] = r[3 + j]; w.y[7 + j] = r[15 + j]; }
+  double q[4];
+  R_to_quat(r + 6, q);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w.y[3 + j] = q[j];
+  store_state<XV, QW, double>(a, i, w);
 }
 
 // ------------------------------------------------------------------------------------
@@ -715,15 +829,18 @@ static void fill_coeffs(Coeffs& o, const QrCoeffs& q) {
   o.rmin_mono = -ceil(q.Cx + q.CIx + q.Cv + q.Cb1 + q.CIb1 + q.CW);  // quad.py:81
   o.rmin_1 = -ceil(q.Cx + q.CIx + q.Cv + q.Cw12);                    // quad.py:85
   o.rmin_2 = -ceil(q.Cb1 + q.CW3 + q.CIb1);                          // quad.py:88
+  o.inv_x_lim = 1.0 / q.x_lim; o.inv_v_lim = 1.0 / q.v_lim; o.inv_W_lim = 1.0 / q.W_lim;
+  o.inv_eIx_lim = 1.0 / q.eIx_lim; o.inv_eIb1_lim = 1.0 / q.eIb1_lim;
+  o.inv_nrmin_mono = -1.0 / o.rmin_mono; o.inv_nrmin_1 = -1.0 / o.rmin_1; o.inv_nrmin_2 = -1.0 / o.rmin_2;
 }
 
 static int fill_env(Args& a, const QrEnv* e) {
   if (!e) return QR_E_NULL;
-  if (e->kind < 0 || e->kind > 2) return QR_E_KIND;
+  if (e->kind < 0 || e->kind > 2 || e->layout < 0 || e->layout > 2) return QR_E_KIND;
   if (e->num_envs < 0) return QR_E_SIZE;
-  if (!e->state) return QR_E_NULL;
-  if (reinterpret_cast<uintptr_t>(e->state) & 15u) return QR_E_ALIGN;
-  a.state = e->state; a.integ = e->integ; a.params = e->params; a.goal = e->goal;
+  if (!e->pos_vel || !e->att_rate) return QR_E_NULL;
+  if ((reinterpret_cast<uintptr_t>(e->pos_vel) | reinterpret_cast<uintptr_t>(e->att_rate)) & 15u) return QR_E_ALIGN;
+  a.pos_vel = e->pos_vel; a.att_rate = e->att_rate; a.integ = e->integ; a.params = e->params; a.goal = e->goal;
   a.episode = e->episode; a.steps = e->steps;
   a.n = e->num_envs; a.env_offset = e->env_offset; a.seed = e->seed;
   a.max_episode_steps = e->max_episode_steps; a.flags = e->flags;
@@ -731,16 +848,54 @@ static int fill_env(Args& a, const QrEnv* e) {
   return 0;
 }
 
-template <typename T>
+// Workgroup size: one wavefront per workgroup while that still gives <= 4096 workgroups
+// (small batches: every SIMD gets a wave, no cross-wave barriers); 256 threads beyond that,
+// where 64-thread workgroups would be bound by the dispatcher (~3.6 workgroups/ns measured).
+static inline int pick_block(int64_t n) { return n <= 64 * 4096 ? 64 : 256; }
+
+template <int KIND, typename XV, typename QW>
+static void launch_kind(const Args& a, hipStream_t s) {
+  if (pick_block(a.n) == 64) {
+    hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64>), dim3((unsigned)((a.n + 63) / 64)), dim3(64), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 256>), dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a);
+  }
+}
+
+template <typename XV, typename QW>
 static int launch_step(const Args& a, int kind, hipStream_t s) {
-  const unsigned grid = (unsigned)((a.n + kBlock - 1) / kBlock);
-  if (grid == 0) return 0;
+  if (a.n == 0) return 0;
   switch (kind) {
-    case QR_KIND_QUAD: hipLaunchKernelGGL((step_kernel<QR_KIND_QUAD, T>), dim3(grid), dim3(kBlock), 0, s, a); break;
-    case QR_KIND_COUPLED: hipLaunchKernelGGL((step_kernel<QR_KIND_COUPLED, T>), dim3(grid), dim3(kBlock), 0, s, a); break;
-    default: hipLaunchKernelGGL((step_kernel<QR_KIND_DECOUPLED, T>), dim3(grid), dim3(kBlock), 0, s, a); break;
+    case QR_KIND_QUAD: launch_kind<QR_KIND_QUAD, XV, QW>(a, s); break;
+    case QR_KIND_COUPLED: launch_kind<QR_KIND_COUPLED, XV, QW>(a, s); break;
+    default: launch_kind<QR_KIND_DECOUPLED, XV, QW>(a, s); break;
   }
   return (int)hipGetLastError();
+}
+
+#define QR_DISPATCH_LAYOUT(layout, CALL)                                        \
+  switch (layout) {                                                             \
+    case QR_LAYOUT_MIXED: { using XV = float; using QW = double; CALL; } break; \
+    case QR_LAYOUT_F64:   { using XV = double; using QW = double; CALL; } break; \
+    default:              { using XV = float; using QW = float; CALL; } break;  \
+  }
+
+template <typename XV, typename QW>
+static void launch_error_obs(const Args& a, int kind, unsigned grid, hipStream_t s) {
+  if (kind == QR_KIND_COUPLED) hipLaunchKernelGGL((error_obs_kernel<QR_KIND_COUPLED, XV, QW>), dim3(grid), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL((error_obs_kernel<QR_KIND_DECOUPLED, XV, QW>), dim3(grid), dim3(64), 0, s, a);
+}
+template <typename XV, typename QW>
+static void launch_reset(const Args& a, unsigned grid, hipStream_t s) {
+  hipLaunchKernelGGL((reset_kernel<XV, QW>), dim3(grid), dim3(64), 0, s, a);
+}
+template <typename XV, typename QW>
+static void launch_get_state(const Args& a, unsigned grid, hipStream_t s) {
+  hipLaunchKernelGGL((get_state_kernel<XV, QW>), dim3(grid), dim3(64), 0, s, a);
+}
+template <typename XV, typename QW>
+static void launch_set_state(const Args& a, unsigned grid, hipStream_t s) {
+  hipLaunchKernelGGL((set_state_kernel<XV, QW>), dim3(grid), dim3(64), 0, s, a);
 }
 
 static int do_rollout(const QrEnv* env, const float* action, int32_t n_steps, int32_t substeps, const QrStepOut* out, void* stream) {
@@ -756,7 +911,9 @@ static int do_rollout(const QrEnv* env, const float* action, int32_t n_steps, in
   a.reward = out->reward; a.reward_raw = out->reward_raw; a.done = out->done; a.truncated = out->truncated;
   a.n_steps = n_steps; a.substeps = substeps;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  return env->state_f64 ? launch_step<double>(a, env->kind, s) : launch_step<float>(a, env->kind, s);
+  int rc = 0;
+  QR_DISPATCH_LAYOUT(env->layout, (rc = launch_step<XV, QW>(a, env->kind, s)));
+  return rc;
 }
 
 }  // namespace qr
@@ -788,16 +945,10 @@ int qr_error_obs(const QrEnv* env, float* obs0, float* obs1, void* stream) {
   if (env->kind == QR_KIND_QUAD) return QR_E_KIND;
   if (!env->integ || !obs0 || (env->kind == QR_KIND_DECOUPLED && !obs1)) return QR_E_NULL;
   a.obs0 = obs0; a.obs1 = obs1;
-  const unsigned grid = (unsigned)((a.n + qr::kBlock - 1) / qr::kBlock);
+  const unsigned grid = (unsigned)((a.n + 63) / 64);
   if (grid == 0) return 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (env->state_f64) {
-    if (env->kind == QR_KIND_COUPLED) hipLaunchKernelGGL((qr::error_obs_kernel<QR_KIND_COUPLED, double>), dim3(grid), dim3(qr::kBlock), 0, s, a);
-    else hipLaunchKernelGGL((qr::error_obs_kernel<QR_KIND_DECOUPLED, double>), dim3(grid), dim3(qr::kBlock), 0, s, a);
-  } else {
-    if (env->kind == QR_KIND_COUPLED) hipLaunchKernelGGL((qr::error_obs_kernel<QR_KIND_COUPLED, float>), dim3(grid), dim3(qr::kBlock), 0, s, a);
-    else hipLaunchKernelGGL((qr::error_obs_kernel<QR_KIND_DECOUPLED, float>), dim3(grid), dim3(qr::kBlock), 0, s, a);
-  }
+  QR_DISPATCH_LAYOUT(env->layout, (qr::launch_error_obs<XV, QW>(a, env->kind, grid, s)));
   return (int)hipGetLastError();
 }
 
@@ -806,22 +957,46 @@ int qr_reset(const QrEnv* env, const uint8_t* mask, void* stream) {
   if (int rc = qr::fill_env(a, env)) return rc;
   if (!env->episode) return QR_E_NULL;
   a.mask = mask;
-  const unsigned grid = (unsigned)((a.n + qr::kBlock - 1) / qr::kBlock);
+  const unsigned grid = (unsigned)((a.n + 63) / 64);
   if (grid == 0) return 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (env->state_f64) hipLaunchKernelGGL((qr::reset_kernel<double>), dim3(grid), dim3(qr::kBlock), 0, s, a);
-  else hipLaunchKernelGGL((qr::reset_kernel<float>), dim3(grid), dim3(qr::kBlock), 0, s, a);
+  QR_DISPATCH_LAYOUT(env->layout, (qr::launch_reset<XV, QW>(a, grid, s)));
   return (int)hipGetLastError();
 }
 
-const char* qr_step_kernel_info(int32_t kind, int32_t state_f64, int64_t num_envs, int32_t* grid, int32_t* block) {
-  if (grid) *grid = (int32_t)((num_envs + qr::kBlock - 1) / qr::kBlock);
-  if (block) *block = qr::kBlock;
-  (void)state_f64;
+int qr_get_state(const QrEnv* env, double* rows, void* stream) {
+  qr::Args a{};
+  if (int rc = qr::fill_env(a, env)) return rc;
+  if (!rows) return QR_E_NULL;
+  a.rows_out = rows;
+  const unsigned grid = (unsigned)((a.n + 63) / 64);
+  if (grid == 0) return 0;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  QR_DISPATCH_LAYOUT(env->layout, (qr::launch_get_state<XV, QW>(a, grid, s)));
+  return (int)hipGetLastError();
+}
+
+int qr_set_state(const QrEnv* env, const double* rows, const uint8_t* mask, void* stream) {
+  qr::Args a{};
+  if (int rc = qr::fill_env(a, env)) return rc;
+  if (!rows) return QR_E_NULL;
+  a.rows_in = rows; a.mask = mask;
+  const unsigned grid = (unsigned)((a.n + 63) / 64);
+  if (grid == 0) return 0;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  QR_DISPATCH_LAYOUT(env->layout, (qr::launch_set_state<XV, QW>(a, grid, s)));
+  return (int)hipGetLastError();
+}
+
+const char* qr_step_kernel_info(int32_t kind, int32_t layout, int64_t num_envs, int32_t* grid, int32_t* block) {
+  const int b = qr::pick_block(num_envs);
+  if (grid) *grid = (int32_t)((num_envs + b - 1) / b);
+  if (block) *block = b;
+  (void)layout;
   switch (kind) {
-    case QR_KIND_QUAD: return "qr::step_kernel<0>";
-    case QR_KIND_COUPLED: return "qr::step_kernel<1>";
-    case QR_KIND_DECOUPLED: return "qr::step_kernel<2>";
+    case QR_KIND_QUAD: return "qr::step_kernel<0,...>";
+    case QR_KIND_COUPLED: return "qr::step_kernel<1,...>";
+    case QR_KIND_DECOUPLED: return "qr::step_kernel<2,...>";
     default: return "";
   }
 }

@@ -37,28 +37,35 @@ class QuadVecEnv:
     kind            'quad' | 'coupled' | 'decoupled'  (MONO: coupled, MODUL: decoupled)
     num_envs        N envs owned by this object (this GPU's shard)
     substeps        fixed RK4 substeps per env-step replacing solve_ivp(DOP853) (quad.py:265)
-    state_dtype     torch.float64 (default; parity mode) or torch.float32
+    layout          internal state precision (the state is 13 words: x, v, unit quaternion q, W):
+                    'mixed' (default) x,v float32 + q,W float64, float64 arithmetic;
+                    'f64' all float64; 'f32' all float32 (fast, outside the 1e-5 parity bar)
     use_UDM         per-env domain randomisation at reset (quad.py:359-404)
     auto_reset      re-sample terminated/truncated envs inside the step launch; the returned
                     observation is then the first observation of the new episode
     max_episode_steps  >0 sets truncated when an episode reaches that many steps
     env_offset      global index of local env 0 (multi-GPU sharding; part of the RNG key)
+    obs_rows        write float32 observation rows [N,D].  Always on for the wrappers.  For
+                    kind='quad' the observation is the next state (quad.py:269-271): True writes
+                    it as float32 [N,18] rows each step; False (default) writes nothing and
+                    step() returns obs=None (use get_current_state() when it is needed)
     """
 
     metadata = {"render_modes": []}
 
     def __init__(self, kind: str = "decoupled", num_envs: int = 1, device="cuda", seed: int = 0,
-                 substeps: int = 2, state_dtype: torch.dtype = torch.float64, use_UDM: bool = True,
+                 substeps: int = 1, layout: str = "mixed", use_UDM: bool = True,
                  UDM_percentage: float = 10.0, auto_reset: bool = False, max_episode_steps: int = 0,
-                 env_offset: int = 0, want_raw_reward: bool = False, constants: Optional[QuadConstants] = None):
+                 env_offset: int = 0, want_raw_reward: bool = False, obs_rows: Optional[bool] = None,
+                 constants: Optional[QuadConstants] = None):
         if kind not in KINDS:
             raise ValueError(f"kind must be one of {KINDS}, got {kind!r}")
         if num_envs < 1:
             raise ValueError("num_envs must be >= 1")
         if substeps < 1:
             raise ValueError("substeps must be >= 1")
-        if state_dtype not in (torch.float64, torch.float32):
-            raise ValueError("state_dtype must be torch.float64 or torch.float32")
+        if layout not in _lib.LAYOUT_ID:
+            raise ValueError(f"layout must be one of {tuple(_lib.LAYOUT_ID)}, got {layout!r}")
         self._lib = _lib.load()  # raises if the HIP library is missing
         if not torch.cuda.is_available():
             raise RuntimeError("QuadVecEnv needs an AMD GPU (torch.cuda.is_available() is False); "
@@ -71,7 +78,7 @@ class QuadVecEnv:
         self.kind, self.num_envs, self.substeps = kind, int(num_envs), int(substeps)
         self.framework = FRAMEWORK[kind]
         self.n_agents, self.action_dim, self.obs_dims = N_AGENTS[kind], ACTION_DIM[kind], OBS_DIMS[kind]
-        self.state_dtype = state_dtype
+        self.layout = layout
         self.use_UDM, self.UDM_percentage = bool(use_UDM), float(UDM_percentage)
         self.auto_reset, self.max_episode_steps = bool(auto_reset), int(max_episode_steps)
         self.env_offset, self.seed = int(env_offset), int(seed)
@@ -99,17 +106,23 @@ class QuadVecEnv:
 
         # ---- device buffers (SoA [field][N]) ----
         N, dev = self.num_envs, self.device
-        self._state = torch.zeros(18, N, dtype=state_dtype, device=dev)
-        self._state[6].fill_(1.0); self._state[10].fill_(1.0); self._state[14].fill_(1.0)
+        xv_dt = torch.float64 if layout == "f64" else torch.float32
+        qw_dt = torch.float32 if layout == "f32" else torch.float64
+        self._pos_vel = torch.zeros(6, N, dtype=xv_dt, device=dev)    # x(3), v(3)
+        self._att_rate = torch.zeros(7, N, dtype=qw_dt, device=dev)   # q(w,x,y,z), W(3)
+        self._att_rate[0].fill_(1.0)
         self._integ = None if kind == "quad" else torch.zeros(8, N, dtype=torch.float32, device=dev)
         self._params = None
         if self.use_UDM:
             self._params = torch.tensor(c.nominal_params, dtype=torch.float32, device=dev)[:, None].repeat(1, N).contiguous()
         self._goal = None  # default hover goal until set_goal_state is called (quad.py:98-101)
         self._episode = torch.zeros(N, dtype=torch.int32, device=dev)
-        self._steps = torch.zeros(N, dtype=torch.int32, device=dev)
+        self._steps = torch.zeros(N, dtype=torch.int32, device=dev) if self.max_episode_steps > 0 else None
         # caller-facing rows
-        self._obs0 = torch.empty(N, self.obs_dims[0], dtype=torch.float32, device=dev)
+        self.obs_rows = (kind != "quad") if obs_rows is None else bool(obs_rows)
+        if kind != "quad" and not self.obs_rows:
+            raise ValueError("obs_rows=False is only meaningful for kind='quad'")
+        self._obs0 = torch.empty(N, self.obs_dims[0], dtype=torch.float32, device=dev) if self.obs_rows else None
         self._obs1 = torch.empty(N, self.obs_dims[1], dtype=torch.float32, device=dev) if len(self.obs_dims) > 1 else None
         self._reward = torch.empty(N, self.n_agents, dtype=torch.float32, device=dev)
         self._reward_raw = torch.empty(N, self.n_agents, dtype=torch.float32, device=dev) if want_raw_reward else None
@@ -131,14 +144,15 @@ class QuadVecEnv:
     # ------------------------------------------------------------------------------
     def _sync_structs(self):
         e, o = self._cenv, self._cout
-        e.kind, e.state_f64 = _lib.KIND_ID[self.kind], int(self.state_dtype == torch.float64)
+        e.kind, e.layout = _lib.KIND_ID[self.kind], _lib.LAYOUT_ID[self.layout]
         e.num_envs, e.env_offset, e.seed = self.num_envs, self.env_offset, self.seed & (2 ** 64 - 1)
-        e.state, e.integ, e.params, e.goal = _ptr(self._state), _ptr(self._integ), _ptr(self._params), _ptr(self._goal)
+        e.pos_vel, e.att_rate = _ptr(self._pos_vel), _ptr(self._att_rate)
+        e.integ, e.params, e.goal = _ptr(self._integ), _ptr(self._params), _ptr(self._goal)
         e.episode, e.steps = _ptr(self._episode), _ptr(self._steps)
         e.max_episode_steps = self.max_episode_steps
         e.flags = (_lib.FLAG_AUTO_RESET if self.auto_reset else 0) | (0 if self.use_UDM else _lib.FLAG_NO_UDM)
         o.obs0, o.obs1, o.reward, o.reward_raw = _ptr(self._obs0), _ptr(self._obs1), _ptr(self._reward), _ptr(self._reward_raw)
-        o.done, o.truncated = _ptr(self._done), _ptr(self._trunc)
+        o.done, o.truncated = _ptr(self._done), (_ptr(self._trunc) if self._steps is not None else None)
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -156,6 +170,8 @@ class QuadVecEnv:
         return actions if actions.is_contiguous() else actions.contiguous()
 
     def _obs(self):
+        if self._obs0 is None:  # kind='quad' without observation rows: fetch with get_current_state()
+            return None
         return self._obs0 if self._obs1 is None else (self._obs0, self._obs1)
 
     # ------------------------------------------------------------------------------
@@ -176,15 +192,16 @@ class QuadVecEnv:
         a = self._check_actions(actions, lead=(T,))
         N, dev = self.num_envs, self.device
         if out is None:
-            out = {"obs0": torch.empty(T, N, self.obs_dims[0], dtype=torch.float32, device=dev),
+            out = {"obs0": torch.empty(T, N, self.obs_dims[0], dtype=torch.float32, device=dev) if self.obs_rows else None,
                    "reward": torch.empty(T, N, self.n_agents, dtype=torch.float32, device=dev),
                    "terminated": torch.zeros(T, N, self.n_agents, dtype=torch.bool, device=dev),
                    "truncated": torch.zeros(T, N, dtype=torch.bool, device=dev)}
             if self._obs1 is not None:
                 out["obs1"] = torch.empty(T, N, self.obs_dims[1], dtype=torch.float32, device=dev)
         o = _lib.QrStepOut()
-        o.obs0, o.obs1, o.reward = _ptr(out["obs0"]), _ptr(out.get("obs1")), _ptr(out["reward"])
-        o.reward_raw, o.done, o.truncated = _ptr(out.get("reward_raw")), _ptr(out["terminated"]), _ptr(out["truncated"])
+        o.obs0, o.obs1, o.reward = _ptr(out.get("obs0")), _ptr(out.get("obs1")), _ptr(out["reward"])
+        o.reward_raw, o.done = _ptr(out.get("reward_raw")), _ptr(out["terminated"])
+        o.truncated = _ptr(out["truncated"]) if self._steps is not None else None
         rc = self._lib.qr_rollout(C.byref(self._cenv), a.data_ptr(), T, self.substeps, C.byref(o), self._stream())
         _lib.check(rc, "qr_rollout")
         out["obs"] = out["obs0"] if self._obs1 is None else (out["obs0"], out["obs1"])
@@ -214,7 +231,7 @@ class QuadVecEnv:
         finally:
             self._cenv.flags = flags
         _lib.check(rc, "qr_reset")
-        return self._state.t().to(torch.float32)
+        return self.get_current_state().to(torch.float32)
 
     def get_norm_error_state(self, framework: Optional[str] = None):
         """quad.py:421-466.  Advances the integral terms (same side effect as the reference)."""
@@ -246,15 +263,20 @@ class QuadVecEnv:
         self._goal[9:12] = self._rows3(np.zeros(3) if Wd is None else Wd, "Wd")
 
     def get_current_state(self) -> torch.Tensor:
-        """quad.py:409-410: the internal state, [N,18] view (x, v, vec_F(R), W)."""
-        return self._state.t()
+        """quad.py:409-410: float64 [N,18] = (x, v, vec_F(R), W), rebuilt from the 13-word
+        internal state (R = R(q)) by a small kernel; a fresh tensor each call."""
+        rows = torch.empty(self.num_envs, 18, dtype=torch.float64, device=self.device)
+        _lib.check(self._lib.qr_get_state(C.byref(self._cenv), rows.data_ptr(), self._stream()), "qr_get_state")
+        return rows
 
-    def set_state(self, state, integ=None, params=None):
-        """Inject states (and optionally integrator terms / parameters): [N,18] / [N,8] / [N,6]."""
-        s = torch.as_tensor(state, device=self.device).to(self.state_dtype)
+    def set_state(self, state, integ=None, params=None, mask=None):
+        """Inject states (and optionally integrator terms / parameters): [N,18] / [N,8] / [N,6].
+        R goes through the reference's ensure_SO3 rule and is stored as a unit quaternion."""
+        s = torch.as_tensor(state, device=self.device).to(torch.float64).contiguous()
         if tuple(s.shape) != (self.num_envs, 18):
             raise ValueError(f"state must be [{self.num_envs}, 18]")
-        self._state.copy_(s.t())
+        m = None if mask is None else torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        _lib.check(self._lib.qr_set_state(C.byref(self._cenv), s.data_ptr(), _ptr(m), self._stream()), "qr_set_state")
         if integ is not None and self._integ is not None:
             self._integ.copy_(torch.as_tensor(integ, device=self.device).to(torch.float32).t())
         if params is not None:
@@ -265,7 +287,7 @@ class QuadVecEnv:
 
     def state_dict(self) -> dict:
         """Checkpoint of everything the env owns (18 + 8 words per env + params/goal/counters)."""
-        keys = ("_state", "_integ", "_params", "_goal", "_episode", "_steps")
+        keys = ("_pos_vel", "_att_rate", "_integ", "_params", "_goal", "_episode", "_steps")
         return {k[1:]: (None if getattr(self, k) is None else getattr(self, k).clone()) for k in keys}
 
     def load_state_dict(self, sd: dict):
@@ -294,7 +316,7 @@ class QuadVecEnv:
 
     def kernel_info(self):
         g, b = C.c_int32(), C.c_int32()
-        name = self._lib.qr_step_kernel_info(_lib.KIND_ID[self.kind], int(self.state_dtype == torch.float64),
+        name = self._lib.qr_step_kernel_info(_lib.KIND_ID[self.kind], _lib.LAYOUT_ID[self.layout],
                                              self.num_envs, C.byref(g), C.byref(b))
         return name.decode(), g.value, b.value
 

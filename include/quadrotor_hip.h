@@ -18,11 +18,18 @@
  *     Caller-facing rows (actions in, observations/reward/done out) are AoS `[N][D]`
  *     row-major, i.e. what a policy network produces/consumes; the kernels transpose
  *     through LDS so that those rows are written with coalesced 16-byte stores.
- *   - state vector order is the reference's (quad.py:146, quad_utils.py:12-16):
- *       f = 0..2 x, 3..5 v, 6..14 vec_F(R) (column-major: b1,b2,b3), 15..17 W.
- *     `state_f64 != 0` selects float64 storage + float64 integrator arithmetic (default;
- *     the reference keeps a float64 state and fp32 storage cannot hold the 1e-5 /
- *     1000-step parity bar); 0 selects float32 storage + arithmetic.
+ *   - INTERNAL STATE (13 words per env instead of the reference's 18): the step is
+ *     HBM/fabric-bound, so the rotation is kept as a unit quaternion, which the kernel
+ *     integrates directly (q' = q (0,W)/2 is the same flow as R' = R hat(W),
+ *     quad.py:328):
+ *         pos_vel  [6][N]  x(3), v(3)
+ *         att_rate [7][N]  q = (w,x,y,z) with R = R(q), W(3)
+ *     The reference's 18-vector (x, v, vec_F(R) column-major, W; quad.py:146,
+ *     quad_utils.py:12-16) is produced / consumed by qr_get_state / qr_set_state.
+ *   - precision (`layout`): QR_LAYOUT_MIXED (default) stores x,v as float32 and q,W as
+ *     float64 and integrates in float64; QR_LAYOUT_F64 stores everything as float64;
+ *     QR_LAYOUT_F32 stores and computes in float32 (fast, NOT inside the 1e-5/1000-step
+ *     parity bar).  See DESIGN.md §4 for the measurements behind this.
  */
 #ifndef QUADROTOR_HIP_H
 #define QUADROTOR_HIP_H
@@ -33,18 +40,23 @@
 extern "C" {
 #endif
 
-#define QR_ABI_VERSION 1
+#define QR_ABI_VERSION 2
 
 /* env kinds */
 #define QR_KIND_QUAD      0 /* QuadEnv            gym_rotor/envs/quad.py:19            */
 #define QR_KIND_COUPLED   1 /* CoupledWrapper     wrappers/coupled_yaw_wrapper.py:11   */
 #define QR_KIND_DECOUPLED 2 /* DecoupledWrapper   wrappers/decoupled_yaw_wrapper.py:12 */
 
+/* state layouts */
+#define QR_LAYOUT_MIXED 0 /* pos_vel float32, att_rate float64, float64 arithmetic */
+#define QR_LAYOUT_F64   1 /* all float64                                           */
+#define QR_LAYOUT_F32   2 /* all float32                                           */
+
 /* argument errors */
-#define QR_E_NULL   (-1) /* a required pointer is NULL        */
-#define QR_E_KIND   (-2) /* kind not in {0,1,2}               */
-#define QR_E_SIZE   (-3) /* num_envs < 0 or substeps < 1      */
-#define QR_E_ALIGN  (-4) /* a buffer is not 16-byte aligned   */
+#define QR_E_NULL   (-1) /* a required pointer is NULL             */
+#define QR_E_KIND   (-2) /* kind / layout out of range             */
+#define QR_E_SIZE   (-3) /* num_envs < 0, substeps < 1, n_steps < 1 */
+#define QR_E_ALIGN  (-4) /* a buffer is not 16-byte aligned        */
 
 /* flags */
 #define QR_FLAG_AUTO_RESET   1u /* re-sample a done env inside the same launch (train distribution) */
@@ -67,27 +79,28 @@ typedef struct QrCoeffs {
 /* Per-env device buffers owned by the caller (the Python env object). */
 typedef struct QrEnv {
   int32_t kind;        /* QR_KIND_*                                                       */
-  int32_t state_f64;   /* 1: state is double[18][N]; 0: float[18][N]                      */
+  int32_t layout;      /* QR_LAYOUT_*                                                     */
   int64_t num_envs;    /* N                                                               */
   int64_t env_offset;  /* global id of local env 0 (multi-GPU shard offset; RNG key)      */
   uint64_t seed;       /* RNG seed; draws depend only on (seed, global env id, episode)   */
-  void*    state;      /* [18][N]   in/out                                                */
-  float*   integ;      /* [8][N]    in/out: eIx(3), g_x prev(3), eIb1, g_b prev (quad_utils.py:38-63); NULL for QUAD */
-  float*   params;     /* [6][N]    m,d,J1(=J2),J3,c_tf,c_tw (quad.py:359-387); NULL = nominal   */
-  float*   goal;       /* [12][N]   xd,vd,b1d,Wd (quad.py:413-418); NULL = hover default  */
-  int32_t* episode;    /* [N]       episode counter (RNG stream id); required for resets  */
-  int32_t* steps;      /* [N]       steps since reset; NULL = no time-limit bookkeeping   */
+  void*    pos_vel;    /* [6][N]  x, v                                         in/out      */
+  void*    att_rate;   /* [7][N]  q(w,x,y,z), W                                in/out      */
+  float*   integ;      /* [8][N]  eIx(3), g_x prev(3), eIb1, g_b prev (quad_utils.py:38-63); NULL for QUAD */
+  float*   params;     /* [6][N]  m,d,J1(=J2),J3,c_tf,c_tw (quad.py:359-387); NULL = nominal */
+  float*   goal;       /* [12][N] xd,vd,b1d,Wd (quad.py:413-418); NULL = hover default     */
+  int32_t* episode;    /* [N]     episode counter (RNG stream id); required for resets     */
+  int32_t* steps;      /* [N]     steps since reset; NULL = no time-limit bookkeeping      */
   int32_t  max_episode_steps; /* >0: truncated[i]=1 when steps reaches it (gym_rotor/__init__.py:3-7) */
   uint32_t flags;      /* QR_FLAG_*                                                       */
   QrCoeffs coeffs;
 } QrEnv;
 
-/* Outputs of one step, all AoS rows.  obs0 is float32 [N][18] (QUAD: the next state,
- * quad.py:269-271), [N][23] (COUPLED) or [N][15] (DECOUPLED agent 1); obs1 is [N][3]
- * (DECOUPLED agent 2) else NULL.  reward/done are [N][n_agents], n_agents = 2 for
- * DECOUPLED, else 1. */
+/* Outputs of one step, all AoS rows.  obs0 is float32 [N][18] (QUAD: the next state in the
+ * reference's order, quad.py:269-271; optional), [N][23] (COUPLED) or [N][15] (DECOUPLED
+ * agent 1); obs1 is [N][3] (DECOUPLED agent 2) else NULL.  reward/done are [N][n_agents],
+ * n_agents = 2 for DECOUPLED, else 1. */
 typedef struct QrStepOut {
-  float*   obs0;        /* QUAD: may be NULL (the observation IS the state buffer)        */
+  float*   obs0;        /* QUAD: may be NULL (no observation rows written)                */
   float*   obs1;
   float*   reward;      /* normalised to [0,1], -1 on crash (quad.py:154-166)             */
   float*   reward_raw;  /* optional: hook output before np.interp / crash override        */
@@ -122,12 +135,21 @@ int qr_error_obs(const QrEnv* env, float* obs0, float* obs1, void* stream);
  * (seed, env_offset+i, episode): results do not depend on sharding or launch geometry. */
 int qr_reset(const QrEnv* env, const uint8_t* mask, void* stream);
 
+/* Replaces QuadEnv.get_current_state() (quad.py:409-410): writes the reference's float64
+ * 18-vector rows [N][18] = (x, v, vec_F(R(q)), W). */
+int qr_get_state(const QrEnv* env, double* rows, void* stream);
+
+/* Replaces assignment to QuadEnv.state: reads float64 rows [N][18] for envs with
+ * mask[i] != 0 (NULL = all).  R is first passed through the reference's ensure_SO3 rule
+ * (quad_utils.py:123-142) — and, because the internal attitude is a unit quaternion, always
+ * projected onto SO(3) (nearest rotation, the same U V^T the reference's SVD yields). */
+int qr_set_state(const QrEnv* env, const double* rows, const uint8_t* mask, void* stream);
+
 /* Host-side helpers (no device work). */
 void qr_default_coeffs(QrCoeffs* c);
 int  qr_abi_version(void);
-/* Kernel name + launch geometry used for `n` envs (for profiling tools): writes
- * grid/block into the out params, returns a static NUL-terminated kernel symbol name. */
-const char* qr_step_kernel_info(int32_t kind, int32_t state_f64, int64_t num_envs, int32_t* grid, int32_t* block);
+/* Kernel family name + launch geometry used for `num_envs` envs (for profiling tools). */
+const char* qr_step_kernel_info(int32_t kind, int32_t layout, int64_t num_envs, int32_t* grid, int32_t* block);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,195 @@
+"""CPU: host-side logic, the C-ABI surface (loads, exports, struct layout, argument errors)
+and the multi-process sharding path over gloo.  No compute kernel is launched here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from oracle import quad_oracle as orc
+
+
+def _lib():
+    from gym_rotor_amd import _lib as L
+    if not os.path.exists(L.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return L
+
+
+def test_constants_match_reference(golden):
+    from gym_rotor_amd import QuadConstants
+    c, k = QuadConstants(), golden("kat_units")["constants"]
+    assert (c.reward_min, c.reward_min_1, c.reward_min_2) == tuple(k[0:3])
+    assert (c.dt, c.x_lim, c.v_lim, c.W_lim, c.euler_lim) == tuple(k[3:8])
+    d = golden("kat_units")["act_quad_derived"][0]  # nominal params row
+    assert np.allclose([c.hover_force, c.max_force, c.avrg_act, c.scale_act], d, rtol=1e-7)  # params row is f32-rounded
+    assert np.array_equal(c.forces_to_fM, orc.forces_to_fM(c.d_nominal, c.c_tf_nominal))
+    assert np.array_equal(c.nominal_params, orc.NOMINAL_PARAMS)
+
+
+def test_box_space():
+    from gym_rotor_amd import Box
+    b = Box(-1.0, 1.0, shape=(5,), dtype=np.float32)
+    b.seed(3); x = b.sample(); b.seed(3)
+    assert x.dtype == np.float32 and x.shape == (5,) and np.array_equal(x, b.sample()) and b.contains(x)
+    assert not b.contains(np.full(5, 2.0, np.float32))
+
+
+def test_shard_range_properties():
+    from hypothesis import given, settings, strategies as st
+    from gym_rotor_amd import shard_range
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(0, 10 ** 7), st.integers(1, 64))
+    def prop(n, w):
+        rs = [shard_range(n, r, w) for r in range(w)]
+        assert rs[0][0] == 0 and rs[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+        sizes = [e - s for s, e in rs]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+    prop()
+    with pytest.raises(ValueError):
+        shard_range(10, 4, 4)
+    assert shard_range(262144, 3, 8) == (98304, 131072)  # BASELINE.json configs[3]: 32 768 envs per GPU
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib()
+    hdr = open(os.path.join(ROOT, "include", "quadrotor_hip.h")).read()
+    declared = set(re.findall(r"\b(qr_[a-z_]+)\s*\(", hdr))
+    assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
+    lib = L.load()
+    for s in declared:
+        assert hasattr(lib, s)
+    assert lib.qr_abi_version() == L.ABI_VERSION
+    assert int(re.search(r"#define QR_ABI_VERSION (\d+)", hdr).group(1)) == L.ABI_VERSION
+
+
+def test_ctypes_structs_mirror_the_header(tmp_path):
+    """Compile a C program against include/quadrotor_hip.h and compare sizeof/offsetof."""
+    L = _lib()
+    fields = {"QrEnv": [f[0] for f in L.QrEnv._fields_], "QrStepOut": [f[0] for f in L.QrStepOut._fields_],
+              "QrCoeffs": [f[0] for f in L.QrCoeffs._fields_]}
+    lines = []
+    for sname, fl in fields.items():
+        lines.append(f'printf("{sname} %zu\\n", sizeof({sname}));')
+        lines += [f'printf("{sname}.{f} %zu\\n", offsetof({sname}, {f}));' for f in fl]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "quadrotor_hip.h"\nint main(void){' + "".join(lines) + "return 0;}")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", f"-I{ROOT}/include", str(src), "-o", str(exe)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for sname, fl in fields.items():
+        ct = getattr(L, sname)
+        assert int(out[sname]) == C.sizeof(ct)
+        for f in fl:
+            assert int(out[f"{sname}.{f}"]) == getattr(ct, f).offset, (sname, f)
+
+
+def test_abi_argument_errors_without_gpu():
+    L = _lib()
+    lib = L.load()
+    e, o = L.QrEnv(), L.QrStepOut()
+    assert lib.qr_step(None, None, 1, None, None) == -1
+    e.kind = 7
+    assert lib.qr_step(C.byref(e), None, 1, C.byref(o), None) == -2
+    e.kind, e.layout = 0, 5
+    assert lib.qr_step(C.byref(e), None, 1, C.byref(o), None) == -2
+    e.layout, e.num_envs = 0, -3
+    assert lib.qr_step(C.byref(e), None, 1, C.byref(o), None) == -3
+    e.num_envs = 4
+    assert lib.qr_step(C.byref(e), None, 1, C.byref(o), None) == -1          # NULL state buffers
+    e.pos_vel, e.att_rate = 0x1008, 0x2000
+    assert lib.qr_reset(C.byref(e), None, None) == -4                         # misaligned
+    e.pos_vel = 0x1000
+    assert lib.qr_reset(C.byref(e), None, None) == -1                         # no episode counters
+    assert lib.qr_step(C.byref(e), None, 1, C.byref(o), None) == -1          # NULL action
+    assert lib.qr_step(C.byref(e), 0x3000, 0, C.byref(o), None) == -1        # outputs missing
+    o.reward, o.done = 0x4000, 0x5000
+    assert lib.qr_step(C.byref(e), 0x3000, 0, C.byref(o), None) == -3        # substeps < 1
+    assert lib.qr_rollout(C.byref(e), 0x3000, 0, 1, C.byref(o), None) == -3  # n_steps < 1
+    e.kind = 1
+    assert lib.qr_step(C.byref(e), 0x3000, 1, C.byref(o), None) == -1        # wrapper without integ/obs
+    assert lib.qr_error_obs(C.byref(e), None, None, None) == -1
+    e.kind = 0
+    assert lib.qr_error_obs(C.byref(e), 0x6000, None, None) == -2            # undefined for Quad-v0
+    assert lib.qr_get_state(C.byref(e), None, None) == -1 and lib.qr_set_state(C.byref(e), None, None, None) == -1
+    with pytest.raises(ValueError):
+        L.check(-3, "x")
+    with pytest.raises(L.QuadrotorLibError):
+        L.check(700, "x")
+    co = L.default_coeffs()
+    assert (co.Cx, co.CIx, co.Cv, co.Cb1, co.CIb1, co.CW, co.Cw12, co.CW3) == (6.0, 0.1, 0.4, 6.0, 0.1, 0.6, 0.6, 0.1)
+    assert (co.alpha, co.beta, co.dt, co.W_lim) == (0.01, 0.05, 1 / 200, 2 * np.pi)
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the env refuses to exist; without the library the import of the binding raises."""
+    _lib()
+    from gym_rotor_amd import QuadVecEnv
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU execution path"):
+            QuadVecEnv("coupled", 4)
+    with pytest.raises(ValueError):
+        QuadVecEnv("hexa", 4)
+    with pytest.raises(ValueError):
+        QuadVecEnv("quad", 4, layout="bf16")
+    code = "import os; os.environ['QR_LIB']='/nonexistent/lib.so'; from gym_rotor_amd import _lib; _lib.load()"
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "gym_rotor_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("no torch/NumPy", ""), fn
+
+
+_GLOO_WORKER = textwrap.dedent("""
+    import os, sys, torch, torch.distributed as dist
+    sys.path.insert(0, {root!r})
+    from gym_rotor_amd import shard_range, all_gather_rows
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    N, T = 1001, 5                      # uneven shards: 501 + 500
+    s, e = shard_range(N, rank, world)
+    g = torch.arange(T * N, dtype=torch.float32).reshape(T, N)
+    full = all_gather_rows(g[:, s:e].contiguous(), N)
+    assert full.shape == (T, N) and torch.equal(full, g), rank
+    # per-shard env-steps summed like bench.py does
+    t = torch.tensor([float(e - s)]); dist.all_reduce(t); assert t.item() == N
+    dist.barrier(); dist.destroy_process_group()
+    print("ok", rank)
+""")
+
+
+def test_sharding_world_size_2_gloo(tmp_path):
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    script = tmp_path / "w.py"
+    script.write_text(_GLOO_WORKER.format(root=ROOT, port=port))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=180)
+        assert p.returncode == 0, err
+        assert "ok" in out
+
+
+def test_all_gather_rows_single_process_is_identity():
+    from gym_rotor_amd import all_gather_rows
+    x = torch.arange(12.).reshape(3, 4)
+    assert all_gather_rows(x, 4) is x

@@ -7,7 +7,9 @@ Requires: /root/reference, numpy, scipy.  `gymnasium` is not installed in this i
 so a ~40-line stand-in (tools/_gymnasium_shim) is put on sys.path first; `sys.argv` is
 set before every constructor because the reference re-parses it (quad.py:24-25).
 
-All inputs are float32-representable so the fp32 GPU path sees bit-identical inputs.
+Inputs (x, v, W, actions, parameters, goals, integrator terms) are float32-representable so
+the GPU path, whose I/O is float32, sees bit-identical inputs; input rotations are exact
+float64 rotations (see state_in).
 
 Files written (see tests/golden/README.md for the field lists):
   kat_units.npz            hat / ensure_SO3 / angle / euler / interp / mixing known answers
@@ -39,6 +41,20 @@ from gym_rotor.wrappers.decoupled_yaw_wrapper import DecoupledWrapper  # noqa: E
 from oracle import quad_oracle as orc  # noqa: E402  (only for the reset-state sampler)
 
 f32r = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)  # float32-representable f64
+
+
+def state_in(s):
+    """Input states: x, v, W float32-representable; R an exact (float64) rotation, as every
+    state the reference itself produces is (reset builds R from Euler angles in float64 and
+    the ODE flow keeps it orthonormal to ~3e-15)."""
+    s = np.array(s, dtype=np.float64)
+    lead = s.shape[:-1]
+    R = np.swapaxes(s[..., 6:15].reshape(-1, 3, 3), 1, 2)
+    U, _, Vt = np.linalg.svd(R)
+    R = U @ Vt
+    out = f32r(s)
+    out[..., 6:15] = np.swapaxes(R, 1, 2).reshape(lead + (9,))
+    return out
 
 
 def make_env(kind):
@@ -117,7 +133,7 @@ def check_step_template(kind):
     """Confirm the hook sequence above reproduces env.step() for the two wrappers."""
     rng = np.random.default_rng(5)
     env_a, env_b = make_env(kind), make_env(kind)
-    st = f32r(orc.sample_reset_state(rng, 1)[0])
+    st = state_in(orc.sample_reset_state(rng, 1)[0])
     for e in (env_a, env_b):
         inject(e, st, orc.DEFAULT_GOAL, np.zeros(8))
     for _ in range(20):
@@ -169,7 +185,7 @@ def gen_onestep(kind, n=512, seed=0):
     rng = np.random.default_rng(1000 + seed + 17 * orc.KINDS.index(kind))
     A = orc.ACTION_DIM[kind]
     nb = n // 4
-    state = f32r(np.concatenate([orc.sample_reset_state(rng, n - nb, "train"), boundary_states(rng, nb)]))
+    state = state_in(np.concatenate([orc.sample_reset_state(rng, n - nb, "train"), boundary_states(rng, nb)]))
     action = f32r(rng.uniform(-1, 1, (n, A)))
     action[::7] = f32r(np.sign(action[::7]))  # saturated commands
     params = np.tile(orc.NOMINAL_PARAMS, (n, 1)); params[1::2] = random_params(rng, n)[1::2]
@@ -217,8 +233,8 @@ def gen_traj(kind, mode, n_env=4, T=1000, seed=0):
     params = np.tile(orc.NOMINAL_PARAMS, (n_env, 1)); params[n_env // 2:] = random_params(rng, n_env)[n_env // 2:]
     params = f32r(params)
     goal = np.tile(orc.DEFAULT_GOAL, (n_env, 1)); goal[1::2] = random_goal(rng, n_env)[1::2]
-    init = f32r(orc.sample_reset_state(rng, n_env, "train"))
-    pool = f32r(orc.sample_reset_state(rng, 64 * n_env, "train")).reshape(n_env, 64, 18)
+    init = state_in(orc.sample_reset_state(rng, n_env, "train"))
+    pool = state_in(orc.sample_reset_state(rng, 64 * n_env, "train")).reshape(n_env, 64, 18)
     actions = f32r(rng.uniform(-1, 1, (T, n_env, A)))
     states = np.zeros((T + 1, n_env, 18)); integs = np.zeros((T + 1, n_env, 8))
     rewards = np.zeros((T, n_env, nag)); raws = np.zeros((T, n_env, nag)); dones = np.zeros((T, n_env, nag), bool)
@@ -290,7 +306,7 @@ def gen_kats():
         P = np.tile(orc.NOMINAL_PARAMS, (n, 1)); P[1::2] = random_params(rng, n)[1::2]
         P = f32r(P)
         Aa = f32r(rng.uniform(-1.3, 1.3, (n, orc.ACTION_DIM[kind])))
-        S = f32r(orc.sample_reset_state(rng, n))
+        S = state_in(orc.sample_reset_state(rng, n))
         F, Mo, der = np.zeros(n), np.zeros((n, 3)), np.zeros((n, 4))
         for i in range(n):
             inject_params(env, P[i]); inject(env, S[i], orc.DEFAULT_GOAL, np.zeros(8))
