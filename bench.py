@@ -7,17 +7,20 @@
 
 Workload (BASELINE.json configs[1]): Quad-v0, 65 536 envs per GPU, per-env reset-distribution
 states, +-10 % randomised parameters, U(-1,1) actions pre-generated on the device, float32
-I/O, auto-reset on (episodes that terminate are re-sampled inside the launch).  A "step" is
-one env.step() launch over the whole batch.  Envs are sharded over ranks with NO collective
-on the step path (weak scaling: 65 536 envs per GPU); `value` = all ranks' env-steps / the
-max-over-ranks time of the K timed steps, inputs resident in HBM.
+I/O.  A "step" is ONE env.step() launch over the whole batch (qr_step through the C-ABI).
+Episodes that terminate are re-sampled inside the same launch (auto-reset, the way a vector
+env is driven in training; the CPU baseline resets on done too).  Envs are sharded over ranks
+with NO collective on the step path (weak scaling: 65 536 envs per GPU); `value` = all ranks'
+env-steps / the max-over-ranks time of the K timed steps, inputs resident in HBM.
 
-The K timed steps are issued as one hipGraph replay (K captured qr_step launches) unless
---mode eager; HIP events on the launch stream bracket exactly those K launches, and
-`roofline.achieved` = algorithmic bytes per launch / (event time / K).
+The K timed steps are issued as one hipGraph replay of K captured qr_step launches (default)
+or eagerly (--mode eager); HIP events recorded on the launch stream bracket exactly those K
+launches.  `roofline.achieved` = SURVEY.md §8(d) algorithmic bytes per launch / (event time / K);
+`roofline.traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed under
+profiles/ (tools/profile.sh), when one exists for this configuration.
 
-`cpu_baseline` (rank 0, N=1 only) times the oracle's reference-style single-env path (NumPy
-RHS + scipy DOP853 + ensure_SO3, oracle/quad_oracle.py) on one host core for ~12 s.
+`cpu_baseline` (rank 0, N=1 only) times the oracle's reference-style single-env path (NumPy RHS
++ scipy DOP853 + ensure_SO3, reset-on-done; oracle/quad_oracle.py) on one host core for ~12 s.
 """
 from __future__ import annotations
 
@@ -81,6 +84,23 @@ def cpu_baseline(kind: str, seconds: float):
             "vectorised_numpy_value": vec}
 
 
+def committed_traffic(kind, envs, layout, auto_reset):
+    """HBM bytes per launch from the PMC profile committed under profiles/ (None if absent)."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    if not os.path.isdir(pdir):
+        return None
+    for fn in sorted(os.listdir(pdir)):
+        if fn.endswith("_traffic.json"):
+            try:
+                for rec in json.load(open(os.path.join(pdir, fn))):
+                    if (rec["kind"], rec["envs"], rec["layout"], rec["auto_reset"]) == (kind, envs, layout, auto_reset):
+                        best = rec
+            except Exception:
+                pass
+    return best
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,13 +121,7 @@ def main():
     from gym_rotor_amd import ALGO_BYTES, QuadVecEnv
     from gym_rotor_amd.constants import ALGO_BYTES_PARAMS
     N = a.envs
-    env = QuadVecEnv(a.kind, N, device=dev, seed=0, substeps=a.substeps, layout=a.layout, use_UDM=True,
-                     auto_reset=not a.no_auto_reset, env_offset=rank * N)
-    env.reset("train")
-    if a.kind != "quad":
-        env.get_norm_error_state()
-    gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
-    acts = [torch.rand(N, env.action_dim, device=dev, generator=gen) * 2 - 1 for _ in range(a.action_batches)]
+    auto_reset = not a.no_auto_reset
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -115,64 +129,78 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(a.warmup):
-        env.step(acts[i % len(acts)])
-    graph = None
-    if a.mode == "graph":
-        torch.cuda.synchronize(dev)
-        side = torch.cuda.Stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(graph, stream=side):
-                for i in range(a.steps):
-                    env.step(acts[i % len(acts)])
-        torch.cuda.current_stream(dev).wait_stream(side)
-        graph.replay()  # untimed: first replay uploads the graph
-
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    t0 = time.perf_counter()
-    ev0.record()
-    if graph is not None:
-        graph.replay()
-    else:
-        for i in range(a.steps):
+    def run(ar: bool, timed: bool):
+        """W warmup steps, then exactly K timed steps."""
+        env = QuadVecEnv(a.kind, N, device=dev, seed=0, substeps=a.substeps, layout=a.layout, use_UDM=True,
+                         auto_reset=ar, env_offset=rank * N)
+        env.reset("train")
+        if a.kind != "quad":
+            env.get_norm_error_state()
+        gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
+        acts = [torch.rand(N, env.action_dim, device=dev, generator=gen) * 2 - 1 for _ in range(a.action_batches)]
+        for i in range(a.warmup):
             env.step(acts[i % len(acts)])
-    ev1.record()
-    barrier()
-    wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
+        graph = None
+        if a.mode == "graph":
+            torch.cuda.synchronize(dev)
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    for i in range(a.steps):
+                        env.step(acts[i % len(acts)])
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph.replay()  # untimed: the first replay uploads the graph
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier() if timed else torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        ev0.record()
+        if graph is not None:
+            graph.replay()
+        else:
+            for i in range(a.steps):
+                env.step(acts[i % len(acts)])
+        ev1.record()
+        barrier() if timed else torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t0
+        dev_ms = ev0.elapsed_time(ev1)
+        finite = bool(torch.isfinite(env.get_current_state()).all())
+        done_rate = float(env._done.float().mean())
+        return wall, dev_ms, finite, done_rate, env.kernel_info()
+
+    wall, dev_ms, finite, done_rate, kinfo = run(auto_reset, True)
     tmax = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall, dev_ms = float(tmax[0]), float(tmax[1])
-    finite = bool(torch.isfinite(env.get_current_state()).all())
 
     if rank == 0:
         ms_per_step = wall * 1e3 / a.steps
         launch_us = dev_ms * 1e3 / a.steps
         algo = ALGO_BYTES[a.kind] + ALGO_BYTES_PARAMS
         # bytes this layout really moves per env-step: 13-word state r/w, action, [integ r/w, obs rows],
-        # reward, done, params
+        # reward, done, params (+ episode counter read with auto-reset)
         state_b = {"mixed": 6 * 4 + 7 * 8, "f64": 13 * 8, "f32": 13 * 4}[a.layout] * 2
         layout = state_b + {"quad": 16 + 4 + 1 + 24, "coupled": 16 + 64 + 92 + 4 + 1 + 24,
-                            "decoupled": 20 + 64 + 72 + 8 + 2 + 24}[a.kind]
+                            "decoupled": 20 + 64 + 72 + 8 + 2 + 24}[a.kind] + (4 if auto_reset else 0)
         achieved = algo * N / (launch_us * 1e-6) / 1e9
-        kname, grid, block = env.kernel_info()
+        kname, grid, block = kinfo
+        traffic = committed_traffic(a.kind, N, a.layout, auto_reset)
         out = {
             "metric": "quadrotor env-steps/sec at 65 536 envs; 1/2/4/8 MI355X + CPU ref",
             "value": N * n_gpus * a.steps / wall, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if a.layout == "f32" else "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[1]: Quad-v0 batched {N} envs per GPU, random actions, fp32 I/O"
-                       if a.kind == "quad" else f"{a.kind} {N} envs per GPU",
+            "config": {"workload": (f"BASELINE.json configs[1]: Quad-v0 batched {N} envs per GPU, random actions, fp32 I/O"
+                                    if a.kind == "quad" else f"{a.kind} wrapper, {N} envs per GPU, random actions, fp32 I/O"),
                        "kind": a.kind, "envs_per_gpu": N, "global_envs": N * n_gpus, "substeps": a.substeps,
                        "integrator": "RK4 fixed-step on (v, unit quaternion, W)", "state_layout": a.layout, "io_dtype": "f32",
-                       "auto_reset": not a.no_auto_reset, "launch_mode": a.mode, "parallelism": f"env-shard x{n_gpus}, no collective",
-                       "state_finite": finite},
+                       "auto_reset": auto_reset, "done_rate_last_step": done_rate, "launch_mode": a.mode,
+                       "parallelism": f"env-shard x{n_gpus}, no collective", "state_finite": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": (traffic or {}).get("bytes_per_launch"),
+                         "traffic_source": (traffic or {}).get("source"),
                          "kernel": kname, "grid": grid, "block": block, "avg_launch_us": launch_us,
                          "algorithmic_bytes_per_env_step": algo, "layout_bytes_per_env_step": layout,
                          "achieved_layout_GBs": layout * N / (launch_us * 1e-6) / 1e9,
@@ -180,8 +208,13 @@ def main():
                                  "avg_launch_us = HIP-event time of the K back-to-back launches / K (includes the "
                                  "~1.7 us launch floor of an empty kernel of this grid)"},
         }
-        if n_gpus == 1 and a.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(a.kind, a.cpu_seconds)
+        if n_gpus == 1:
+            # secondary figure: the other reset mode (no reset inside step = the reference's own semantics)
+            w2, d2, _, _, _ = run(not auto_reset, False)
+            out["config"]["other_reset_mode"] = {"auto_reset": not auto_reset, "env_steps_per_s": N * a.steps / w2,
+                                                 "avg_launch_us": d2 * 1e3 / a.steps}
+            if a.cpu_seconds > 0:
+                out["cpu_baseline"] = cpu_baseline(a.kind, a.cpu_seconds)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -160,6 +160,36 @@ __device__ __forceinline__ void draw20(Draws& d, uint64_t seed, uint64_t gid, ui
   }
 }
 
+// Wave-cooperative form for the in-step auto-reset.  Only ~1 % of the envs reset in a given
+// step, but a wave runs the reset path if ANY of its 64 lanes needs it, so what counts is the
+// instruction count of the path, and Philox is the bulk of it (v_mul_hi/lo_u32 are
+// quarter-rate).  Instead of one lane grinding through 5 Philox blocks with 63 lanes idle,
+// the 5 blocks of one resetting env are computed by 5 different lanes in ONE pass and the 20
+// words are moved into the owner lane with v_readlane + v_cndmask.  Same draws as draw20.
+__device__ __forceinline__ void coop_draw20(Draws& d, bool need, uint64_t seed, uint64_t gid, uint32_t episode) {
+  const int lane = (int)__lane_id();
+  const int glo = (int)(uint32_t)gid, ghi = (int)(uint32_t)(gid >> 32), ep = (int)episode;
+#pragma unroll
+  for (int j = 0; j < 20; ++j) d.r[j] = 0u;
+  unsigned long long m = __ballot(need);
+  while (m) {  // wave-uniform loop over the resetting lanes
+    const int src = __builtin_ctzll(m);
+    m &= m - 1;
+    const bool mine = lane == src;
+    uint32_t ctr[4] = {(uint32_t)__builtin_amdgcn_readlane(glo, src), (uint32_t)__builtin_amdgcn_readlane(ghi, src),
+                       (uint32_t)__builtin_amdgcn_readlane(ep, src), (uint32_t)(lane % 5)};
+    philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)ctr[j], b);
+        d.r[4 * b + j] = mine ? v : d.r[4 * b + j];
+      }
+    }
+  }
+}
+
 // sin/cos of a random angle: float evaluation re-normalised in f64, so every factor (hence
 // q) has unit norm to f64 round-off.
 __device__ __forceinline__ void unit_sincos(double ang, double& s, double& c) {
@@ -178,10 +208,7 @@ __device__ __forceinline__ void unit_sincos(double ang, double& s, double& c) {
 // 14..16 W; 17,18 roll,pitch.  R = Rz(yaw) Ry(pitch) Rx(roll) (scipy 'xyz' extrinsic,
 // quad.py:199)  <=>  q = qz(yaw) qy(pitch) qx(roll).
 template <typename T>
-__device__ void sample_reset(Work<T>& w, bool randomise, bool eval, const Coeffs& c, uint64_t seed, uint64_t gid,
-                             uint32_t episode) {
-  Draws d;
-  draw20(d, seed, gid, episode);
+__device__ void sample_reset(Work<T>& w, const Draws& d, bool randomise, bool eval, const Coeffs& c) {
   Phys<T>& ph = w.ph;
   if (randomise) {  // values are rounded to float32: that is how the params buffer stores them
     const double p = c.udm;
@@ -557,6 +584,10 @@ __global__ __launch_bounds__(B) void step_kernel(const Args a) {
   }
   w.ph.derive();
   int32_t steps = (a.steps && active) ? a.steps[i] : 0;
+  // The episode counter (RNG stream id) is fetched with the rest of the working set: read
+  // lazily inside the reset path it would put a full memory round-trip (~1.5 us) on the
+  // critical path of every wave that has a resetting lane.
+  int32_t episode = ((a.flags & QR_FLAG_AUTO_RESET) && active) ? a.episode[i] : 0;
   bool params_dirty = false;
 
   for (int t = 0; t < a.n_steps; ++t) {
@@ -659,23 +690,43 @@ __global__ __launch_bounds__(B) void step_kernel(const Args a) {
     bool any_done = trunc;
 #pragma unroll
     for (int g = 0; g < NAG; ++g) any_done = any_done || dn[g];
-    if ((a.flags & QR_FLAG_AUTO_RESET) && any_done && active) {
-      const int32_t episode = a.episode[i] + 1;  // touched only by the (rare) resetting lanes
-      a.episode[i] = episode;
-      const bool eval = (a.flags & QR_FLAG_EVAL_RESET) != 0;
-      const bool randomise = !eval && !(a.flags & QR_FLAG_NO_UDM) && a.params != nullptr;
-      const Phys<T> keep = w.ph;
-      sample_reset(w, randomise, eval, c, a.seed, (uint64_t)(a.env_offset + i), (uint32_t)episode);
-      if (a.params != nullptr) params_dirty = true; else w.ph = keep;
-      steps = 0;
-      quat_to_R(&w.y[3], R);
-      if constexpr (KIND != QR_KIND_QUAD) {
+    const bool need_reset = (a.flags & QR_FLAG_AUTO_RESET) && any_done && active;
+    if (__ballot(need_reset)) {  // wave-uniform: skip unless some lane of this wave resets
+      if (need_reset) episode += 1;
+      Draws d;
+#if QR_ABLATE == 3  // measurement build: reset path without the RNG
 #pragma unroll
-        for (int f = 0; f < 8; ++f) w.integ[f] = T(0);
-        error_obs<KIND, T>(w, R, c, o0, o1);  // first observation of the new episode (main.py:226-230)
+      for (int j = 0; j < 20; ++j) d.r[j] = 0x9E3779B9u * (uint32_t)(j + 1) + (uint32_t)episode;
+#else
+      coop_draw20(d, need_reset, a.seed, (uint64_t)(a.env_offset + i), (uint32_t)episode);
+#endif
+#if QR_ABLATE == 4  // measurement build: RNG only, trivial consumption
+      if (need_reset) {
+        uint32_t acc = 0;
 #pragma unroll
-        for (int f = 0; f < 8; ++f) w.integ[f] = T((float)w.integ[f]);
+        for (int j = 0; j < 20; ++j) acc ^= d.r[j];
+        w.x[0] = T((float)(acc & 0xFFFF) * 1e-5f);
+        a.episode[i] = episode;
       }
+#else
+      if (need_reset) {
+        const bool eval = (a.flags & QR_FLAG_EVAL_RESET) != 0;
+        const bool randomise = !eval && !(a.flags & QR_FLAG_NO_UDM) && a.params != nullptr;
+        const Phys<T> keep = w.ph;
+        sample_reset(w, d, randomise, eval, c);
+        if (a.params != nullptr) params_dirty = true; else w.ph = keep;
+        a.episode[i] = episode;
+        steps = 0;
+        quat_to_R(&w.y[3], R);
+        if constexpr (KIND != QR_KIND_QUAD) {
+#pragma unroll
+          for (int f = 0; f < 8; ++f) w.integ[f] = T(0);
+          error_obs<KIND, T>(w, R, c, o0, o1);  // first observation of the new episode (main.py:226-230)
+#pragma unroll
+          for (int f = 0; f < 8; ++f) w.integ[f] = T((float)w.integ[f]);
+        }
+      }
+#endif
     }
 
     // ---- outputs of step t ----
@@ -770,7 +821,9 @@ __global__ __launch_bounds__(64) void reset_kernel(const Args a) {
   const bool eval = (a.flags & QR_FLAG_EVAL_RESET) != 0;
   const bool randomise = !eval && !(a.flags & QR_FLAG_NO_UDM);
   Work<T> w;
-  sample_reset(w, randomise, eval, a.c, a.seed, (uint64_t)(a.env_offset + i), (uint32_t)episode);
+  Draws d;
+  draw20(d, a.seed, (uint64_t)(a.env_offset + i), (uint32_t)episode);
+  sample_reset(w, d, randomise, eval, a.c);
   store_state<XV, QW, T>(a, i, w);
   if (a.params) {
     a.params[i] = (float)w.ph.m; a.params[N + i] = (float)w.ph.d; a.params[2 * N + i] = (float)w.ph.J1;

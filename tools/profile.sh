@@ -1,0 +1,25 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): kernel-trace stats + PMC traffic counters for bench.py.
+# Usage: tools/profile.sh <tag> [bench args...]     -> gpurun_out/<tag>/{stats,fetch,write}*
+set -u
+TAG=${1:-r01}; shift || true
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+# (1) per-kernel time: kernel trace + stats only
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --cpu-seconds 0 "$@" > "$OUT/stats.log" 2>&1
+# (2)/(3) HBM traffic counters, each in its own pass, no tracing (FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 "$ROOT/bench.py" --cpu-seconds 0 "$@" > "$OUT/fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 "$ROOT/bench.py" --cpu-seconds 0 "$@" > "$OUT/write.log" 2>&1
+# calibration of the counters on a copy of known size in torch (16 B/lane vectorised): 256 MiB
+cat > /tmp/calib.py <<'PY'
+import torch
+x = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device="cuda").normal_()
+for _ in range(5):
+    y = x.clone()
+torch.cuda.synchronize()
+PY
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/calib_fetch" -- python3 /tmp/calib.py > "$OUT/calib_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/calib_write" -- python3 /tmp/calib.py > "$OUT/calib_write.log" 2>&1
+python3 "$ROOT/tools/summarize_profile.py" "$OUT" | tee "$OUT/summary.txt"
