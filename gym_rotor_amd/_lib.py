@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("QR_LIB", os.path.join(_HERE, "libquadrotor_hip.so"))
 KIND_QUAD, KIND_COUPLED, KIND_DECOUPLED = 0, 1, 2
 KIND_ID = {"quad": KIND_QUAD, "coupled": KIND_COUPLED, "decoupled": KIND_DECOUPLED}
 FLAG_AUTO_RESET, FLAG_EVAL_RESET, FLAG_NO_UDM = 1, 2, 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 LAYOUT_ID = {"mixed": 0, "f64": 1, "f32": 2}
 
 ERRORS = {-1: "QR_E_NULL: a required pointer is NULL", -2: "QR_E_KIND: bad env kind",
@@ -34,7 +34,7 @@ class QrCoeffs(C.Structure):
 
 
 class QrEnv(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("layout", C.c_int32), ("num_envs", C.c_int64),
+    _fields_ = [("kind", C.c_int32), ("layout", C.c_int32), ("num_envs", C.c_int64), ("field_stride", C.c_int64),
                 ("env_offset", C.c_int64), ("seed", C.c_uint64),
                 ("pos_vel", C.c_void_p), ("att_rate", C.c_void_p),
                 ("integ", C.c_void_p), ("params", C.c_void_p), ("goal", C.c_void_p),

@@ -22,9 +22,9 @@
 // rows (actions, observations) go through LDS so global traffic is linear 16-byte-per-lane
 // stores.  There is no contraction larger than 3x3 anywhere, so no MFMA.
 //
-// Written directly for CDNA4 (64-lane wavefronts).  Small batches use one wavefront per
-// workgroup (N = 65 536 -> 1024 workgroups, one per SIMD, no cross-wave barriers); large
-// batches use 256-thread workgroups to stay under the workgroup dispatch rate.
+// Written directly for CDNA4: 64-lane wavefronts, one wavefront per workgroup (N = 65 536 ->
+// 1024 workgroups = one per SIMD; no cross-wave barriers), <= 256 VGPRs so that two waves fit
+// per SIMD at large N.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -33,7 +33,10 @@
 #include "quadrotor_hip.h"
 
 #ifndef QR_ABLATE
-#define QR_ABLATE 0  // 0 = product build; 1/2 = measurement-only builds (tools/microbench.py)
+#define QR_ABLATE 0  // 0 = product build; 1..4 = measurement-only builds (tools/microbench.py)
+#endif
+#ifndef QR_WAVES_PER_SIMD
+#define QR_WAVES_PER_SIMD 2  // 2nd __launch_bounds__ argument of the step kernel (<= 256 VGPRs)
 #endif
 
 namespace qr {
@@ -71,6 +74,7 @@ struct Args {
   double* rows_out;       // qr_get_state
   const double* rows_in;  // qr_set_state
   int64_t n;
+  int64_t ld;             // elements between consecutive fields of every SoA buffer (>= n)
   int64_t env_offset;
   uint64_t seed;
   int32_t n_steps;
@@ -100,30 +104,36 @@ __device__ __forceinline__ float recip(float a) {
   return fmaf(fmaf(-a, x, 1.0f), x, x);
 }
 
+// Per-env working set held in VGPRs.  y = (v[0..2], q[3..6] = w,x,y,z, W[7..9]) is the RK4
+// vector; x' = v is integrated from the stage velocities.  Everything that is STORED as
+// float32 is also HELD as float32 (converted at use): the step kernel is register-bound —
+// two waves per SIMD need <= 256 VGPRs — and a float64 copy of 26 words costs 26 registers.
 template <typename T>
-struct Phys {  // per-env physical parameters + what set_random_parameters derives (quad.py:389-404)
+struct Work {
+  T x[3];
+  T y[10];
+  float prm[6];    // m, d, J1(=J2), J3, c_tf, c_tw (quad.py:359-387); kNominal[] when not randomised
+  float goal[12];  // xd, vd, b1d, Wd
+  float integ[8];  // eIx, g_x prev, eIb1, g_b prev
+  bool nominal;    // parameters are the exact float64 nominal values, not prm[]
+};
+
+template <typename T>
+struct Phys {  // what set_random_parameters derives (quad.py:389-404), formed when needed
   T m, d, J1, J3, ctf, ctw;
   T max_force, avrg_act, scale_act;
-  __device__ __forceinline__ void nominal() {
-    m = T(kMnom); d = T(kDnom); J1 = T(kJ1nom); J3 = T(kJ3nom); ctf = T(kCtfNom); ctw = T(kCtwNom);
-  }
-  __device__ __forceinline__ void derive() {
+  template <typename W>
+  __device__ __forceinline__ explicit Phys(const W& w) {
+    if (w.nominal) {
+      m = T(kMnom); d = T(kDnom); J1 = T(kJ1nom); J3 = T(kJ3nom); ctf = T(kCtfNom); ctw = T(kCtwNom);
+    } else {
+      m = T(w.prm[0]); d = T(w.prm[1]); J1 = T(w.prm[2]); J3 = T(w.prm[3]); ctf = T(w.prm[4]); ctw = T(w.prm[5]);
+    }
     const T hover = m * T(kG * 0.25);
     max_force = ctw * hover;
     avrg_act = (T(kMinForce) + max_force) * T(0.5);
     scale_act = max_force - avrg_act;
   }
-};
-
-// Per-env working set.  y = (v[0..2], q[3..6] = w,x,y,z, W[7..9]) is the RK4 vector; x' = v is
-// integrated from the stage velocities.
-template <typename T>
-struct Work {
-  T x[3];
-  T y[10];
-  Phys<T> ph;
-  T goal[12];   // xd, vd, b1d, Wd
-  T integ[8];   // eIx, g_x prev, eIb1, g_b prev
 };
 
 // ------------------------------------------------------------------------------------
@@ -144,10 +154,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&ctr)[4], uint32_t k0, u
   }
 }
 
-struct Draws {  // 20 uniforms
+struct Draws {  // 20 x 32 random bits -> uniforms (24-bit mantissa: these are random draws, float is plenty)
   uint32_t r[20];
-  __device__ __forceinline__ double u01(int i) const { return ((double)r[i] + 0.5) * (1.0 / 4294967296.0); }
-  __device__ __forceinline__ double sym(int i) const { return 2.0 * u01(i) - 1.0; }
+  __device__ __forceinline__ float u01(int i) const { return fmaf((float)(r[i] >> 8), 0x1p-24f, 0x1p-25f); }
+  __device__ __forceinline__ float sym(int i) const { return fmaf((float)(r[i] >> 8), 0x1p-23f, 0x1p-24f - 1.0f); }
 };
 
 __device__ __forceinline__ void draw20(Draws& d, uint64_t seed, uint64_t gid, uint32_t episode) {
@@ -161,43 +171,52 @@ __device__ __forceinline__ void draw20(Draws& d, uint64_t seed, uint64_t gid, ui
 }
 
 // Wave-cooperative form for the in-step auto-reset.  Only ~1 % of the envs reset in a given
-// step, but a wave runs the reset path if ANY of its 64 lanes needs it, so what counts is the
-// instruction count of the path, and Philox is the bulk of it (v_mul_hi/lo_u32 are
-// quarter-rate).  Instead of one lane grinding through 5 Philox blocks with 63 lanes idle,
-// the 5 blocks of one resetting env are computed by 5 different lanes in ONE pass and the 20
-// words are moved into the owner lane with v_readlane + v_cndmask.  Same draws as draw20.
+// step, but a wave runs the reset path if ANY of its 64 lanes needs it and the kernel ends with
+// its slowest wave, so what counts is the instruction count of the path — and Philox is the
+// bulk of it (v_mul_hi/lo_u32 are quarter-rate).  Instead of each resetting lane grinding
+// through 5 Philox blocks with the rest of the wave idle, ONE Philox pass serves up to 12
+// resetting envs: lane 5k+b computes block b of the k-th resetting env, then each owner pulls
+// its 20 words with ds_bpermute.  Same draws as draw20.
 __device__ __forceinline__ void coop_draw20(Draws& d, bool need, uint64_t seed, uint64_t gid, uint32_t episode) {
   const int lane = (int)__lane_id();
   const int glo = (int)(uint32_t)gid, ghi = (int)(uint32_t)(gid >> 32), ep = (int)episode;
 #pragma unroll
   for (int j = 0; j < 20; ++j) d.r[j] = 0u;
   unsigned long long m = __ballot(need);
-  while (m) {  // wave-uniform loop over the resetting lanes
-    const int src = __builtin_ctzll(m);
-    m &= m - 1;
-    const bool mine = lane == src;
-    uint32_t ctr[4] = {(uint32_t)__builtin_amdgcn_readlane(glo, src), (uint32_t)__builtin_amdgcn_readlane(ghi, src),
-                       (uint32_t)__builtin_amdgcn_readlane(ep, src), (uint32_t)(lane % 5)};
+  const int my_rank = __popcll(m & ((1ull << lane) - 1ull));  // rank among the resetting lanes
+  const int k = lane / 5, b = lane - 5 * k;                   // slot / block of this lane (k = 12: idle)
+  int base = 0;
+  while (m) {  // wave-uniform; one pass unless > 12 lanes of this wave reset
+    int src = lane, cnt = 0;
+    for (int s = 0; s < 12 && m; ++s) {  // lane index of the s-th resetting env -> lanes of slot s
+      const int l = __builtin_ctzll(m);
+      m &= m - 1;
+      if (k == s) src = l;
+      ++cnt;
+    }
+    uint32_t ctr[4] = {(uint32_t)__shfl(glo, src), (uint32_t)__shfl(ghi, src), (uint32_t)__shfl(ep, src), (uint32_t)b};
     philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const int r = my_rank - base;
+    const bool mine = need && r >= 0 && r < cnt;
+    const int from = mine ? 5 * r : 0;
 #pragma unroll
-    for (int b = 0; b < 5; ++b) {
+    for (int bb = 0; bb < 5; ++bb) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)ctr[j], b);
-        d.r[4 * b + j] = mine ? v : d.r[4 * b + j];
+        const uint32_t v = (uint32_t)__shfl((int)ctr[j], from + bb);
+        d.r[4 * bb + j] = mine ? v : d.r[4 * bb + j];
       }
     }
+    base += cnt;
   }
 }
 
-// sin/cos of a random angle: float evaluation re-normalised in f64, so every factor (hence
-// q) has unit norm to f64 round-off.
-__device__ __forceinline__ void unit_sincos(double ang, double& s, double& c) {
-  float sf, cf;
-  sincosf((float)ang, &sf, &cf);
-  s = sf; c = cf;
+// sin/cos of a random angle: hardware float evaluation (v_sin/v_cos, ~1e-6 — it is a random
+// draw) re-normalised in f64, so every factor, hence q, has unit norm to f64 round-off.
+__device__ __forceinline__ void unit_sincos(float ang, double& s, double& c) {
+  s = (double)__sinf(ang); c = (double)__cosf(ang);
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {  // r = 1/sqrt(n2) to first order around 1: 1e-7 -> 1e-14 -> 1e-28
+  for (int it = 0; it < 2; ++it) {  // r = 1/sqrt(n2) to first order around 1: 1e-6 -> 1e-12 -> 1e-24
     const double r = 1.5 - 0.5 * (s * s + c * c);
     s *= r; c *= r;
   }
@@ -209,38 +228,39 @@ __device__ __forceinline__ void unit_sincos(double ang, double& s, double& c) {
 // quad.py:199)  <=>  q = qz(yaw) qy(pitch) qx(roll).
 template <typename T>
 __device__ void sample_reset(Work<T>& w, const Draws& d, bool randomise, bool eval, const Coeffs& c) {
-  Phys<T>& ph = w.ph;
-  if (randomise) {  // values are rounded to float32: that is how the params buffer stores them
-    const double p = c.udm;
-    ph.m = T((float)(kMnom * (1.0 + p * d.sym(0))));
-    ph.d = T((float)(kDnom * (1.0 + p * d.sym(1))));
-    ph.J1 = T((float)(kJ1nom * (1.0 + p * d.sym(2))));
-    ph.J3 = T((float)(kJ3nom * (1.0 + p * d.sym(3))));
-    ph.ctf = T((float)(kCtfNom * (1.0 + p * d.sym(4))));
-    ph.ctw = T((float)(kCtwNom * (1.0 + 0.5 * p * d.sym(5))));
+  if (randomise) {  // float32 values: that is how the params buffer stores them
+    const float p = (float)c.udm;
+    w.prm[0] = (float)kMnom * fmaf(p, d.sym(0), 1.0f);
+    w.prm[1] = (float)kDnom * fmaf(p, d.sym(1), 1.0f);
+    w.prm[2] = (float)kJ1nom * fmaf(p, d.sym(2), 1.0f);
+    w.prm[3] = (float)kJ3nom * fmaf(p, d.sym(3), 1.0f);
+    w.prm[4] = (float)kCtfNom * fmaf(p, d.sym(4), 1.0f);
+    w.prm[5] = (float)kCtwNom * fmaf(0.5f * p, d.sym(5), 1.0f);
+    w.nominal = false;
   } else {
-    ph.nominal();
+    w.prm[0] = (float)kMnom; w.prm[1] = (float)kDnom; w.prm[2] = (float)kJ1nom;
+    w.prm[3] = (float)kJ3nom; w.prm[4] = (float)kCtfNom; w.prm[5] = (float)kCtwNom;
+    w.nominal = true;
   }
-  ph.derive();
-  const double yaw = kPi * d.sym(6);
-  double ix, iv, iR, iW;
+  const float yaw = (float)kPi * d.sym(6);
+  float ix, iv, iR, iW;
   if (eval) {  // quad.py:352-356
-    ix = 0.4; iv = 0.0; iR = 0.0; iW = 0.0;
-  } else if (d.u01(7) < 0.2) {  // quad.py:342-346
-    ix = 0.0; iv = 0.0; iR = 0.0; iW = 0.0;
+    ix = 0.4f; iv = 0.0f; iR = 0.0f; iW = 0.0f;
+  } else if (d.u01(7) < 0.2f) {  // quad.py:342-346
+    ix = 0.0f; iv = 0.0f; iR = 0.0f; iW = 0.0f;
   } else {  // quad.py:348-351
-    ix = 0.6; iv = c.v_lim * 0.5; iR = 50.0 * kPi / 180.0; iW = c.W_lim * 0.5;
+    ix = 0.6f; iv = (float)(c.v_lim * 0.5); iR = (float)(50.0 * kPi / 180.0); iW = (float)(c.W_lim * 0.5);
   }
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    w.x[j] = T((float)(ix * d.sym(8 + j)));
-    w.y[j] = T((float)(iv * d.sym(11 + j)));
+    w.x[j] = T(ix * d.sym(8 + j));
+    w.y[j] = T(iv * d.sym(11 + j));
     w.y[7 + j] = T(iW * d.sym(14 + j));
   }
   double sr, cr, sp, cp, sy, cy;
-  unit_sincos(0.5 * iR * d.sym(17), sr, cr);
-  unit_sincos(0.5 * iR * d.sym(18), sp, cp);
-  unit_sincos(0.5 * yaw, sy, cy);
+  unit_sincos(0.5f * iR * d.sym(17), sr, cr);
+  unit_sincos(0.5f * iR * d.sym(18), sp, cp);
+  unit_sincos(0.5f * yaw, sy, cy);
   w.y[3] = T(cr * cp * cy + sr * sp * sy);
   w.y[4] = T(sr * cp * cy - cr * sp * sy);
   w.y[5] = T(cr * sp * cy + sr * cp * sy);
@@ -416,7 +436,7 @@ template <> struct KindTraits<QR_KIND_DECOUPLED> { static constexpr int A = 5, D
 // action_wrapper of the three kinds (quad.py:225-242, coupled:44-53, decoupled:49-59 + 68-73)
 template <int KIND, typename T>
 __device__ __forceinline__ void action_map(const float* a, const Work<T>& w, Dyn<T>& p) {
-  const Phys<T>& ph = w.ph;
+  const Phys<T> ph(w);
   T f, M1, M2, M3;
   if constexpr (KIND == QR_KIND_QUAD) {
     T t[4];
@@ -432,10 +452,11 @@ __device__ __forceinline__ void action_map(const float* a, const Work<T>& w, Dyn
       M1 = T(a[1]); M2 = T(a[2]); M3 = T(a[3]);
     } else {  // M1 = b1.tau + J3 W3 W2, M2 = b2.tau - J3 W3 W1 from (R, W) at step start
       const T t1 = T(a[1]), t2 = T(a[2]), t3 = T(a[3]);
-      T R[9];
-      quat_to_R(&w.y[3], R);
-      M1 = (R[0] * t1 + R[1] * t2 + R[2] * t3) + ph.J3 * w.y[9] * w.y[8];
-      M2 = (R[3] * t1 + R[4] * t2 + R[5] * t3) - ph.J3 * w.y[9] * w.y[7];
+      const T qw = w.y[3], qx = w.y[4], qy = w.y[5], qz = w.y[6];  // b1, b2 = first two columns of R(q)
+      const T b1t = (T(1) - T(2) * (qy * qy + qz * qz)) * t1 + T(2) * (qx * qy + qw * qz) * t2 + T(2) * (qx * qz - qw * qy) * t3;
+      const T b2t = T(2) * (qx * qy - qw * qz) * t1 + (T(1) - T(2) * (qx * qx + qz * qz)) * t2 + T(2) * (qy * qz + qw * qx) * t3;
+      M1 = b1t + ph.J3 * w.y[9] * w.y[8];
+      M2 = b2t - ph.J3 * w.y[9] * w.y[7];
       M3 = T(a[4]);
     }
   }
@@ -454,47 +475,48 @@ __device__ __forceinline__ void error_obs(Work<T>& w, const T (&R)[9], const Coe
   T ex[3], ev[3], eW[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {  // x/x_lim - xd/x_lim etc. (quad.py:423-434)
-    ex[j] = w.x[j] * ixl - w.goal[j] * ixl;
-    ev[j] = w.y[j] * ivl - w.goal[3 + j] * ivl;
-    eW[j] = w.y[7 + j] * iWl - w.goal[9 + j] * iWl;
+    ex[j] = w.x[j] * ixl - T(w.goal[j]) * ixl;
+    ev[j] = w.y[j] * ivl - T(w.goal[3 + j]) * ivl;
+    eW[j] = w.y[7 + j] * iWl - T(w.goal[9 + j]) * iWl;
   }
   const T* b1 = &R[0]; const T* b2 = &R[3]; const T* b3 = &R[6];
-  const T* b1d = &w.goal[6];
+  const T b1d[3] = {T(w.goal[6]), T(w.goal[7]), T(w.goal[8])};
   const T db3 = b1d[0] * b3[0] + b1d[1] * b3[1] + b1d[2] * b3[2];
   T b1c[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) b1c[j] = b1d[j] - db3 * b3[j];
   const T sn = -(b1c[0] * b2[0] + b1c[1] * b2[1] + b1c[2] * b2[2]);
   const T cs = b1c[0] * b1[0] + b1c[1] * b1[1] + b1c[2] * b1[2];
-  const T eb1 = T(atan2f((float)sn, (float)cs));  // [rad]
-  const T eb1n = eb1 * T(1.0 / kPi);
-  // integrators: I += (g_prev + g) dt/2 ; g uses I before the update
-  const T hdt = T(c.dt) * T(0.5);
-  T eIxn[3];
+  const float eb1 = atan2f((float)sn, (float)cs);  // [rad]
+  const float eb1n = eb1 * (float)(1.0 / kPi);
+  // integrators: I += (g_prev + g) dt/2 ; g uses I before the update.  They are float32 words
+  // (stored and held), advanced in float32.
+  const float hdt = (float)(c.dt * 0.5);
+  float eIxn[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    const T g = -T(c.alpha) * w.integ[j] + ex[j] * xl;
-    w.integ[j] += (w.integ[3 + j] + g) * hdt;
+    const float g = fmaf(-(float)c.alpha, w.integ[j], (float)(ex[j] * xl));
+    w.integ[j] = fmaf(w.integ[3 + j] + g, hdt, w.integ[j]);
     w.integ[3 + j] = g;
-    eIxn[j] = clampT(w.integ[j] * T(c.inv_eIx_lim), T(-1), T(1));
+    eIxn[j] = clampT(w.integ[j] * (float)c.inv_eIx_lim, -1.0f, 1.0f);
   }
-  const T gb = -T(c.beta) * w.integ[6] + eb1n * T(kPi);
-  w.integ[6] += (w.integ[7] + gb) * hdt;
+  const float gb = fmaf(-(float)c.beta, w.integ[6], eb1);
+  w.integ[6] = fmaf(w.integ[7] + gb, hdt, w.integ[6]);
   w.integ[7] = gb;
-  const T eIb1n = clampT(w.integ[6] * T(c.inv_eIb1_lim), T(-1), T(1));
+  const float eIb1n = clampT(w.integ[6] * (float)c.inv_eIb1_lim, -1.0f, 1.0f);
   if constexpr (KIND == QR_KIND_COUPLED) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { o0[j] = (float)ex[j]; o0[3 + j] = (float)eIxn[j]; o0[6 + j] = (float)ev[j]; o0[20 + j] = (float)eW[j]; }
+    for (int j = 0; j < 3; ++j) { o0[j] = (float)ex[j]; o0[3 + j] = eIxn[j]; o0[6 + j] = (float)ev[j]; o0[20 + j] = (float)eW[j]; }
 #pragma unroll
     for (int j = 0; j < 9; ++j) o0[9 + j] = (float)R[j];
-    o0[18] = (float)eb1n; o0[19] = (float)eIb1n;
+    o0[18] = eb1n; o0[19] = eIb1n;
   } else {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      o0[j] = (float)ex[j]; o0[3 + j] = (float)eIxn[j]; o0[6 + j] = (float)ev[j]; o0[9 + j] = (float)b3[j];
+      o0[j] = (float)ex[j]; o0[3 + j] = eIxn[j]; o0[6 + j] = (float)ev[j]; o0[9 + j] = (float)b3[j];
       o0[12 + j] = (float)(eW[0] * b1[j] + eW[1] * b2[j]);
     }
-    o1[0] = (float)eb1n; o1[1] = (float)eIb1n; o1[2] = (float)eW[2];
+    o1[0] = eb1n; o1[1] = eIb1n; o1[2] = (float)eW[2];
   }
 }
 
@@ -507,22 +529,22 @@ template <typename XV, typename QW, typename T>
 __device__ __forceinline__ void load_state(const Args& a, int64_t i, Work<T>& w) {
   const XV* pv = reinterpret_cast<const XV*>(a.pos_vel);
   const QW* ar = reinterpret_cast<const QW*>(a.att_rate);
-  const int64_t N = a.n;
+  const int64_t L = a.ld;
 #pragma unroll
-  for (int f = 0; f < 3; ++f) { w.x[f] = T(pv[(int64_t)f * N + i]); w.y[f] = T(pv[(int64_t)(3 + f) * N + i]); }
+  for (int f = 0; f < 3; ++f) { w.x[f] = T(pv[(int64_t)f * L + i]); w.y[f] = T(pv[(int64_t)(3 + f) * L + i]); }
 #pragma unroll
-  for (int f = 0; f < 7; ++f) w.y[3 + f] = T(ar[(int64_t)f * N + i]);
+  for (int f = 0; f < 7; ++f) w.y[3 + f] = T(ar[(int64_t)f * L + i]);
 }
 
 template <typename XV, typename QW, typename T>
 __device__ __forceinline__ void store_state(const Args& a, int64_t i, const Work<T>& w) {
   XV* pv = reinterpret_cast<XV*>(a.pos_vel);
   QW* ar = reinterpret_cast<QW*>(a.att_rate);
-  const int64_t N = a.n;
+  const int64_t L = a.ld;
 #pragma unroll
-  for (int f = 0; f < 3; ++f) { pv[(int64_t)f * N + i] = (XV)w.x[f]; pv[(int64_t)(3 + f) * N + i] = (XV)w.y[f]; }
+  for (int f = 0; f < 3; ++f) { pv[(int64_t)f * L + i] = (XV)w.x[f]; pv[(int64_t)(3 + f) * L + i] = (XV)w.y[f]; }
 #pragma unroll
-  for (int f = 0; f < 7; ++f) ar[(int64_t)f * N + i] = (QW)w.y[3 + f];
+  for (int f = 0; f < 7; ++f) ar[(int64_t)f * L + i] = (QW)w.y[3 + f];
 }
 
 template <typename T>
@@ -532,17 +554,19 @@ __device__ __forceinline__ void idle_work(Work<T>& w) {  // lanes past the ragge
 #pragma unroll
   for (int f = 0; f < 10; ++f) w.y[f] = T(f == 3 ? 1 : 0);
 #pragma unroll
-  for (int f = 0; f < 12; ++f) w.goal[f] = T(f == 6 ? 1 : 0);
+  for (int f = 0; f < 12; ++f) w.goal[f] = f == 6 ? 1.0f : 0.0f;
 #pragma unroll
-  for (int f = 0; f < 8; ++f) w.integ[f] = T(0);
-  w.ph.nominal();
+  for (int f = 0; f < 8; ++f) w.integ[f] = 0.0f;
+#pragma unroll
+  for (int f = 0; f < 6; ++f) w.prm[f] = 0.0f;
+  w.nominal = true;
 }
 
 // ------------------------------------------------------------------------------------
 // The fused step / rollout kernel
 // ------------------------------------------------------------------------------------
 template <int KIND, typename XV, typename QW, int B>
-__global__ __launch_bounds__(B) void step_kernel(const Args a) {
+__global__ __launch_bounds__(B, QR_WAVES_PER_SIMD) void step_kernel(const Args a) {
   using T = QW;  // arithmetic type
   using KT = KindTraits<KIND>;
   constexpr int A = KT::A, D0 = KT::D0, D1 = KT::D1 ? KT::D1 : 1, NAG = KT::NAG;
@@ -550,7 +574,7 @@ __global__ __launch_bounds__(B) void step_kernel(const Args a) {
   const int tid = threadIdx.x;
   const int64_t first = (int64_t)blockIdx.x * B;
   const int64_t i = first + tid;
-  const int64_t N = a.n;
+  const int64_t N = a.n, L = a.ld;
   const int rows = (int)((N - first) < B ? (N - first) : B);
   const bool active = tid < rows;
   const Coeffs& c = a.c;
@@ -560,29 +584,23 @@ __global__ __launch_bounds__(B) void step_kernel(const Args a) {
 
   Work<T> w;
   // ---- load the env's working set (SoA, lane-contiguous) ----
+  idle_work(w);
   if (active) {
     load_state<XV, QW, T>(a, i, w);
     if (a.params) {
-      w.ph.m = T(a.params[i]); w.ph.d = T(a.params[N + i]); w.ph.J1 = T(a.params[2 * N + i]);
-      w.ph.J3 = T(a.params[3 * N + i]); w.ph.ctf = T(a.params[4 * N + i]); w.ph.ctw = T(a.params[5 * N + i]);
-    } else {
-      w.ph.nominal();
+#pragma unroll
+      for (int f = 0; f < 6; ++f) w.prm[f] = a.params[(int64_t)f * L + i];
+      w.nominal = false;
     }
     if (a.goal) {
 #pragma unroll
-      for (int f = 0; f < 12; ++f) w.goal[f] = T(a.goal[(int64_t)f * N + i]);
-    } else {
-#pragma unroll
-      for (int f = 0; f < 12; ++f) w.goal[f] = T(f == 6 ? 1 : 0);
+      for (int f = 0; f < 12; ++f) w.goal[f] = a.goal[(int64_t)f * L + i];
     }
     if (KIND != QR_KIND_QUAD) {
 #pragma unroll
-      for (int f = 0; f < 8; ++f) w.integ[f] = T(a.integ[(int64_t)f * N + i]);
+      for (int f = 0; f < 8; ++f) w.integ[f] = a.integ[(int64_t)f * L + i];
     }
-  } else {
-    idle_work(w);
   }
-  w.ph.derive();
   int32_t steps = (a.steps && active) ? a.steps[i] : 0;
   // The episode counter (RNG stream id) is fetched with the rest of the working set: read
   // lazily inside the reset path it would put a full memory round-trip (~1.5 us) on the
@@ -635,16 +653,17 @@ __global__ __launch_bounds__(B) void step_kernel(const Args a) {
       T eX2 = 0, eV2 = 0, W2 = 0;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const T dx = w.x[j] - w.goal[j], dv = w.y[j] - w.goal[3 + j];
+        const T dx = w.x[j] - T(w.goal[j]), dv = w.y[j] - T(w.goal[3 + j]);
         eX2 += dx * dx; eV2 += dv * dv; W2 += w.y[7 + j] * w.y[7 + j];
       }
       // eb1 = signed angle from b1d to b1_proj ~ (R00, R10, 0) (quad_utils.py:97-101,157-177).
       // acos(du.cu) with the sign of (du x cu)_z == atan2(|du x cu|, du.cu), which is invariant
       // to the lengths of both vectors, so neither is normalised.
-      const T dot = w.goal[6] * R[0] + w.goal[7] * R[1];
-      const T cz = w.goal[6] * R[1] - w.goal[7] * R[0];
+      const T g6 = T(w.goal[6]), g7 = T(w.goal[7]), g8 = T(w.goal[8]);
+      const T dot = g6 * R[0] + g7 * R[1];
+      const T cz = g6 * R[1] - g7 * R[0];
       const T hy2 = R[0] * R[0] + R[1] * R[1];
-      const float sabs = sqrtf((float)(w.goal[8] * w.goal[8] * hy2 + cz * cz));
+      const float sabs = sqrtf((float)(g8 * g8 * hy2 + cz * cz));
       float ang = atan2f(sabs, (float)dot);
       if (cz < T(0)) ang = -ang;
       const T eb1 = T(ang) * T(1.0 / kPi);
@@ -661,8 +680,6 @@ __global__ __launch_bounds__(B) void step_kernel(const Args a) {
       dn[0] = d;
     } else {
       error_obs<KIND, T>(w, R, c, o0, o1);
-#pragma unroll
-      for (int f = 0; f < 8; ++f) w.integ[f] = T((float)w.integ[f]);  // storage precision (see x, v above)
       if constexpr (KIND == QR_KIND_COUPLED) {  // coupled:78-110, float32 arithmetic on the float32 obs
         const float r = -(float)c.Cx * sq3(&o0[0]) + -(float)c.CIx * sq3(&o0[3]) + -(float)c.Cv * sq3(&o0[6]) +
                         -(float)c.Cb1 * fabsf(o0[18]) + -(float)c.CIb1 * (o0[19] * o0[19]) + -(float)c.CW * sq3(&o0[20]);
@@ -712,18 +729,15 @@ __global__ __launch_bounds__(B) void step_kernel(const Args a) {
       if (need_reset) {
         const bool eval = (a.flags & QR_FLAG_EVAL_RESET) != 0;
         const bool randomise = !eval && !(a.flags & QR_FLAG_NO_UDM) && a.params != nullptr;
-        const Phys<T> keep = w.ph;
         sample_reset(w, d, randomise, eval, c);
-        if (a.params != nullptr) params_dirty = true; else w.ph = keep;
+        if (a.params != nullptr) params_dirty = true;
         a.episode[i] = episode;
         steps = 0;
         quat_to_R(&w.y[3], R);
         if constexpr (KIND != QR_KIND_QUAD) {
 #pragma unroll
-          for (int f = 0; f < 8; ++f) w.integ[f] = T(0);
+          for (int f = 0; f < 8; ++f) w.integ[f] = 0.0f;
           error_obs<KIND, T>(w, R, c, o0, o1);  // first observation of the new episode (main.py:226-230)
-#pragma unroll
-          for (int f = 0; f < 8; ++f) w.integ[f] = T((float)w.integ[f]);
         }
       }
 #endif
@@ -762,12 +776,12 @@ __global__ __launch_bounds__(B) void step_kernel(const Args a) {
     store_state<XV, QW, T>(a, i, w);
     if (KIND != QR_KIND_QUAD) {
 #pragma unroll
-      for (int f = 0; f < 8; ++f) a.integ[(int64_t)f * N + i] = (float)w.integ[f];
+      for (int f = 0; f < 8; ++f) a.integ[(int64_t)f * L + i] = w.integ[f];
     }
     if (a.steps) a.steps[i] = steps;
     if (params_dirty) {
-      a.params[i] = (float)w.ph.m; a.params[N + i] = (float)w.ph.d; a.params[2 * N + i] = (float)w.ph.J1;
-      a.params[3 * N + i] = (float)w.ph.J3; a.params[4 * N + i] = (float)w.ph.ctf; a.params[5 * N + i] = (float)w.ph.ctw;
+#pragma unroll
+      for (int f = 0; f < 6; ++f) a.params[(int64_t)f * L + i] = w.prm[f];
     }
   }
 }
@@ -782,7 +796,7 @@ __global__ __launch_bounds__(64) void error_obs_kernel(const Args a) {
   const int tid = threadIdx.x;
   const int64_t first = (int64_t)blockIdx.x * B;
   const int64_t i = first + tid;
-  const int64_t N = a.n;
+  const int64_t N = a.n, L = a.ld;
   const int rows = (int)((N - first) < B ? (N - first) : B);
   const bool active = tid < rows;
   Work<T> w;
@@ -791,10 +805,10 @@ __global__ __launch_bounds__(64) void error_obs_kernel(const Args a) {
     load_state<XV, QW, T>(a, i, w);
     if (a.goal) {
 #pragma unroll
-      for (int f = 0; f < 12; ++f) w.goal[f] = T(a.goal[(int64_t)f * N + i]);
+      for (int f = 0; f < 12; ++f) w.goal[f] = a.goal[(int64_t)f * L + i];
     }
 #pragma unroll
-    for (int f = 0; f < 8; ++f) w.integ[f] = T(a.integ[(int64_t)f * N + i]);
+    for (int f = 0; f < 8; ++f) w.integ[f] = a.integ[(int64_t)f * L + i];
   }
   T R[9];
   quat_to_R(&w.y[3], R);
@@ -805,7 +819,7 @@ __global__ __launch_bounds__(64) void error_obs_kernel(const Args a) {
   if constexpr (KT::D1 > 0) store_rows<B, D1>(a.obs1 + first * D1, o1, smem, tid, rows);
   if (active) {
 #pragma unroll
-    for (int f = 0; f < 8; ++f) a.integ[(int64_t)f * N + i] = (float)w.integ[f];
+    for (int f = 0; f < 8; ++f) a.integ[(int64_t)f * L + i] = w.integ[f];
   }
 }
 
@@ -814,7 +828,7 @@ template <typename XV, typename QW>
 __global__ __launch_bounds__(64) void reset_kernel(const Args a) {
   using T = QW;
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  const int64_t N = a.n;
+  const int64_t N = a.n, L = a.ld;
   if (i >= N) return;
   if (a.mask && !a.mask[i]) return;
   const int32_t episode = a.episode[i] + 1;
@@ -826,12 +840,12 @@ __global__ __launch_bounds__(64) void reset_kernel(const Args a) {
   sample_reset(w, d, randomise, eval, a.c);
   store_state<XV, QW, T>(a, i, w);
   if (a.params) {
-    a.params[i] = (float)w.ph.m; a.params[N + i] = (float)w.ph.d; a.params[2 * N + i] = (float)w.ph.J1;
-    a.params[3 * N + i] = (float)w.ph.J3; a.params[4 * N + i] = (float)w.ph.ctf; a.params[5 * N + i] = (float)w.ph.ctw;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) a.params[(int64_t)f * L + i] = w.prm[f];
   }
   if (a.integ) {
 #pragma unroll
-    for (int f = 0; f < 8; ++f) a.integ[(int64_t)f * N + i] = 0.f;
+    for (int f = 0; f < 8; ++f) a.integ[(int64_t)f * L + i] = 0.f;
   }
   if (a.steps) a.steps[i] = 0;
   a.episode[i] = episode;
@@ -890,29 +904,28 @@ static void fill_coeffs(Coeffs& o, const QrCoeffs& q) {
 static int fill_env(Args& a, const QrEnv* e) {
   if (!e) return QR_E_NULL;
   if (e->kind < 0 || e->kind > 2 || e->layout < 0 || e->layout > 2) return QR_E_KIND;
-  if (e->num_envs < 0) return QR_E_SIZE;
+  if (e->num_envs < 0 || (e->field_stride != 0 && (e->field_stride < e->num_envs || (e->field_stride & 3)))) return QR_E_SIZE;
   if (!e->pos_vel || !e->att_rate) return QR_E_NULL;
   if ((reinterpret_cast<uintptr_t>(e->pos_vel) | reinterpret_cast<uintptr_t>(e->att_rate)) & 15u) return QR_E_ALIGN;
   a.pos_vel = e->pos_vel; a.att_rate = e->att_rate; a.integ = e->integ; a.params = e->params; a.goal = e->goal;
   a.episode = e->episode; a.steps = e->steps;
-  a.n = e->num_envs; a.env_offset = e->env_offset; a.seed = e->seed;
+  a.n = e->num_envs; a.ld = e->field_stride > 0 ? e->field_stride : e->num_envs;
+  a.env_offset = e->env_offset; a.seed = e->seed;
   a.max_episode_steps = e->max_episode_steps; a.flags = e->flags;
   fill_coeffs(a.c, e->coeffs);
   return 0;
 }
 
-// Workgroup size: one wavefront per workgroup while that still gives <= 4096 workgroups
-// (small batches: every SIMD gets a wave, no cross-wave barriers); 256 threads beyond that,
-// where 64-thread workgroups would be bound by the dispatcher (~3.6 workgroups/ns measured).
-static inline int pick_block(int64_t n) { return n <= 64 * 4096 ? 64 : 256; }
+// Workgroup size: one wavefront per workgroup at every batch size.  Small batches: every SIMD
+// gets a wave (N = 65 536 -> 1024 workgroups) and the LDS transposes need no cross-wave
+// barrier.  Large batches: measured faster than 256-thread workgroups too (1 M envs: 38.7 vs
+// 42.5 us Quad-v0, 82 vs 114 us Decoupled) — the dispatcher's ~3.6 workgroups/ns is far above
+// what a bandwidth-bound launch needs, and barriers of 4-wave groups at 1-2 waves/SIMD stall.
+static inline int pick_block(int64_t) { return 64; }
 
 template <int KIND, typename XV, typename QW>
 static void launch_kind(const Args& a, hipStream_t s) {
-  if (pick_block(a.n) == 64) {
-    hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64>), dim3((unsigned)((a.n + 63) / 64)), dim3(64), 0, s, a);
-  } else {
-    hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 256>), dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a);
-  }
+  hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64>), dim3((unsigned)((a.n + 63) / 64)), dim3(64), 0, s, a);
 }
 
 template <typename XV, typename QW>

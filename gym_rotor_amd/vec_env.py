@@ -31,6 +31,13 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+def _field_stride(n: int) -> int:
+    """Elements between consecutive fields of the SoA buffers: N rounded up to a multiple of 4.
+    (Padding the stride off powers of two was measured on MI355X and makes no difference: the
+    memory system hashes channels; tools/microbench.py sweep)"""
+    return (n + 3) // 4 * 4
+
+
 class QuadVecEnv:
     """Batched Quad-v0 / CoupledWrapper / DecoupledWrapper.
 
@@ -57,7 +64,7 @@ class QuadVecEnv:
                  substeps: int = 1, layout: str = "mixed", use_UDM: bool = True,
                  UDM_percentage: float = 10.0, auto_reset: bool = False, max_episode_steps: int = 0,
                  env_offset: int = 0, want_raw_reward: bool = False, obs_rows: Optional[bool] = None,
-                 constants: Optional[QuadConstants] = None):
+                 field_stride: Optional[int] = None, constants: Optional[QuadConstants] = None):
         if kind not in KINDS:
             raise ValueError(f"kind must be one of {KINDS}, got {kind!r}")
         if num_envs < 1:
@@ -104,17 +111,21 @@ class QuadVecEnv:
         self.single_action_space = Box(-1.0, 1.0, shape=(self.action_dim,), dtype=np.float32)
         self.observation_space, self.action_space = self.single_observation_space, self.single_action_space
 
-        # ---- device buffers (SoA [field][N]) ----
+        # ---- device buffers (SoA [field][ld], ld >= N: see field_stride in quadrotor_hip.h) ----
         N, dev = self.num_envs, self.device
+        self._ld = _field_stride(N) if field_stride is None else int(field_stride)
+        if self._ld < N or self._ld % 4:
+            raise ValueError("field_stride must be a multiple of 4 and >= num_envs")
         xv_dt = torch.float64 if layout == "f64" else torch.float32
         qw_dt = torch.float32 if layout == "f32" else torch.float64
-        self._pos_vel = torch.zeros(6, N, dtype=xv_dt, device=dev)    # x(3), v(3)
-        self._att_rate = torch.zeros(7, N, dtype=qw_dt, device=dev)   # q(w,x,y,z), W(3)
+        self._pos_vel = self._soa(6, xv_dt)     # x(3), v(3)
+        self._att_rate = self._soa(7, qw_dt)    # q(w,x,y,z), W(3)
         self._att_rate[0].fill_(1.0)
-        self._integ = None if kind == "quad" else torch.zeros(8, N, dtype=torch.float32, device=dev)
+        self._integ = None if kind == "quad" else self._soa(8, torch.float32)
         self._params = None
         if self.use_UDM:
-            self._params = torch.tensor(c.nominal_params, dtype=torch.float32, device=dev)[:, None].repeat(1, N).contiguous()
+            self._params = self._soa(6, torch.float32)
+            self._params.copy_(torch.tensor(c.nominal_params, dtype=torch.float32, device=dev)[:, None].expand(6, N))
         self._goal = None  # default hover goal until set_goal_state is called (quad.py:98-101)
         self._episode = torch.zeros(N, dtype=torch.int32, device=dev)
         self._steps = torch.zeros(N, dtype=torch.int32, device=dev) if self.max_episode_steps > 0 else None
@@ -142,10 +153,15 @@ class QuadVecEnv:
         self._closed = False
 
     # ------------------------------------------------------------------------------
+    def _soa(self, fields: int, dtype) -> torch.Tensor:
+        """[fields, N] view of a zeroed [fields, ld] buffer (the view starts at the buffer's base)."""
+        return torch.zeros(fields, self._ld, dtype=dtype, device=self.device)[:, :self.num_envs]
+
     def _sync_structs(self):
         e, o = self._cenv, self._cout
         e.kind, e.layout = _lib.KIND_ID[self.kind], _lib.LAYOUT_ID[self.layout]
-        e.num_envs, e.env_offset, e.seed = self.num_envs, self.env_offset, self.seed & (2 ** 64 - 1)
+        e.num_envs, e.field_stride = self.num_envs, self._ld
+        e.env_offset, e.seed = self.env_offset, self.seed & (2 ** 64 - 1)
         e.pos_vel, e.att_rate = _ptr(self._pos_vel), _ptr(self._att_rate)
         e.integ, e.params, e.goal = _ptr(self._integ), _ptr(self._params), _ptr(self._goal)
         e.episode, e.steps = _ptr(self._episode), _ptr(self._steps)
@@ -255,7 +271,7 @@ class QuadVecEnv:
     def set_goal_state(self, xd, vd, b1d, b1d_dot=None, Wd=None):
         """quad.py:413-418.  b1d_dot is accepted and ignored (unused by the step path)."""
         if self._goal is None:
-            self._goal = torch.zeros(12, self.num_envs, dtype=torch.float32, device=self.device)
+            self._goal = self._soa(12, torch.float32)
             self._cenv.goal = self._goal.data_ptr()
         self._goal[0:3] = self._rows3(xd, "xd")
         self._goal[3:6] = self._rows3(vd, "vd")
@@ -281,7 +297,7 @@ class QuadVecEnv:
             self._integ.copy_(torch.as_tensor(integ, device=self.device).to(torch.float32).t())
         if params is not None:
             if self._params is None:
-                self._params = torch.empty(6, self.num_envs, dtype=torch.float32, device=self.device)
+                self._params = self._soa(6, torch.float32)
                 self._cenv.params = self._params.data_ptr()
             self._params.copy_(torch.as_tensor(params, device=self.device).to(torch.float32).t())
 
@@ -296,9 +312,9 @@ class QuadVecEnv:
             if v is None:
                 continue
             if cur is None:
-                setattr(self, "_" + k, v.to(self.device).clone())
-            else:
-                cur.copy_(v)
+                cur = self._soa(v.shape[0], v.dtype) if v.dim() == 2 else torch.zeros_like(v, device=self.device)
+                setattr(self, "_" + k, cur)
+            cur.copy_(v)
         self._sync_structs()
 
     @property

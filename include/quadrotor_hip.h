@@ -15,6 +15,7 @@
  *     launch.  Nothing is ever computed on the host: there is no CPU fallback.
  *   - layout: per-env quantities are SoA, `field-major [F][N]` (lane i touches
  *     base[f*N + i], so a 64-lane wavefront reads 256/512 contiguous bytes per field).
+ *     With field_stride = L the address is base[f*L + i].
  *     Caller-facing rows (actions in, observations/reward/done out) are AoS `[N][D]`
  *     row-major, i.e. what a policy network produces/consumes; the kernels transpose
  *     through LDS so that those rows are written with coalesced 16-byte stores.
@@ -40,7 +41,7 @@
 extern "C" {
 #endif
 
-#define QR_ABI_VERSION 2
+#define QR_ABI_VERSION 3
 
 /* env kinds */
 #define QR_KIND_QUAD      0 /* QuadEnv            gym_rotor/envs/quad.py:19            */
@@ -81,6 +82,9 @@ typedef struct QrEnv {
   int32_t kind;        /* QR_KIND_*                                                       */
   int32_t layout;      /* QR_LAYOUT_*                                                     */
   int64_t num_envs;    /* N                                                               */
+  int64_t field_stride;/* elements between consecutive fields of EVERY SoA buffer below; 0 = N.
+                          A multiple of 4, >= N.  Padding it off a power of two avoids all
+                          fields of an env landing on one HBM channel.        */
   int64_t env_offset;  /* global id of local env 0 (multi-GPU shard offset; RNG key)      */
   uint64_t seed;       /* RNG seed; draws depend only on (seed, global env id, episode)   */
   void*    pos_vel;    /* [6][N]  x, v                                         in/out      */
