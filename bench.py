@@ -151,7 +151,14 @@ def main():
                     for i in range(a.steps):
                         env.step(acts[i % len(acts)])
             torch.cuda.current_stream(dev).wait_stream(side)
-            graph.replay()  # untimed: the first replay uploads the graph
+            # untimed: the first replay uploads the graph; keep replaying for ~50 ms so the timed
+            # replay runs at the clocks a training loop sees, not at the idle-to-busy ramp
+            t_w = time.perf_counter()
+            while True:
+                graph.replay()
+                torch.cuda.synchronize(dev)
+                if time.perf_counter() - t_w > 0.05:
+                    break
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier() if timed else torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
@@ -213,6 +220,18 @@ def main():
             w2, d2, _, _, _ = run(not auto_reset, False)
             out["config"]["other_reset_mode"] = {"auto_reset": not auto_reset, "env_steps_per_s": N * a.steps / w2,
                                                  "avg_launch_us": d2 * 1e3 / a.steps}
+            # secondary figure: fused rollout, T=100 env-steps per launch with the state in registers
+            # (SURVEY.md 8(d) config 2 asks for both per-launch step() and rollout(T=100))
+            env = QuadVecEnv(a.kind, N, device=dev, seed=0, substeps=a.substeps, layout=a.layout, use_UDM=True,
+                             auto_reset=auto_reset)
+            env.reset("train")
+            acts = torch.rand(100, N, env.action_dim, device=dev) * 2 - 1
+            ro = env.rollout(acts)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); env.rollout(acts, out=ro); e1.record(); torch.cuda.synchronize(dev)
+            out["config"]["rollout_T100"] = {"env_steps_per_s": N * 100 / (e0.elapsed_time(e1) * 1e-3),
+                                             "us_per_env_step_batch": e0.elapsed_time(e1) * 10.0}
             if a.cpu_seconds > 0:
                 out["cpu_baseline"] = cpu_baseline(a.kind, a.cpu_seconds)
         print(json.dumps(out))

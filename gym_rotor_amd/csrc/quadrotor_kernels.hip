@@ -524,27 +524,60 @@ __device__ __forceinline__ float sq3(const float* v) { return v[0] * v[0] + v[1]
 __device__ __forceinline__ bool out3(const float* v) { return !(fabsf(v[0]) < 1.0f) || !(fabsf(v[1]) < 1.0f) || !(fabsf(v[2]) < 1.0f); }
 __device__ __forceinline__ float interp01(float r, float rmin, float inv_nrmin) { return clampT((r - rmin) * inv_nrmin, 0.0f, 1.0f); }
 
-// ---- SoA load / store of the 13-word state ----
+// ---- SoA access through buffer resources ------------------------------------------------
+// Field f of env (first + lane) of a [F][L] buffer lives at byte (f*L + first + lane)*sizeof(E).
+// `first` and L are wave-uniform, so the access is issued as
+//     buffer_load/store  vdata, voffset = lane*sizeof(E), s[rsrc], soffset = (f*L + first)*sizeof(E)
+// with the 128-bit descriptor and soffset in SGPRs (built once per wave by the SALU).  The
+// equivalent global_load through a pointer makes hipcc chain 64-bit VALU address arithmetic
+// per access (v_mad_u64_u32 / v_lshl_add_u64: ~110 of the ~1100 instructions of the step).
+// soffset is 32-bit: every SoA buffer must be < 4 GiB (checked on the host, QR_E_SIZE).
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+
+template <typename E>
+struct SoA {
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned L;  // elements between fields
+  __device__ __forceinline__ SoA(const void* base, int fields, int64_t ld)
+      : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)((int64_t)fields * ld * (int64_t)sizeof(E) > 0x7fffffffLL ? 0x7fffffffLL : (int64_t)fields * ld * (int64_t)sizeof(E)), 0x00020000)),
+        L((unsigned)ld) {}
+  __device__ __forceinline__ unsigned soff(int f, unsigned first) const { return ((unsigned)f * L + first) * (unsigned)sizeof(E); }
+  __device__ __forceinline__ E load(int f, unsigned first, unsigned lane) const {
+    if constexpr (sizeof(E) == 4) {
+      return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4u, soff(f, first), 0));
+    } else {
+      return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane * 8u, soff(f, first), 0));
+    }
+  }
+  __device__ __forceinline__ void store(int f, unsigned first, unsigned lane, E v) const {
+    if constexpr (sizeof(E) == 4) {
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsrc, lane * 4u, soff(f, first), 0);
+    } else {
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_t, v), rsrc, lane * 8u, soff(f, first), 0);
+    }
+  }
+};
+
 template <typename XV, typename QW, typename T>
-__device__ __forceinline__ void load_state(const Args& a, int64_t i, Work<T>& w) {
-  const XV* pv = reinterpret_cast<const XV*>(a.pos_vel);
-  const QW* ar = reinterpret_cast<const QW*>(a.att_rate);
-  const int64_t L = a.ld;
+__device__ __forceinline__ void load_state(const Args& a, int64_t first64, unsigned lane, Work<T>& w) {
+  const SoA<XV> pv(a.pos_vel, 6, a.ld);
+  const SoA<QW> ar(a.att_rate, 7, a.ld);
+  const unsigned first = (unsigned)first64;
 #pragma unroll
-  for (int f = 0; f < 3; ++f) { w.x[f] = T(pv[(int64_t)f * L + i]); w.y[f] = T(pv[(int64_t)(3 + f) * L + i]); }
+  for (int f = 0; f < 3; ++f) { w.x[f] = T(pv.load(f, first, lane)); w.y[f] = T(pv.load(3 + f, first, lane)); }
 #pragma unroll
-  for (int f = 0; f < 7; ++f) w.y[3 + f] = T(ar[(int64_t)f * L + i]);
+  for (int f = 0; f < 7; ++f) w.y[3 + f] = T(ar.load(f, first, lane));
 }
 
 template <typename XV, typename QW, typename T>
-__device__ __forceinline__ void store_state(const Args& a, int64_t i, const Work<T>& w) {
-  XV* pv = reinterpret_cast<XV*>(a.pos_vel);
-  QW* ar = reinterpret_cast<QW*>(a.att_rate);
-  const int64_t L = a.ld;
+__device__ __forceinline__ void store_state(const Args& a, int64_t first64, unsigned lane, const Work<T>& w) {
+  const SoA<XV> pv(a.pos_vel, 6, a.ld);
+  const SoA<QW> ar(a.att_rate, 7, a.ld);
+  const unsigned first = (unsigned)first64;
 #pragma unroll
-  for (int f = 0; f < 3; ++f) { pv[(int64_t)f * L + i] = (XV)w.x[f]; pv[(int64_t)(3 + f) * L + i] = (XV)w.y[f]; }
+  for (int f = 0; f < 3; ++f) { pv.store(f, first, lane, (XV)w.x[f]); pv.store(3 + f, first, lane, (XV)w.y[f]); }
 #pragma unroll
-  for (int f = 0; f < 7; ++f) ar[(int64_t)f * L + i] = (QW)w.y[3 + f];
+  for (int f = 0; f < 7; ++f) ar.store(f, first, lane, (QW)w.y[3 + f]);
 }
 
 template <typename T>
@@ -572,6 +605,8 @@ __global__ __launch_bounds__(B, QR_WAVES_PER_SIMD) void step_kernel(const Args a
   constexpr int A = KT::A, D0 = KT::D0, D1 = KT::D1 ? KT::D1 : 1, NAG = KT::NAG;
   __shared__ __attribute__((aligned(16))) float smem[B * (D0 > A ? D0 : A)];
   const int tid = threadIdx.x;
+  const unsigned lane = threadIdx.x;
+  const unsigned ufirst = blockIdx.x * (unsigned)B;
   const int64_t first = (int64_t)blockIdx.x * B;
   const int64_t i = first + tid;
   const int64_t N = a.n, L = a.ld;
@@ -586,26 +621,29 @@ __global__ __launch_bounds__(B, QR_WAVES_PER_SIMD) void step_kernel(const Args a
   // ---- load the env's working set (SoA, lane-contiguous) ----
   idle_work(w);
   if (active) {
-    load_state<XV, QW, T>(a, i, w);
+    load_state<XV, QW, T>(a, first, lane, w);
     if (a.params) {
+      const SoA<float> prm(a.params, 6, L);
 #pragma unroll
-      for (int f = 0; f < 6; ++f) w.prm[f] = a.params[(int64_t)f * L + i];
+      for (int f = 0; f < 6; ++f) w.prm[f] = prm.load(f, ufirst, lane);
       w.nominal = false;
     }
     if (a.goal) {
+      const SoA<float> goal(a.goal, 12, L);
 #pragma unroll
-      for (int f = 0; f < 12; ++f) w.goal[f] = a.goal[(int64_t)f * L + i];
+      for (int f = 0; f < 12; ++f) w.goal[f] = goal.load(f, ufirst, lane);
     }
     if (KIND != QR_KIND_QUAD) {
+      const SoA<float> integ(a.integ, 8, L);
 #pragma unroll
-      for (int f = 0; f < 8; ++f) w.integ[f] = a.integ[(int64_t)f * L + i];
+      for (int f = 0; f < 8; ++f) w.integ[f] = integ.load(f, ufirst, lane);
     }
   }
-  int32_t steps = (a.steps && active) ? a.steps[i] : 0;
+  int32_t steps = (a.steps && active) ? (a.steps + first)[lane] : 0;
   // The episode counter (RNG stream id) is fetched with the rest of the working set: read
   // lazily inside the reset path it would put a full memory round-trip (~1.5 us) on the
   // critical path of every wave that has a resetting lane.
-  int32_t episode = ((a.flags & QR_FLAG_AUTO_RESET) && active) ? a.episode[i] : 0;
+  int32_t episode = ((a.flags & QR_FLAG_AUTO_RESET) && active) ? (a.episode + first)[lane] : 0;
   bool params_dirty = false;
 
   for (int t = 0; t < a.n_steps; ++t) {
@@ -614,7 +652,7 @@ __global__ __launch_bounds__(B, QR_WAVES_PER_SIMD) void step_kernel(const Args a
     const float* abase = a.action + ((int64_t)t * N + first) * A;
     if constexpr (A == 4) {
       if (active) {
-        const float4 v = reinterpret_cast<const float4*>(abase)[tid];
+        const float4 v = reinterpret_cast<const float4*>(abase)[lane];
         act[0] = v.x; act[1] = v.y; act[2] = v.z; act[3] = v.w;
       } else {
         act[0] = act[1] = act[2] = act[3] = 0.f;
@@ -731,7 +769,7 @@ __global__ __launch_bounds__(B, QR_WAVES_PER_SIMD) void step_kernel(const Args a
         const bool randomise = !eval && !(a.flags & QR_FLAG_NO_UDM) && a.params != nullptr;
         sample_reset(w, d, randomise, eval, c);
         if (a.params != nullptr) params_dirty = true;
-        a.episode[i] = episode;
+        (a.episode + first)[lane] = episode;
         steps = 0;
         quat_to_R(&w.y[3], R);
         if constexpr (KIND != QR_KIND_QUAD) {
@@ -759,29 +797,31 @@ __global__ __launch_bounds__(B, QR_WAVES_PER_SIMD) void step_kernel(const Args a
     if constexpr (KT::D1 > 0) store_rows<B, D1>(a.obs1 + row0 * D1, o1, smem, tid, rows);
     if (active) {
       if constexpr (NAG == 1) {
-        a.reward[row0 + tid] = rwd[0];
-        if (a.reward_raw) a.reward_raw[row0 + tid] = rraw[0];
-        a.done[row0 + tid] = dn[0] ? 1 : 0;
+        (a.reward + row0)[lane] = rwd[0];
+        if (a.reward_raw) (a.reward_raw + row0)[lane] = rraw[0];
+        (a.done + row0)[lane] = dn[0] ? 1 : 0;
       } else {
-        reinterpret_cast<float2*>(a.reward)[row0 + tid] = make_float2(rwd[0], rwd[NAG - 1]);
-        if (a.reward_raw) reinterpret_cast<float2*>(a.reward_raw)[row0 + tid] = make_float2(rraw[0], rraw[NAG - 1]);
-        reinterpret_cast<uchar2*>(a.done)[row0 + tid] = make_uchar2(dn[0] ? 1 : 0, dn[NAG - 1] ? 1 : 0);
+        (reinterpret_cast<float2*>(a.reward) + row0)[lane] = make_float2(rwd[0], rwd[NAG - 1]);
+        if (a.reward_raw) (reinterpret_cast<float2*>(a.reward_raw) + row0)[lane] = make_float2(rraw[0], rraw[NAG - 1]);
+        (reinterpret_cast<uchar2*>(a.done) + row0)[lane] = make_uchar2(dn[0] ? 1 : 0, dn[NAG - 1] ? 1 : 0);
       }
-      if (a.truncated) a.truncated[row0 + tid] = trunc ? 1 : 0;
+      if (a.truncated) (a.truncated + row0)[lane] = trunc ? 1 : 0;
     }
   }
 
   // ---- write the working set back ----
   if (active) {
-    store_state<XV, QW, T>(a, i, w);
+    store_state<XV, QW, T>(a, first, lane, w);
     if (KIND != QR_KIND_QUAD) {
+      const SoA<float> integ(a.integ, 8, L);
 #pragma unroll
-      for (int f = 0; f < 8; ++f) a.integ[(int64_t)f * L + i] = w.integ[f];
+      for (int f = 0; f < 8; ++f) integ.store(f, ufirst, lane, w.integ[f]);
     }
-    if (a.steps) a.steps[i] = steps;
+    if (a.steps) (a.steps + first)[lane] = steps;
     if (params_dirty) {
+      const SoA<float> prm(a.params, 6, L);
 #pragma unroll
-      for (int f = 0; f < 6; ++f) a.params[(int64_t)f * L + i] = w.prm[f];
+      for (int f = 0; f < 6; ++f) prm.store(f, ufirst, lane, w.prm[f]);
     }
   }
 }
@@ -802,7 +842,7 @@ __global__ __launch_bounds__(64) void error_obs_kernel(const Args a) {
   Work<T> w;
   idle_work(w);
   if (active) {
-    load_state<XV, QW, T>(a, i, w);
+    load_state<XV, QW, T>(a, first, (unsigned)tid, w);
     if (a.goal) {
 #pragma unroll
       for (int f = 0; f < 12; ++f) w.goal[f] = a.goal[(int64_t)f * L + i];
@@ -838,7 +878,7 @@ __global__ __launch_bounds__(64) void reset_kernel(const Args a) {
   Draws d;
   draw20(d, a.seed, (uint64_t)(a.env_offset + i), (uint32_t)episode);
   sample_reset(w, d, randomise, eval, a.c);
-  store_state<XV, QW, T>(a, i, w);
+  store_state<XV, QW, T>(a, (int64_t)blockIdx.x * 64, threadIdx.x, w);
   if (a.params) {
 #pragma unroll
     for (int f = 0; f < 6; ++f) a.params[(int64_t)f * L + i] = w.prm[f];
@@ -857,7 +897,7 @@ __global__ __launch_bounds__(64) void get_state_kernel(const Args a) {
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= a.n) return;
   Work<double> w;
-  load_state<XV, QW, double>(a, i, w);
+  load_state<XV, QW, double>(a, (int64_t)blockIdx.x * 64, threadIdx.x, w);
   double R[9];
   quat_to_R(&w.y[3], R);
   double* o = a.rows_out + i * 18;
@@ -881,7 +921,7 @@ __global__ __launch_bounds__(64) void set_state_kernel(const Args a) {
   R_to_quat(r + 6, q);
 #pragma unroll
   for (int j = 0; j < 4; ++j) w.y[3 + j] = q[j];
-  store_state<XV, QW, double>(a, i, w);
+  store_state<XV, QW, double>(a, (int64_t)blockIdx.x * 64, threadIdx.x, w);
 }
 
 // ------------------------------------------------------------------------------------
@@ -905,6 +945,7 @@ static int fill_env(Args& a, const QrEnv* e) {
   if (!e) return QR_E_NULL;
   if (e->kind < 0 || e->kind > 2 || e->layout < 0 || e->layout > 2) return QR_E_KIND;
   if (e->num_envs < 0 || (e->field_stride != 0 && (e->field_stride < e->num_envs || (e->field_stride & 3)))) return QR_E_SIZE;
+  if ((e->field_stride > 0 ? e->field_stride : e->num_envs) > (int64_t)0x7fffffff / (12 * 8)) return QR_E_SIZE;  // SoA buffers < 2 GiB (32-bit buffer offsets)
   if (!e->pos_vel || !e->att_rate) return QR_E_NULL;
   if ((reinterpret_cast<uintptr_t>(e->pos_vel) | reinterpret_cast<uintptr_t>(e->att_rate)) & 15u) return QR_E_ALIGN;
   a.pos_vel = e->pos_vel; a.att_rate = e->att_rate; a.integ = e->integ; a.params = e->params; a.goal = e->goal;

@@ -52,3 +52,23 @@ for n in map(int, a.envs.split(",")):
                     us = time_env(env, a.steps)
                     print(f"{kind:10s} {n:8d} {dt:>5s} {sub:3d} {ar:2d} {us:9.2f} {n / us / 1e3:12.2f} {(ALGO_BYTES[kind] + 24) * n / us / 1e3:9.1f}", flush=True)
                     del env
+
+# fused rollout: T env-steps per launch, state in registers (rollout(T=100))
+print(f"\n{'rollout':10s} {'N':>8s} {'lay':>5s} {'T':>4s} {'ar':>2s} {'us/step':>9s} {'Genv-steps/s':>12s}")
+for n in map(int, a.envs.split(",")):
+    for kind in a.kinds.split(","):
+        for ar in map(int, a.auto_reset.split(",")):
+            T = 100
+            env = QuadVecEnv(kind, n, device=dev, substeps=1, auto_reset=bool(ar), layout="mixed",
+                             obs_rows=True if kind != "quad" else bool(a.obs_rows))
+            env.reset("train")
+            acts = torch.rand(T, n, env.action_dim, device=dev) * 2 - 1
+            out = env.rollout(acts)
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); env.rollout(acts, out=out); e1.record(); torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) * 1e3 / T)
+            print(f"{kind:10s} {n:8d} mixed {T:4d} {ar:2d} {best:9.3f} {n / best / 1e3:12.2f}", flush=True)
+            del env, out, acts
