@@ -16,7 +16,8 @@ LIB_PATH = os.environ.get("QR_LIB", os.path.join(_HERE, "libquadrotor_hip.so"))
 KIND_QUAD, KIND_COUPLED, KIND_DECOUPLED = 0, 1, 2
 KIND_ID = {"quad": KIND_QUAD, "coupled": KIND_COUPLED, "decoupled": KIND_DECOUPLED}
 FLAG_AUTO_RESET, FLAG_EVAL_RESET, FLAG_NO_UDM = 1, 2, 4
-ABI_VERSION = 3
+ABI_VERSION = 4
+GOAL_EXTERNAL, GOAL_MODE0, GOAL_MODE1 = 0, 1, 2
 LAYOUT_ID = {"mixed": 0, "f64": 1, "f32": 2}
 
 ERRORS = {-1: "QR_E_NULL: a required pointer is NULL", -2: "QR_E_KIND: bad env kind",
@@ -24,6 +25,7 @@ ERRORS = {-1: "QR_E_NULL: a required pointer is NULL", -2: "QR_E_KIND: bad env k
 
 # every symbol include/quadrotor_hip.h declares
 SYMBOLS = ("qr_step", "qr_rollout", "qr_error_obs", "qr_reset", "qr_get_state", "qr_set_state",
+           "qr_traj_start", "qr_get_desired",
            "qr_default_coeffs", "qr_abi_version", "qr_step_kernel_info")
 
 
@@ -38,6 +40,7 @@ class QrEnv(C.Structure):
                 ("env_offset", C.c_int64), ("seed", C.c_uint64),
                 ("pos_vel", C.c_void_p), ("att_rate", C.c_void_p),
                 ("integ", C.c_void_p), ("params", C.c_void_p), ("goal", C.c_void_p),
+                ("traj", C.c_void_p), ("goal_mode", C.c_int32), ("reserved0", C.c_int32),
                 ("episode", C.c_void_p), ("steps", C.c_void_p),
                 ("max_episode_steps", C.c_int32), ("flags", C.c_uint32), ("coeffs", QrCoeffs)]
 
@@ -84,6 +87,10 @@ def load():
     lib.qr_get_state.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p]
     lib.qr_set_state.restype = C.c_int
     lib.qr_set_state.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.qr_traj_start.restype = C.c_int
+    lib.qr_traj_start.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.qr_get_desired.restype = C.c_int
+    lib.qr_get_desired.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.qr_step_kernel_info.restype = C.c_char_p
     lib.qr_step_kernel_info.argtypes = [C.c_int32, C.c_int32, C.c_int64, P(C.c_int32), P(C.c_int32)]
     if lib.qr_abi_version() != ABI_VERSION:

@@ -60,6 +60,7 @@ struct Args {
   float* integ;
   float* params;
   float* goal;
+  float* traj;
   int32_t* episode;
   int32_t* steps;
   // per-call
@@ -73,6 +74,10 @@ struct Args {
   const uint8_t* mask;
   double* rows_out;       // qr_get_state
   const double* rows_in;  // qr_set_state
+  const float* draws;     // qr_traj_start: injected [3][N] theta_b1d, t_traj, w_b1d
+  float* goal_rows;       // qr_get_desired: [N][15]
+  int32_t goal_mode;
+  int32_t store_goal;
   int64_t n;
   int64_t ld;             // elements between consecutive fields of every SoA buffer (>= n)
   int64_t env_offset;
@@ -211,10 +216,29 @@ __device__ __forceinline__ void coop_draw20(Draws& d, bool need, uint64_t seed, 
   }
 }
 
-// sin/cos of a random angle: hardware float evaluation (v_sin/v_cos, ~1e-6 — it is a random
-// draw) re-normalised in f64, so every factor, hence q, has unit norm to f64 round-off.
+// sin and cos of a float angle of moderate size (|x| < ~1e3): Cody-Waite reduction by pi/2 and
+// the cephes minimax polynomials on [-pi/4, pi/4]; ~1e-7 absolute.  Branch-free and small: the
+// OCML sincosf drags its Payne-Hanek slow path (and its registers) into every kernel using it.
+__device__ __forceinline__ void sincos_small(float x, float& sn, float& cs) {
+  const float k = rintf(x * 0.63661977236758134f);
+  float r = fmaf(-k, 1.5707962512969971f, x);
+  r = fmaf(-k, 7.5497894158615964e-08f, r);
+  const float r2 = r * r;
+  const float ps = fmaf(r * r2, fmaf(r2, fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+  const float pc = fmaf(r2 * r2, fmaf(r2, fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                        fmaf(-0.5f, r2, 1.0f));
+  const int q = (int)k;
+  const float s0 = (q & 1) ? pc : ps, c0 = (q & 1) ? ps : pc;
+  sn = (q & 2) ? -s0 : s0;
+  cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// sin/cos of a random angle re-normalised in f64, so every factor, hence q, has unit norm to
+// f64 round-off.
 __device__ __forceinline__ void unit_sincos(float ang, double& s, double& c) {
-  s = (double)__sinf(ang); c = (double)__cosf(ang);
+  float sf, cf;
+  sincos_small(ang, sf, cf);
+  s = (double)sf; c = (double)cf;
 #pragma unroll
   for (int it = 0; it < 2; ++it) {  // r = 1/sqrt(n2) to first order around 1: 1e-6 -> 1e-12 -> 1e-24
     const double r = 1.5 - 0.5 * (s * s + c * c);
@@ -520,6 +544,91 @@ __device__ __forceinline__ void error_obs(Work<T>& w, const T (&R)[9], const Coe
   }
 }
 
+// ------------------------------------------------------------------------------------
+// Goal generation: utils/trajectory_generator.py modes 0 and 1, per env.
+// tr[8] = {calls, theta_init, b1d_x | w_b1d, b1d_y | smooth_term, x_init[3], -}
+// ------------------------------------------------------------------------------------
+// mark_traj_start(state) (:176-204) + the episode-start branch of calculate_desired:
+//   mode 0 (:141-148): b1d = Rz(theta) b1_proj, theta ~ U(+-25 deg)
+//   mode 1 (:253-266): x_init = x, t_traj ~ U(2,5), smooth = -ln(0.001)/t_traj, w_b1d ~ U(+-0.15 pi)
+template <typename T>
+__device__ __forceinline__ void traj_start(const Work<T>& w, float (&tr)[8], int goal_mode, float theta_b1d, float t_traj, float w_b1d) {
+  const T qw = w.y[3], qx = w.y[4], qy = w.y[5], qz = w.y[6];
+  const float b1x = (float)(T(1) - T(2) * (qy * qy + qz * qz)), b1y = (float)(T(2) * (qx * qy + qw * qz));
+  const float theta_init = atan2f(b1y, b1x);  // update_initial_state (:199-204)
+  tr[0] = 0.0f;
+  tr[1] = theta_init;
+  if (goal_mode == QR_GOAL_MODE0) {
+    float sn, cs;
+    sincos_small(theta_init + theta_b1d, sn, cs);  // Rz(theta) (cos th_i, sin th_i, 0)
+    tr[2] = cs; tr[3] = sn;
+    tr[4] = tr[5] = tr[6] = 0.0f;
+  } else {
+    tr[2] = w_b1d;
+    tr[3] = 6.907755278982137f / t_traj;  // -ln(0.001) / t_traj
+#pragma unroll
+    for (int j = 0; j < 3; ++j) tr[4 + j] = (float)w.x[j];
+  }
+  tr[7] = 0.0f;
+}
+
+// Draws of an episode start that the reset sampler leaves unused (word 19 of the env's Philox
+// stream): mode 0 takes 24 bits for theta; mode 1 splits it 16/16 into t_traj and w_b1d.
+__device__ __forceinline__ void traj_draws(uint32_t r19, float& theta_b1d, float& t_traj, float& w_b1d) {
+  theta_b1d = (float)(25.0 * kPi / 180.0) * fmaf((float)(r19 >> 8), 0x1p-23f, 0x1p-24f - 1.0f);
+  t_traj = 2.0f + 3.0f * fmaf((float)(r19 >> 16), 0x1p-16f, 0x1p-17f);
+  w_b1d = (float)(0.15 * kPi) * fmaf((float)(r19 & 0xFFFFu), 0x1p-15f, 0x1p-16f - 1.0f);
+}
+
+// get_desired(state, mode) (:113-173) for the state in w: advances the call counter, fills
+// w.goal = (xd, vd, b1d, Wd) and returns b1d_dot.
+template <typename T>
+__device__ __forceinline__ void traj_goal(Work<T>& w, float (&tr)[8], int goal_mode, const Coeffs& c, float (&b1d_dot)[3]) {
+  tr[0] += 1.0f;  // update_current_time (:224-229): t = t + dt on every call
+  float b1d[3];
+  if (goal_mode == QR_GOAL_MODE0) {  // set_desired_states_to_zero + the b1d drawn at episode start
+#pragma unroll
+    for (int j = 0; j < 6; ++j) w.goal[j] = 0.0f;
+    b1d[0] = tr[2]; b1d[1] = tr[3]; b1d[2] = 0.0f;
+    b1d_dot[0] = b1d_dot[1] = b1d_dot[2] = 0.0f;
+  } else {  // hovering (:268-277), x_goal = 0
+    const float t = tr[0] * (float)c.dt;
+    const float wb = tr[2], sm = tr[3];
+    const float e = expf(-sm * t);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { w.goal[j] = tr[4 + j] * e; w.goal[3 + j] = -tr[4 + j] * sm * e; }
+    float sn, cs;
+    sincos_small(fmaf(wb, t, tr[1]), sn, cs);
+    b1d[0] = cs; b1d[1] = sn; b1d[2] = 0.0f;
+    b1d_dot[0] = -wb * sn; b1d_dot[1] = wb * cs; b1d_dot[2] = 0.0f;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) w.goal[6 + j] = b1d[j];
+  // Wd = (0, 0, b3 . (b1c x b1c_dot)) with b3' = R hat(W) e3 = W2 b1 - W1 b2 (:165-172)
+  T R[9];
+  quat_to_R(&w.y[3], R);
+  const T W1 = w.y[7], W2 = w.y[8];
+  T b3d[3], b1c[3], b1cd[3];
+  const T d0 = T(b1d[0]), d1 = T(b1d[1]), d2 = T(b1d[2]);
+  const T dd0 = T(b1d_dot[0]), dd1 = T(b1d_dot[1]), dd2 = T(b1d_dot[2]);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) b3d[j] = W2 * R[j] - W1 * R[3 + j];
+  const T b1d_b3 = d0 * R[6] + d1 * R[7] + d2 * R[8];
+  const T b1dd_b3 = dd0 * R[6] + dd1 * R[7] + dd2 * R[8];
+  const T b1d_b3d = d0 * b3d[0] + d1 * b3d[1] + d2 * b3d[2];
+  const T dv[3] = {d0, d1, d2}, ddv[3] = {dd0, dd1, dd2};
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    b1c[j] = dv[j] - b1d_b3 * R[6 + j];
+    b1cd[j] = ddv[j] - (b1dd_b3 * R[6 + j] + b1d_b3d * R[6 + j] + b1d_b3 * b3d[j]);
+  }
+  const T oc0 = b1c[1] * b1cd[2] - b1c[2] * b1cd[1];
+  const T oc1 = b1c[2] * b1cd[0] - b1c[0] * b1cd[2];
+  const T oc2 = b1c[0] * b1cd[1] - b1c[1] * b1cd[0];
+  w.goal[9] = 0.0f; w.goal[10] = 0.0f;
+  w.goal[11] = (float)(R[6] * oc0 + R[7] * oc1 + R[8] * oc2);
+}
+
 __device__ __forceinline__ float sq3(const float* v) { return v[0] * v[0] + v[1] * v[1] + v[2] * v[2]; }
 __device__ __forceinline__ bool out3(const float* v) { return !(fabsf(v[0]) < 1.0f) || !(fabsf(v[1]) < 1.0f) || !(fabsf(v[2]) < 1.0f); }
 __device__ __forceinline__ float interp01(float r, float rmin, float inv_nrmin) { return clampT((r - rmin) * inv_nrmin, 0.0f, 1.0f); }
@@ -598,8 +707,10 @@ __device__ __forceinline__ void idle_work(Work<T>& w) {  // lanes past the ragge
 // ------------------------------------------------------------------------------------
 // The fused step / rollout kernel
 // ------------------------------------------------------------------------------------
-template <int KIND, typename XV, typename QW, int B>
-__global__ __launch_bounds__(B, QR_WAVES_PER_SIMD) void step_kernel(const Args a) {
+// TRAJ = the goal generator (trajectory_generator.py modes 0/1) is fused into the step; a
+// separate instantiation so that the default path carries none of its registers.
+template <int KIND, typename XV, typename QW, int B, bool TRAJ>
+__global__ __launch_bounds__(B, (TRAJ ? 1 : QR_WAVES_PER_SIMD)) void step_kernel(const Args a) {
   using T = QW;  // arithmetic type
   using KT = KindTraits<KIND>;
   constexpr int A = KT::A, D0 = KT::D0, D1 = KT::D1 ? KT::D1 : 1, NAG = KT::NAG;
@@ -639,6 +750,15 @@ __global__ __launch_bounds__(B, QR_WAVES_PER_SIMD) void step_kernel(const Args a
       for (int f = 0; f < 8; ++f) w.integ[f] = integ.load(f, ufirst, lane);
     }
   }
+  float tr[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) tr[f] = 0.0f;
+  const int goal_mode = TRAJ ? a.goal_mode : QR_GOAL_EXTERNAL;  // wave-uniform
+  if (TRAJ && active) {
+    const SoA<float> traj(a.traj, 8, L);
+#pragma unroll
+    for (int f = 0; f < 7; ++f) tr[f] = traj.load(f, ufirst, lane);
+  }
   int32_t steps = (a.steps && active) ? (a.steps + first)[lane] : 0;
   // The episode counter (RNG stream id) is fetched with the rest of the working set: read
   // lazily inside the reset path it would put a full memory round-trip (~1.5 us) on the
@@ -664,6 +784,11 @@ __global__ __launch_bounds__(B, QR_WAVES_PER_SIMD) void step_kernel(const Args a
 #if QR_ABLATE == 2  // measurement build: memory traffic only (no integration)
     w.x[0] += T(act[0]);
 #else
+    // ---- goal for this step from the pre-step state (main.py:145-147) ----
+    if constexpr (TRAJ) {
+      float b1d_dot[3];
+      traj_goal(w, tr, goal_mode, c, b1d_dot);
+    }
     // ---- action_wrapper ----
     Dyn<T> dyn;
     action_map<KIND, T>(act, w, dyn);
@@ -771,6 +896,12 @@ __global__ __launch_bounds__(B, QR_WAVES_PER_SIMD) void step_kernel(const Args a
         if (a.params != nullptr) params_dirty = true;
         (a.episode + first)[lane] = episode;
         steps = 0;
+        if constexpr (TRAJ) {  // mark_traj_start + first get_desired of the episode (main.py:227-229)
+          float th, tt, wb, b1d_dot[3];
+          traj_draws(d.r[19], th, tt, wb);
+          traj_start(w, tr, goal_mode, th, tt, wb);
+          traj_goal(w, tr, goal_mode, c, b1d_dot);
+        }
         quat_to_R(&w.y[3], R);
         if constexpr (KIND != QR_KIND_QUAD) {
 #pragma unroll
@@ -818,6 +949,14 @@ __global__ __launch_bounds__(B, QR_WAVES_PER_SIMD) void step_kernel(const Args a
       for (int f = 0; f < 8; ++f) integ.store(f, ufirst, lane, w.integ[f]);
     }
     if (a.steps) (a.steps + first)[lane] = steps;
+    if constexpr (TRAJ) {
+      const SoA<float> traj(a.traj, 8, L);
+      traj.store(0, ufirst, lane, tr[0]);
+      if (params_dirty || (a.flags & QR_FLAG_AUTO_RESET)) {  // the rest changes only at a reset
+#pragma unroll
+        for (int f = 1; f < 7; ++f) traj.store(f, ufirst, lane, tr[f]);
+      }
+    }
     if (params_dirty) {
       const SoA<float> prm(a.params, 6, L);
 #pragma unroll
@@ -924,6 +1063,65 @@ __global__ __launch_bounds__(64) void set_state_kernel(const Args a) {
   store_state<XV, QW, double>(a, (int64_t)blockIdx.x * 64, threadIdx.x, w);
 }
 
+// mark_traj_start for masked envs, from the current state
+template <typename XV, typename QW>
+__global__ __launch_bounds__(64) void traj_start_kernel(const Args a) {
+  using T = QW;
+  const int64_t first = (int64_t)blockIdx.x * 64;
+  const unsigned lane = threadIdx.x;
+  const int64_t i = first + lane;
+  if (i >= a.n) return;
+  if (a.mask && !a.mask[i]) return;
+  Work<T> w;
+  load_state<XV, QW, T>(a, first, lane, w);
+  float th, tt, wb;
+  if (a.draws) {
+    th = a.draws[i]; tt = a.draws[a.n + i]; wb = a.draws[2 * a.n + i];
+  } else {
+    Draws d;
+    draw20(d, a.seed, (uint64_t)(a.env_offset + i), (uint32_t)a.episode[i]);
+    traj_draws(d.r[19], th, tt, wb);
+  }
+  float tr[8];
+  traj_start(w, tr, a.goal_mode, th, tt, wb);
+  const SoA<float> traj(a.traj, 8, a.ld);
+#pragma unroll
+  for (int f = 0; f < 8; ++f) traj.store(f, (unsigned)first, lane, tr[f]);
+}
+
+// get_desired for the current state: rows [N][15] = xd, vd, b1d, b1d_dot, Wd
+template <typename XV, typename QW>
+__global__ __launch_bounds__(64) void get_desired_kernel(const Args a) {
+  using T = QW;
+  const int64_t first = (int64_t)blockIdx.x * 64;
+  const unsigned lane = threadIdx.x;
+  const int64_t i = first + lane;
+  if (i >= a.n) return;
+  if (a.mask && !a.mask[i]) return;
+  Work<T> w;
+  idle_work(w);
+  load_state<XV, QW, T>(a, first, lane, w);
+  const SoA<float> traj(a.traj, 8, a.ld);
+  float tr[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) tr[f] = traj.load(f, (unsigned)first, lane);
+  float b1d_dot[3];
+  traj_goal(w, tr, a.goal_mode, a.c, b1d_dot);
+  traj.store(0, (unsigned)first, lane, tr[0]);
+  if (a.goal_rows) {
+    float* o = a.goal_rows + i * 15;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) o[j] = w.goal[j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { o[9 + j] = b1d_dot[j]; o[12 + j] = w.goal[9 + j]; }
+  }
+  if (a.store_goal && a.goal) {
+    const SoA<float> goal(a.goal, 12, a.ld);
+#pragma unroll
+    for (int f = 0; f < 12; ++f) goal.store(f, (unsigned)first, lane, w.goal[f]);
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------
@@ -946,9 +1144,12 @@ static int fill_env(Args& a, const QrEnv* e) {
   if (e->kind < 0 || e->kind > 2 || e->layout < 0 || e->layout > 2) return QR_E_KIND;
   if (e->num_envs < 0 || (e->field_stride != 0 && (e->field_stride < e->num_envs || (e->field_stride & 3)))) return QR_E_SIZE;
   if ((e->field_stride > 0 ? e->field_stride : e->num_envs) > (int64_t)0x7fffffff / (12 * 8)) return QR_E_SIZE;  // SoA buffers < 2 GiB (32-bit buffer offsets)
+  if (e->goal_mode < 0 || e->goal_mode > 2) return QR_E_KIND;
+  if (e->goal_mode != QR_GOAL_EXTERNAL && !e->traj) return QR_E_NULL;
   if (!e->pos_vel || !e->att_rate) return QR_E_NULL;
   if ((reinterpret_cast<uintptr_t>(e->pos_vel) | reinterpret_cast<uintptr_t>(e->att_rate)) & 15u) return QR_E_ALIGN;
   a.pos_vel = e->pos_vel; a.att_rate = e->att_rate; a.integ = e->integ; a.params = e->params; a.goal = e->goal;
+  a.traj = e->traj; a.goal_mode = e->goal_mode;
   a.episode = e->episode; a.steps = e->steps;
   a.n = e->num_envs; a.ld = e->field_stride > 0 ? e->field_stride : e->num_envs;
   a.env_offset = e->env_offset; a.seed = e->seed;
@@ -966,7 +1167,9 @@ static inline int pick_block(int64_t) { return 64; }
 
 template <int KIND, typename XV, typename QW>
 static void launch_kind(const Args& a, hipStream_t s) {
-  hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64>), dim3((unsigned)((a.n + 63) / 64)), dim3(64), 0, s, a);
+  const dim3 grid((unsigned)((a.n + 63) / 64));
+  if (a.goal_mode == QR_GOAL_EXTERNAL) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false>), grid, dim3(64), 0, s, a);
+  else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true>), grid, dim3(64), 0, s, a);
 }
 
 template <typename XV, typename QW>
@@ -1003,6 +1206,14 @@ static void launch_get_state(const Args& a, unsigned grid, hipStream_t s) {
 template <typename XV, typename QW>
 static void launch_set_state(const Args& a, unsigned grid, hipStream_t s) {
   hipLaunchKernelGGL((set_state_kernel<XV, QW>), dim3(grid), dim3(64), 0, s, a);
+}
+template <typename XV, typename QW>
+static void launch_traj_start(const Args& a, unsigned grid, hipStream_t s) {
+  hipLaunchKernelGGL((traj_start_kernel<XV, QW>), dim3(grid), dim3(64), 0, s, a);
+}
+template <typename XV, typename QW>
+static void launch_get_desired(const Args& a, unsigned grid, hipStream_t s) {
+  hipLaunchKernelGGL((get_desired_kernel<XV, QW>), dim3(grid), dim3(64), 0, s, a);
 }
 
 static int do_rollout(const QrEnv* env, const float* action, int32_t n_steps, int32_t substeps, const QrStepOut* out, void* stream) {
@@ -1092,6 +1303,33 @@ int qr_set_state(const QrEnv* env, const double* rows, const uint8_t* mask, void
   if (grid == 0) return 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   QR_DISPATCH_LAYOUT(env->layout, (qr::launch_set_state<XV, QW>(a, grid, s)));
+  return (int)hipGetLastError();
+}
+
+int qr_traj_start(const QrEnv* env, const uint8_t* mask, const float* draws, void* stream) {
+  qr::Args a{};
+  if (int rc = qr::fill_env(a, env)) return rc;
+  if (env->goal_mode == QR_GOAL_EXTERNAL) return QR_E_KIND;
+  if (!draws && !env->episode) return QR_E_NULL;
+  a.mask = mask; a.draws = draws;
+  const unsigned grid = (unsigned)((a.n + 63) / 64);
+  if (grid == 0) return 0;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  QR_DISPATCH_LAYOUT(env->layout, (qr::launch_traj_start<XV, QW>(a, grid, s)));
+  return (int)hipGetLastError();
+}
+
+int qr_get_desired(const QrEnv* env, const uint8_t* mask, float* rows, int32_t store_goal, void* stream) {
+  qr::Args a{};
+  if (int rc = qr::fill_env(a, env)) return rc;
+  if (env->goal_mode == QR_GOAL_EXTERNAL) return QR_E_KIND;
+  if (!rows && !store_goal) return QR_E_NULL;
+  if (store_goal && !env->goal) return QR_E_NULL;
+  a.goal_rows = rows; a.store_goal = store_goal; a.mask = mask;
+  const unsigned grid = (unsigned)((a.n + 63) / 64);
+  if (grid == 0) return 0;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  QR_DISPATCH_LAYOUT(env->layout, (qr::launch_get_desired<XV, QW>(a, grid, s)));
   return (int)hipGetLastError();
 }
 

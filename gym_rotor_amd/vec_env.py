@@ -52,6 +52,11 @@ class QuadVecEnv:
                     observation is then the first observation of the new episode
     max_episode_steps  >0 sets truncated when an episode reaches that many steps
     env_offset      global index of local env 0 (multi-GPU sharding; part of the RNG key)
+    goal_mode       None: goals come from set_goal_state() (hover default).  0 / 1: the reference's
+                    TrajectoryGenerator mode 0 (idle/warm-up: xd = vd = 0, b1d drawn per episode)
+                    or 1 (hovering: exponential approach of the origin + yaw rate) is evaluated
+                    INSIDE the step launch from the pre-step state, as main.py:145-147 does on the
+                    host every step; see mark_traj_start() / get_desired()
     obs_rows        write float32 observation rows [N,D].  Always on for the wrappers.  For
                     kind='quad' the observation is the next state (quad.py:269-271): True writes
                     it as float32 [N,18] rows each step; False (default) writes nothing and
@@ -64,7 +69,8 @@ class QuadVecEnv:
                  substeps: int = 1, layout: str = "mixed", use_UDM: bool = True,
                  UDM_percentage: float = 10.0, auto_reset: bool = False, max_episode_steps: int = 0,
                  env_offset: int = 0, want_raw_reward: bool = False, obs_rows: Optional[bool] = None,
-                 field_stride: Optional[int] = None, constants: Optional[QuadConstants] = None):
+                 field_stride: Optional[int] = None, goal_mode: Optional[int] = None,
+                 constants: Optional[QuadConstants] = None):
         if kind not in KINDS:
             raise ValueError(f"kind must be one of {KINDS}, got {kind!r}")
         if num_envs < 1:
@@ -127,6 +133,10 @@ class QuadVecEnv:
             self._params = self._soa(6, torch.float32)
             self._params.copy_(torch.tensor(c.nominal_params, dtype=torch.float32, device=dev)[:, None].expand(6, N))
         self._goal = None  # default hover goal until set_goal_state is called (quad.py:98-101)
+        if goal_mode not in (None, 0, 1):
+            raise ValueError("goal_mode must be None, 0 or 1 (TrajectoryGenerator modes fused into the step)")
+        self.goal_mode = goal_mode
+        self._traj = None if goal_mode is None else self._soa(8, torch.float32)
         self._episode = torch.zeros(N, dtype=torch.int32, device=dev)
         self._steps = torch.zeros(N, dtype=torch.int32, device=dev) if self.max_episode_steps > 0 else None
         # caller-facing rows
@@ -164,6 +174,8 @@ class QuadVecEnv:
         e.env_offset, e.seed = self.env_offset, self.seed & (2 ** 64 - 1)
         e.pos_vel, e.att_rate = _ptr(self._pos_vel), _ptr(self._att_rate)
         e.integ, e.params, e.goal = _ptr(self._integ), _ptr(self._params), _ptr(self._goal)
+        e.traj = _ptr(self._traj)
+        e.goal_mode = _lib.GOAL_EXTERNAL if self.goal_mode is None else self.goal_mode + 1
         e.episode, e.steps = _ptr(self._episode), _ptr(self._steps)
         e.max_episode_steps = self.max_episode_steps
         e.flags = (_lib.FLAG_AUTO_RESET if self.auto_reset else 0) | (0 if self.use_UDM else _lib.FLAG_NO_UDM)
@@ -247,6 +259,8 @@ class QuadVecEnv:
         finally:
             self._cenv.flags = flags
         _lib.check(rc, "qr_reset")
+        if self.goal_mode is not None:  # main.py:226-227: reset, then mark_traj_start(state)
+            _lib.check(self._lib.qr_traj_start(C.byref(self._cenv), _ptr(m), None, self._stream()), "qr_traj_start")
         return self.get_current_state().to(torch.float32)
 
     def get_norm_error_state(self, framework: Optional[str] = None):
@@ -278,6 +292,38 @@ class QuadVecEnv:
         self._goal[6:9] = self._rows3(b1d, "b1d")
         self._goal[9:12] = self._rows3(np.zeros(3) if Wd is None else Wd, "Wd")
 
+    # ---- goal generation (utils/trajectory_generator.py modes 0 / 1) ----------------
+    def mark_traj_start(self, mask: Optional[torch.Tensor] = None, theta_b1d=None, t_traj=None, w_b1d=None):
+        """TrajectoryGenerator.mark_traj_start(state) + the episode-start draws of mode 0
+        (theta_b1d ~ U(+-25 deg)) / mode 1 (t_traj ~ U(2,5) s, w_b1d ~ U(+-0.15 pi) rad/s), from the
+        current state.  Pass the draws ([N] tensors) to inject them; default: the env's RNG."""
+        if self.goal_mode is None:
+            raise RuntimeError("mark_traj_start needs goal_mode 0 or 1")
+        m = None if mask is None else torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        draws = None
+        if theta_b1d is not None or t_traj is not None or w_b1d is not None:
+            z = torch.zeros(self.num_envs, dtype=torch.float32, device=self.device)
+            one = torch.ones(self.num_envs, dtype=torch.float32, device=self.device)
+            cols = [z if theta_b1d is None else torch.as_tensor(theta_b1d, dtype=torch.float32, device=self.device).expand(self.num_envs),
+                    3.0 * one if t_traj is None else torch.as_tensor(t_traj, dtype=torch.float32, device=self.device).expand(self.num_envs),
+                    z if w_b1d is None else torch.as_tensor(w_b1d, dtype=torch.float32, device=self.device).expand(self.num_envs)]
+            draws = torch.stack(cols).contiguous()
+        _lib.check(self._lib.qr_traj_start(C.byref(self._cenv), _ptr(m), _ptr(draws), self._stream()), "qr_traj_start")
+
+    def get_desired(self, store_goal: bool = False, mask: Optional[torch.Tensor] = None):
+        """TrajectoryGenerator.get_desired(state, mode): (xd, vd, b1d, b1d_dot, Wd) as [N,3] views
+        for the current state (rows of envs outside `mask` are left zero); advances the generator's
+        clock by dt like every reference call.  store_goal=True also does set_goal_state()."""
+        if self.goal_mode is None:
+            raise RuntimeError("get_desired needs goal_mode 0 or 1")
+        rows = torch.zeros(self.num_envs, 15, dtype=torch.float32, device=self.device)
+        m = None if mask is None else torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        if store_goal and self._goal is None:
+            self._goal = self._soa(12, torch.float32)
+            self._cenv.goal = self._goal.data_ptr()
+        _lib.check(self._lib.qr_get_desired(C.byref(self._cenv), _ptr(m), rows.data_ptr(), int(store_goal), self._stream()), "qr_get_desired")
+        return rows[:, 0:3], rows[:, 3:6], rows[:, 6:9], rows[:, 9:12], rows[:, 12:15]
+
     def get_current_state(self) -> torch.Tensor:
         """quad.py:409-410: float64 [N,18] = (x, v, vec_F(R), W), rebuilt from the 13-word
         internal state (R = R(q)) by a small kernel; a fresh tensor each call."""
@@ -303,7 +349,7 @@ class QuadVecEnv:
 
     def state_dict(self) -> dict:
         """Checkpoint of everything the env owns (18 + 8 words per env + params/goal/counters)."""
-        keys = ("_pos_vel", "_att_rate", "_integ", "_params", "_goal", "_episode", "_steps")
+        keys = ("_pos_vel", "_att_rate", "_integ", "_params", "_goal", "_traj", "_episode", "_steps")
         return {k[1:]: (None if getattr(self, k) is None else getattr(self, k).clone()) for k in keys}
 
     def load_state_dict(self, sd: dict):

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define QR_ABI_VERSION 3
+#define QR_ABI_VERSION 4
 
 /* env kinds */
 #define QR_KIND_QUAD      0 /* QuadEnv            gym_rotor/envs/quad.py:19            */
@@ -58,6 +58,11 @@ extern "C" {
 #define QR_E_KIND   (-2) /* kind / layout out of range             */
 #define QR_E_SIZE   (-3) /* num_envs < 0, substeps < 1, n_steps < 1 */
 #define QR_E_ALIGN  (-4) /* a buffer is not 16-byte aligned        */
+
+/* goal sources */
+#define QR_GOAL_EXTERNAL 0 /* goal buffer set by the caller (set_goal_state), or the hover default    */
+#define QR_GOAL_MODE0    1 /* TrajectoryGenerator mode 0: xd = vd = 0, b1d drawn at episode start     */
+#define QR_GOAL_MODE1    2 /* TrajectoryGenerator mode 1: exponential approach of the origin + yaw rate */
 
 /* flags */
 #define QR_FLAG_AUTO_RESET   1u /* re-sample a done env inside the same launch (train distribution) */
@@ -92,6 +97,12 @@ typedef struct QrEnv {
   float*   integ;      /* [8][N]  eIx(3), g_x prev(3), eIb1, g_b prev (quad_utils.py:38-63); NULL for QUAD */
   float*   params;     /* [6][N]  m,d,J1(=J2),J3,c_tf,c_tw (quad.py:359-387); NULL = nominal */
   float*   goal;       /* [12][N] xd,vd,b1d,Wd (quad.py:413-418); NULL = hover default     */
+  float*   traj;       /* [8][N]  goal-generator state, required when goal_mode != QR_GOAL_EXTERNAL:
+                          0 #get_desired calls since mark_traj_start (t = calls*dt), 1 theta_init,
+                          2,3 b1d x,y (mode 0) | w_b1d, smooth_term (mode 1), 4..6 x_init, 7 unused */
+  int32_t  goal_mode;  /* QR_GOAL_EXTERNAL (0), or a utils/trajectory_generator.py mode fused into
+                          the step: QR_GOAL_MODE0 idle/warm-up (:141-148), QR_GOAL_MODE1 hovering (:252-277) */
+  int32_t  reserved0;
   int32_t* episode;    /* [N]     episode counter (RNG stream id); required for resets     */
   int32_t* steps;      /* [N]     steps since reset; NULL = no time-limit bookkeeping      */
   int32_t  max_episode_steps; /* >0: truncated[i]=1 when steps reaches it (gym_rotor/__init__.py:3-7) */
@@ -148,6 +159,22 @@ int qr_get_state(const QrEnv* env, double* rows, void* stream);
  * (quad_utils.py:123-142) — and, because the internal attitude is a unit quaternion, always
  * projected onto SO(3) (nearest rotation, the same U V^T the reference's SVD yields). */
 int qr_set_state(const QrEnv* env, const double* rows, const uint8_t* mask, void* stream);
+
+/* Replaces TrajectoryGenerator.mark_traj_start(state) (utils/trajectory_generator.py:176-204)
+ * plus the episode-start branch of calculate_desired (mode 0 :141-148: b1d = Rz(theta) b1_proj,
+ * theta ~ U(+-25 deg); mode 1 :253-266: x_init, t_traj ~ U(2,5) s, w_b1d ~ U(+-0.15 pi) rad/s)
+ * for envs with mask[i] != 0 (NULL = all), from the CURRENT state.  `draws` (optional, device,
+ * [3][N] = theta_b1d [rad], t_traj [s], w_b1d [rad/s]) injects the random draws; NULL draws them
+ * from the env's Philox stream.  Requires env->traj and goal_mode != QR_GOAL_EXTERNAL. */
+int qr_traj_start(const QrEnv* env, const uint8_t* mask, const float* draws, void* stream);
+
+/* Replaces TrajectoryGenerator.get_desired(state, mode) (trajectory_generator.py:113-173) for
+ * the CURRENT state of envs with mask[i] != 0 (NULL = all): advances the per-env call counter
+ * (t += dt) and writes rows [N][15] = (xd, vd, b1d, b1d_dot, Wd), Wd = (0, 0, b3 . (b1c x b1c_dot)) (:165-172).  With
+ * store_goal != 0 the result also becomes the env's goal buffer (set_goal_state).  The fused
+ * path (goal_mode != QR_GOAL_EXTERNAL in qr_step / qr_rollout) does the same at the start of every env-step
+ * and after an in-launch reset, exactly as main.py:145-147,226-229 call it. */
+int qr_get_desired(const QrEnv* env, const uint8_t* mask, float* rows, int32_t store_goal, void* stream);
 
 /* Host-side helpers (no device work). */
 void qr_default_coeffs(QrCoeffs* c);

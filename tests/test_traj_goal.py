@@ -1,0 +1,167 @@
+"""Goal generation: TrajectoryGenerator modes 0/1 — oracle pinned on the
+reference (CPU), then the HIP path (standalone qr_get_desired and fused into qr_step) against
+the same closed-loop golden runs (GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import grouped_rel_err
+from oracle import quad_oracle as orc
+from oracle import traj_oracle as trj
+
+CASES = [(k, m) for k in ("coupled", "decoupled") for m in (0, 1)]
+
+
+def _draws(d, e, ep):
+    return d["draws"][e, ep]
+
+
+@pytest.mark.parametrize("kind,mode", CASES)
+def test_traj_oracle_matches_reference(kind, mode, golden):
+    d = golden(f"trajgoal_m{mode}_{kind}")
+    T, n = d["actions"].shape[:2]
+    for e in range(n):
+        tr = None
+        for t in range(T):
+            if d["reset_at"][t, e]:
+                ep = d["episode_of"][t, e]
+                th, tt, w = _draws(d, e, ep)
+                tr = trj.traj_start_batch(d["states"][t, e], mode, theta_b1d=th, t_traj=tt, w_b1d=w)
+                g = np.concatenate(trj.get_desired_batch(tr, d["states"][t, e]), 1)[0]
+                assert np.abs(g - d["first_goal"][t, e]).max() <= 1e-13
+            g = np.concatenate(trj.get_desired_batch(tr, d["states"][t, e]), 1)[0]
+            assert np.abs(g - d["goals"][t, e]).max() <= 1e-12
+
+
+@pytest.mark.parametrize("kind,mode", CASES)
+def test_oracle_closed_loop_with_goals(kind, mode, golden):
+    """quad_oracle.step_batch fed with the golden goals reproduces the closed-loop run."""
+    d = golden(f"trajgoal_m{mode}_{kind}")
+    T, n = d["actions"].shape[:2]
+    state, integ = d["init_state"].copy(), np.zeros((n, 8))
+    for t in range(T):
+        ra = d["reset_at"][t]
+        if ra.any():
+            state[ra] = d["states"][t][ra]; integ[ra] = 0.0
+            g = d["first_goal"][t][ra]
+            goal12 = np.concatenate([g[:, 0:9], g[:, 12:15]], 1)
+            o = _first_obs(kind, state[ra], goal12, integ[ra])
+            integ[ra] = o
+        g = d["goals"][t]
+        goal12 = np.concatenate([g[:, 0:9], g[:, 12:15]], 1)
+        out = orc.step_batch(kind, state, d["actions"][t].astype(np.float64), d["params"], goal12, integ)
+        state, integ = out["state"], out["integ"]
+        for k, ob in enumerate(out["obs"]):
+            assert np.abs(ob.astype(np.float64) - d[f"obs{k}"][t]).max() <= 2e-7
+        assert np.array_equal(out["done"], d["dones"][t])
+        nxt = d["reset_at"][t + 1]
+        assert grouped_rel_err(state[~nxt], d["states"][t + 1][~nxt]) <= 1e-10 if (~nxt).any() else True
+
+
+def _first_obs(kind, state, goal12, integ):
+    from test_oracle_golden import _advance
+    return _advance(kind, state, goal12, integ)
+
+
+# ---------------------------------------------------------------- GPU ----------------
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _mk(kind, n, mode, **kw):
+    from gym_rotor_amd import QuadVecEnv
+    return QuadVecEnv(kind, n, device="cuda", goal_mode=mode, layout="f64", **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,mode", CASES)
+def test_get_desired_standalone(kind, mode, golden):
+    """qr_traj_start + qr_get_desired on the golden states: (xd, vd, b1d, b1d_dot, Wd) per call."""
+    d = golden(f"trajgoal_m{mode}_{kind}")
+    T, n = d["actions"].shape[:2]
+    env = _mk(kind, n, mode)
+    worst = 0.0
+    for t in range(T):
+        env.set_state(d["states"][t])
+        ra = d["reset_at"][t]
+        if ra.any():
+            ep = d["episode_of"][t]
+            dr = np.stack([d["draws"][e, ep[e]] for e in range(n)])
+            m = torch.from_numpy(ra).cuda()
+            env.mark_traj_start(mask=m, theta_b1d=dr[:, 0], t_traj=dr[:, 1], w_b1d=dr[:, 2])
+            g = torch.cat(env.get_desired(mask=m), 1)
+            assert np.abs(_np(g)[ra] - d["first_goal"][t][ra]).max() <= 3e-6
+        g = _np(torch.cat(env.get_desired(), 1))
+        err = np.abs(g - d["goals"][t]) / np.maximum(np.abs(d["goals"][t]), 1.0)
+        worst = max(worst, err.max())
+    print(f"get_desired {kind} mode {mode}: worst {worst:.2e}")
+    assert worst <= 3e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,mode", CASES)
+def test_fused_goal_closed_loop(kind, mode, golden):
+    """qr_step with the goal generator fused (goal_mode) against the reference closed loop:
+    obs / reward / done / state of every step, first observation of every episode."""
+    d = golden(f"trajgoal_m{mode}_{kind}")
+    T, n = d["actions"].shape[:2]
+    env = _mk(kind, n, mode)
+    env.set_state(d["init_state"], integ=np.zeros((n, 8)), params=d["params"])
+    acts = torch.from_numpy(d["actions"]).cuda()
+    worst = worst_obs = 0.0
+    ndiff = 0
+    for t in range(T):
+        ra = d["reset_at"][t]
+        if ra.any():
+            ep = d["episode_of"][t]
+            dr = np.stack([d["draws"][e, ep[e]] for e in range(n)])
+            m = torch.from_numpy(ra).cuda()
+            if t > 0:
+                env.set_state(d["states"][t], mask=m)
+                env._integ[:, m] = 0.0
+            env.mark_traj_start(mask=m, theta_b1d=dr[:, 0], t_traj=dr[:, 1], w_b1d=dr[:, 2])
+            env.get_desired(store_goal=True, mask=m)          # main.py:227-229
+            keep = env._integ.clone()
+            first = env.get_norm_error_state()
+            env._integ.copy_(torch.where(m[None, :], env._integ, keep))
+            for k, o in enumerate(first):
+                assert np.abs(_np(o)[ra] - d[f"first_obs{k}"][t][ra]).max() <= 3e-6
+        obs, rwd, done, _, _ = env.step(acts[t])
+        obs = [obs] if isinstance(obs, torch.Tensor) else list(obs)
+        for k, o in enumerate(obs):
+            worst_obs = max(worst_obs, float(np.abs(_np(o).astype(np.float64) - d[f"obs{k}"][t]).max()))
+        dd = _np(done) != d["dones"][t]
+        ndiff += int(dd.sum())
+        assert np.abs(_np(rwd).astype(np.float64) - d["rewards"][t])[~dd].max() <= 1e-5
+        got = _np(env.get_current_state())
+        nxt = d["reset_at"][t + 1]
+        if (~nxt).any():
+            worst = max(worst, grouped_rel_err(got[~nxt], d["states"][t + 1][~nxt]))
+    print(f"fused goal {kind} mode {mode}: state {worst:.2e} obs {worst_obs:.2e} done-diffs {ndiff}")
+    assert worst <= 1e-6 and worst_obs <= 5e-6 and ndiff == 0
+
+
+@pytest.mark.gpu
+def test_fused_goal_auto_reset_runs_and_matches_manual():
+    """auto_reset + goal_mode: the in-launch episode start (reset draw -> mark_traj_start ->
+    first get_desired -> first obs) equals doing the same by hand from the post-reset state."""
+    n = 2048
+    for mode in (0, 1):
+        env = _mk("coupled", n, mode, seed=4, auto_reset=True)
+        env.reset("train")
+        g = torch.Generator(device="cuda"); g.manual_seed(1)
+        hits = 0
+        for _ in range(80):
+            obs, rwd, done, _, _ = env.step(torch.rand(n, 4, device="cuda", generator=g) * 2 - 1)
+            hit = _np(done[:, 0])
+            if hit.any():
+                hits += hit.sum()
+                chk = _mk("coupled", n, mode, seed=0)
+                chk.load_state_dict(env.state_dict())         # state, params, traj state after the reset
+                chk._traj[0].fill_(0.0)                       # calls = 0: redo the episode's first call
+                chk._integ.zero_()
+                chk.get_desired(store_goal=True)
+                first = chk.get_norm_error_state()[0]
+                assert np.abs(_np(first)[hit] - _np(obs)[hit]).max() <= 1e-6
+                assert (_np(env._traj[0])[hit] == 1.0).all()
+        assert hits > 0 and torch.isfinite(env.get_current_state()).all()

@@ -17,6 +17,7 @@ Files written (see tests/golden/README.md for the field lists):
   traj_free_{kind}.npz     1000-step free-run (no reset) trajectories, 4 envs per kind
   traj_reset_{kind}.npz    1000-step trajectories with reset-on-done to injected states
   flightlog_modul.npz      first 1200 rows of results/MODUL_log_20250303_120200.dat
+  trajgoal_m{0,1}_{kind}.npz  closed loop env + TrajectoryGenerator (modes 0/1) as main.py drives them
 """
 import os
 import sys
@@ -326,6 +327,83 @@ def gen_kats():
     print("kat_units written")
 
 
+def gen_trajgoal(kind, mode, n_env=4, T=400, seed=0):
+    """Closed loop exactly as main.py drives it (eval loop :310-331, train loop :145-165,212-230):
+    reset -> mark_traj_start(state) -> get_desired -> set_goal_state -> first obs; then every step
+    get_desired(current state) -> set_goal_state -> step(action); reset-on-done to injected states.
+    The generator's np.random.uniform draws are injected and recorded."""
+    import utils.trajectory_generator as tg_mod
+    rng = np.random.default_rng(3000 + seed + 31 * orc.KINDS.index(kind) + 7 * mode)
+    A, nag = orc.ACTION_DIM[kind], orc.N_AGENTS[kind]
+    obs_dims = {"coupled": [23], "decoupled": [15, 3]}[kind]
+    params = np.tile(orc.NOMINAL_PARAMS, (n_env, 1)); params[n_env // 2:] = random_params(rng, n_env)[n_env // 2:]
+    params = f32r(params)
+    init = state_in(orc.sample_reset_state(rng, n_env, "train"))
+    pool = state_in(orc.sample_reset_state(rng, 32 * n_env, "train")).reshape(n_env, 32, 18)
+    actions = f32r(0.5 * rng.uniform(-1, 1, (T, n_env, A)))  # gentler actions: longer episodes
+    draws = np.zeros((n_env, 33, 3))  # per episode: theta_b1d, t_traj, w_b1d
+    draws[:, :, 0] = f32r(rng.uniform(-np.deg2rad(25), np.deg2rad(25), (n_env, 33)))
+    draws[:, :, 1] = f32r(rng.uniform(2.0, 5.0, (n_env, 33)))
+    draws[:, :, 2] = f32r(rng.uniform(-0.15 * np.pi, 0.15 * np.pi, (n_env, 33)))
+    states = np.zeros((T + 1, n_env, 18)); goals = np.zeros((T, n_env, 15)); first_goal = np.zeros((T + 1, n_env, 15))
+    rewards = np.zeros((T, n_env, nag)); dones = np.zeros((T, n_env, nag), bool)
+    obs_out = [np.zeros((T, n_env, d), np.float32) for d in obs_dims]
+    first_obs = [np.zeros((T + 1, n_env, d), np.float32) for d in obs_dims]
+    reset_at = np.zeros((T + 1, n_env), bool); episode_of = np.zeros((T + 1, n_env), int)
+    saved_uniform = np.random.uniform
+    for e in range(n_env):
+        env = make_env(kind)
+        sys.argv = ["x", "--framework", env.framework]
+        gen = tg_mod.TrajectoryGenerator(env)
+        queue = []
+
+        def fake_uniform(size=None, low=0.0, high=1.0):
+            v = queue.pop(0)
+            assert low - 1e-9 <= v <= high + 1e-9, (low, v, high)
+            return np.array([v])
+
+        def start_episode(state, ep, t):
+            inject(env, state, orc.DEFAULT_GOAL, np.zeros(8))
+            gen.mark_traj_start(env.state)
+            queue[:] = [draws[e, ep, 0]] if mode == 0 else [draws[e, ep, 1], draws[e, ep, 2]]
+            xd, vd, b1d, b1d_dot, Wd = gen.get_desired(env.state, mode)
+            assert not queue
+            env.set_goal_state(xd, vd, b1d, b1d_dot, Wd)
+            first_goal[t, e] = np.concatenate([xd, vd, b1d, b1d_dot, Wd])
+            ob = env.get_norm_error_state(env.framework)
+            for k, o in enumerate(ob):
+                first_obs[k][t, e] = o
+            reset_at[t, e] = True
+
+        np.random.uniform = fake_uniform
+        try:
+            inject_params(env, params[e])
+            ep = 0
+            start_episode(init[e], ep, 0)
+            for t in range(T):
+                states[t, e], episode_of[t, e] = env.state, ep
+                xd, vd, b1d, b1d_dot, Wd = gen.get_desired(env.state, mode)
+                env.set_goal_state(np.copy(xd), np.copy(vd), np.copy(b1d), np.copy(b1d_dot), np.copy(Wd))
+                goals[t, e] = np.concatenate([xd, vd, b1d, b1d_dot, Wd])
+                ns, f, M, obs, raw, rwd, done = ref_step(env, kind, actions[t, e])
+                rewards[t, e], dones[t, e] = rwd, done
+                for k, o in enumerate(obs):
+                    obs_out[k][t, e] = o
+                if any(done):
+                    ep += 1
+                    start_episode(pool[e, (ep - 1) % 32], ep, t + 1)
+            states[T, e] = env.state
+        finally:
+            np.random.uniform = saved_uniform
+    out = dict(params=params, init_state=init, reset_pool=pool, actions=actions.astype(np.float32), draws=draws,
+               states=states, goals=goals, first_goal=first_goal, rewards=rewards, dones=dones, reset_at=reset_at,
+               episode_of=episode_of)
+    for k in range(len(obs_dims)):
+        out[f"obs{k}"] = obs_out[k]; out[f"first_obs{k}"] = first_obs[k]
+    np.savez_compressed(os.path.join(OUT, f"trajgoal_m{mode}_{kind}.npz"), **out)
+    print(f"trajgoal_m{mode}_{kind}: resets/env={reset_at.sum(0).tolist()} max|Wd3|={np.abs(goals[..., 14]).max():.3f}")
+
+
 def gen_flightlog(rows=1200):
     log = np.loadtxt(os.path.join(REF, "results", "MODUL_log_20250303_120200.dat"))
     np.savez_compressed(os.path.join(OUT, "flightlog_modul.npz"), log=log[:rows])
@@ -343,3 +421,6 @@ if __name__ == "__main__":
     for kind in orc.KINDS:
         gen_traj(kind, "free")
         gen_traj(kind, "reset")
+    for kind in ("coupled", "decoupled"):
+        for mode in (0, 1):
+            gen_trajgoal(kind, mode)
