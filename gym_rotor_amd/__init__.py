@@ -9,6 +9,7 @@ from .spaces import Box  # noqa: F401
 from .sharding import shard_range, make_sharded_env, all_gather_rows  # noqa: F401
 from .vec_env import QuadVecEnv  # noqa: F401
 from .compat import QuadEnv, CoupledWrapper, DecoupledWrapper  # noqa: F401
+from .rollout import RolloutStorage  # noqa: F401
 
 __all__ = ["QuadVecEnv", "QuadEnv", "CoupledWrapper", "DecoupledWrapper", "QuadConstants", "Box",
-           "shard_range", "make_sharded_env", "all_gather_rows"]
+           "shard_range", "make_sharded_env", "all_gather_rows", "RolloutStorage"]

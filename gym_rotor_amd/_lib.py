@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("QR_LIB", os.path.join(_HERE, "libquadrotor_hip.so"))
 KIND_QUAD, KIND_COUPLED, KIND_DECOUPLED = 0, 1, 2
 KIND_ID = {"quad": KIND_QUAD, "coupled": KIND_COUPLED, "decoupled": KIND_DECOUPLED}
 FLAG_AUTO_RESET, FLAG_EVAL_RESET, FLAG_NO_UDM = 1, 2, 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 GOAL_EXTERNAL, GOAL_MODE0, GOAL_MODE1 = 0, 1, 2
 LAYOUT_ID = {"mixed": 0, "f64": 1, "f32": 2}
 
@@ -25,7 +25,7 @@ ERRORS = {-1: "QR_E_NULL: a required pointer is NULL", -2: "QR_E_KIND: bad env k
 
 # every symbol include/quadrotor_hip.h declares
 SYMBOLS = ("qr_step", "qr_rollout", "qr_error_obs", "qr_reset", "qr_get_state", "qr_set_state",
-           "qr_traj_start", "qr_get_desired",
+           "qr_traj_start", "qr_get_desired", "qr_gae",
            "qr_default_coeffs", "qr_abi_version", "qr_step_kernel_info")
 
 
@@ -91,6 +91,9 @@ def load():
     lib.qr_traj_start.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p, C.c_void_p]
     lib.qr_get_desired.restype = C.c_int
     lib.qr_get_desired.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.qr_gae.restype = C.c_int
+    lib.qr_gae.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_float,
+                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.qr_step_kernel_info.restype = C.c_char_p
     lib.qr_step_kernel_info.argtypes = [C.c_int32, C.c_int32, C.c_int64, P(C.c_int32), P(C.c_int32)]
     if lib.qr_abi_version() != ABI_VERSION:

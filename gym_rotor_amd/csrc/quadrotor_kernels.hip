@@ -1123,6 +1123,61 @@ __global__ __launch_bounds__(64) void get_desired_kernel(const Args a) {
 }
 
 // ------------------------------------------------------------------------------------
+// GAE reverse scan (algos/ppo/ppo.py:134-146): one lane per (env, agent) column, T steps.
+// The recurrence is serial in t but the loads are not: they are issued kU steps ahead so that
+// a wave keeps kU rows in flight instead of paying one memory round-trip per step.
+// ------------------------------------------------------------------------------------
+struct GaeArgs {
+  const float* reward; const uint8_t* done; const float* value; const float* next_value;
+  float* advantage; float* td_target; double* partials;
+  int64_t m; int32_t T; float gamma; float lam;
+};
+
+__global__ __launch_bounds__(64) void gae_kernel(const GaeArgs g) {
+  constexpr int kU = 8;
+  const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const bool active = j < g.m;
+  const int64_t M = g.m;
+  float adv = 0.0f;
+  double s1 = 0.0, s2 = 0.0;
+  if (active) {
+    float vnext = g.next_value ? 0.0f : g.value[(int64_t)g.T * M + j];  // bootstrap row
+    for (int t0 = g.T; t0 > 0; t0 -= kU) {
+      const int nb = t0 < kU ? t0 : kU;
+      float r[kU], v[kU], vn[kU];
+      uint8_t d[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if (u < nb) {
+          const int64_t idx = (int64_t)(t0 - 1 - u) * M + j;
+          r[u] = g.reward[idx]; d[u] = g.done[idx]; v[u] = g.value[idx];
+          vn[u] = g.next_value ? g.next_value[idx] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if (u < nb) {
+          const int64_t idx = (int64_t)(t0 - 1 - u) * M + j;
+          const float nd = d[u] ? 0.0f : 1.0f;
+          const float vnx = g.next_value ? vn[u] : vnext;
+          const float delta = r[u] + g.gamma * vnx * nd - v[u];
+          adv = delta + g.gamma * nd * g.lam * adv;
+          g.advantage[idx] = adv;
+          g.td_target[idx] = adv + v[u];
+          s1 += (double)adv; s2 += (double)adv * (double)adv;
+          vnext = v[u];
+        }
+      }
+    }
+  }
+  if (g.partials) {  // wave reduction (DPP/bpermute shuffles), one pair of doubles per workgroup
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
+    if (threadIdx.x == 0) { g.partials[2 * (int64_t)blockIdx.x] = s1; g.partials[2 * (int64_t)blockIdx.x + 1] = s2; }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------
 static void fill_coeffs(Coeffs& o, const QrCoeffs& q) {
@@ -1330,6 +1385,16 @@ int qr_get_desired(const QrEnv* env, const uint8_t* mask, float* rows, int32_t s
   if (grid == 0) return 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   QR_DISPATCH_LAYOUT(env->layout, (qr::launch_get_desired<XV, QW>(a, grid, s)));
+  return (int)hipGetLastError();
+}
+
+int qr_gae(const float* reward, const uint8_t* done, const float* value, const float* next_value, int32_t n_steps,
+           int64_t n_cols, float gamma, float lam, float* advantage, float* td_target, double* partials, void* stream) {
+  if (!reward || !done || !value || !advantage || !td_target) return QR_E_NULL;
+  if (n_steps < 1 || n_cols < 0) return QR_E_SIZE;
+  if (n_cols == 0) return 0;
+  qr::GaeArgs g{reward, done, value, next_value, advantage, td_target, partials, n_cols, n_steps, gamma, lam};
+  hipLaunchKernelGGL(qr::gae_kernel, dim3((unsigned)((n_cols + 63) / 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), g);
   return (int)hipGetLastError();
 }
 

@@ -1,0 +1,130 @@
+"""On-device rollout storage + GAE.
+
+Batched replacement of the reference's PPO data path: `ReplayBuffer` (NumPy arrays of
+`T_horizon` rows per agent: obs, act, rwd, obs_next, done, logprob; algos/replay_buffer.py:15-39)
+and the Python GAE loop + advantage normalisation in `PPO.train` (algos/ppo/ppo.py:134-147).
+Transitions of N envs stay on the GPU as `[T, N, ...]` tensors; `QuadVecEnv.step(..., out=slot)`
+writes observation / reward / done rows straight into them; GAE is one HIP launch
+(`qr_gae`: reverse scan over T per (env, agent) column).  Normalisation statistics can be
+all-reduced over the env shards (RCCL when launched under torchrun; gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+
+
+class RolloutStorage:
+    """[T(+1), N, ...] buffers for one PPO horizon of a QuadVecEnv.
+
+    obs[k]      [T+1, N, D_k]   observation of agent k BEFORE step t; row T = after the last step
+                               (obs_next[t] is obs[t+1]: with same-step auto-reset the row after a
+                               terminal step holds the new episode's first observation, and the
+                               GAE masks the bootstrap with (1 - done) exactly like ppo.py:138)
+    act[k]      [T, N, A_k]     logprob[k] [T, N, A_k]  (per-dimension log-probs, ppo.py buffer)
+    reward      [T, N, n_agents]   done [T, N, n_agents] (bool)   truncated [T, N] (bool)
+    value       [T+1, N, n_agents] critic outputs, row T = bootstrap
+    """
+
+    def __init__(self, env, horizon: int, action_dims: Optional[List[int]] = None):
+        self.T, self.N, self.device = int(horizon), env.num_envs, env.device
+        self.n_agents = env.n_agents
+        f32 = dict(dtype=torch.float32, device=self.device)
+        if action_dims is None:
+            action_dims = [env.action_dim] if env.n_agents == 1 else [4, 1]  # main.py:161: agents' actions concatenated
+        if sum(action_dims) != env.action_dim:
+            raise ValueError("action_dims must sum to the env's action dimension")
+        self.action_dims = list(action_dims)
+        T, N = self.T, self.N
+        self.obs = [torch.zeros(T + 1, N, d, **f32) for d in env.obs_dims]
+        self.act = [torch.zeros(T, N, a, **f32) for a in self.action_dims]
+        self.logprob = [torch.zeros(T, N, a, **f32) for a in self.action_dims]
+        self.reward = torch.zeros(T, N, self.n_agents, **f32)
+        self.done = torch.zeros(T, N, self.n_agents, dtype=torch.bool, device=self.device)
+        self.truncated = torch.zeros(T, N, dtype=torch.bool, device=self.device)
+        self.value = torch.zeros(T + 1, N, self.n_agents, **f32)
+        self.advantage = torch.zeros(T, N, self.n_agents, **f32)
+        self.td_target = torch.zeros(T, N, self.n_agents, **f32)
+        self._lib = _lib.load()
+
+    def set_initial_obs(self, obs):
+        obs = [obs] if isinstance(obs, torch.Tensor) else list(obs)
+        for k, o in enumerate(obs):
+            self.obs[k][0].copy_(o)
+
+    def slot(self, t: int) -> dict:
+        """Output slices for `env.step(actions, out=storage.slot(t))`: the step kernel writes the
+        next observation (row t+1), reward, done and truncated of step t directly into the storage."""
+        out = {"obs0": self.obs[0][t + 1], "reward": self.reward[t], "terminated": self.done[t], "truncated": self.truncated[t]}
+        if len(self.obs) > 1:
+            out["obs1"] = self.obs[1][t + 1]
+        return out
+
+    def insert(self, t: int, act=None, logprob=None, value=None):
+        """Learner-side quantities of step t (actions taken, their log-probs, V(obs[t]))."""
+        for dst, src in ((self.act, act), (self.logprob, logprob)):
+            if src is not None:
+                src = [src] if isinstance(src, torch.Tensor) else list(src)
+                for k, s in enumerate(src):
+                    dst[k][t].copy_(s)
+        if value is not None:
+            self.value[t].copy_(value.reshape(self.N, self.n_agents))
+
+    def compute_gae(self, gamma: float = 0.99, lam: float = 0.9, last_value: Optional[torch.Tensor] = None,
+                    next_value: Optional[torch.Tensor] = None, want_stats: bool = True):
+        """ppo.py:134-146 for every (env, agent) column in one launch.  `last_value` fills the
+        bootstrap row value[T]; `next_value` ([T,N,n_agents]) overrides Vnext_t = value[t+1]
+        (e.g. critic(obs_next) evaluated separately, as the reference does).
+        Returns (advantage, td_target[, (sum, sumsq, count) per agent as float64 [n_agents, 3]])."""
+        if last_value is not None:
+            self.value[self.T].copy_(last_value.reshape(self.N, self.n_agents))
+        M = self.N * self.n_agents
+        grid = (M + 63) // 64
+        partials = torch.zeros(grid, 2, dtype=torch.float64, device=self.device) if want_stats else None
+        nv = None if next_value is None else next_value.contiguous()
+        rc = self._lib.qr_gae(self.reward.data_ptr(), self.done.data_ptr(), self.value.data_ptr(),
+                              None if nv is None else nv.data_ptr(), self.T, M, float(gamma), float(lam),
+                              self.advantage.data_ptr(), self.td_target.data_ptr(),
+                              None if partials is None else partials.data_ptr(),
+                              torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(rc, "qr_gae")
+        if not want_stats:
+            return self.advantage, self.td_target
+        if self.n_agents == 1:
+            tot = partials.sum(0, keepdim=True)
+        else:  # columns interleave agents: recompute per-agent sums from the advantages (small)
+            a64 = self.advantage.double()
+            tot = torch.stack([a64.sum((0, 1)), (a64 * a64).sum((0, 1))], 1)
+        cnt = torch.full((self.n_agents, 1), float(self.T * self.N), dtype=torch.float64, device=self.device)
+        return self.advantage, self.td_target, torch.cat([tot, cnt], 1)
+
+    @staticmethod
+    def normalize(advantage: torch.Tensor, stats: torch.Tensor, group=None) -> torch.Tensor:
+        """(adv - mean) / (std + 1e-4) with torch's unbiased std (ppo.py:147), per agent, over ALL
+        envs of all ranks when torch.distributed is initialised (stats are all-reduced: 3 doubles
+        per agent over RCCL/gloo — the only collective of the data path, and optional)."""
+        import torch.distributed as dist
+        st = stats.clone()
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(st, group=group)
+        s1, s2, n = st[:, 0], st[:, 1], st[:, 2]
+        mean = s1 / n
+        var = (s2 - n * mean * mean) / (n - 1.0)
+        std = var.clamp_min(0).sqrt()
+        return ((advantage.double() - mean) / (std + 1e-4)).float()
+
+    def sample(self):
+        """The reference's `ReplayBuffer.sample()` for PPO (replay_buffer.py:41-57): per-agent
+        lists of [T*N, ...] float tensors (obs, act, rwd, obs_next, done, logprob), time-major."""
+        T, N = self.T, self.N
+        flat = lambda x: x.reshape(T * N, -1)
+        obs = [flat(o[:-1]) for o in self.obs]
+        obs_next = [flat(o[1:]) for o in self.obs]
+        act = [flat(a) for a in self.act]
+        logp = [flat(l) for l in self.logprob]
+        rwd = [flat(self.reward[..., k:k + 1]) for k in range(self.n_agents)]
+        done = [flat(self.done[..., k:k + 1].float()) for k in range(self.n_agents)]
+        return obs, act, rwd, obs_next, done, logp

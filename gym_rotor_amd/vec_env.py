@@ -203,13 +203,28 @@ class QuadVecEnv:
         return self._obs0 if self._obs1 is None else (self._obs0, self._obs1)
 
     # ------------------------------------------------------------------------------
-    def step(self, actions: torch.Tensor):
+    def step(self, actions: torch.Tensor, out: Optional[dict] = None):
         """QuadEnv.step (quad.py:142-168) for all envs.  Returned tensors are the env's
-        output buffers: valid until the next step()/rollout() call."""
+        output buffers: valid until the next step()/rollout() call.  `out` (see
+        RolloutStorage.slot) redirects the observation / reward / done rows of this step into
+        caller-owned contiguous tensors, e.g. slices of a [T, N, ...] rollout buffer."""
         a = self._check_actions(actions)
-        rc = self._lib.qr_step(C.byref(self._cenv), a.data_ptr(), self.substeps, C.byref(self._cout), self._stream())
+        if out is None:
+            rc = self._lib.qr_step(C.byref(self._cenv), a.data_ptr(), self.substeps, C.byref(self._cout), self._stream())
+            _lib.check(rc, "qr_step")
+            return self._obs(), self._reward, self._done, self._trunc, {}
+        o = _lib.QrStepOut()
+        for k in ("obs0", "obs1", "reward", "terminated", "truncated"):
+            t = out.get(k)
+            if t is not None and (not t.is_contiguous() or t.device != self.device):
+                raise ValueError(f"out[{k!r}] must be a contiguous tensor on {self.device}")
+        o.obs0, o.obs1, o.reward = _ptr(out.get("obs0")), _ptr(out.get("obs1")), _ptr(out["reward"])
+        o.reward_raw, o.done = _ptr(out.get("reward_raw")), _ptr(out["terminated"])
+        o.truncated = _ptr(out.get("truncated")) if self._steps is not None else None
+        rc = self._lib.qr_step(C.byref(self._cenv), a.data_ptr(), self.substeps, C.byref(o), self._stream())
         _lib.check(rc, "qr_step")
-        return self._obs(), self._reward, self._done, self._trunc, {}
+        obs = out.get("obs0") if "obs1" not in out else (out["obs0"], out["obs1"])
+        return obs, out["reward"], out["terminated"], out.get("truncated", self._trunc), {}
 
     def rollout(self, actions: torch.Tensor, out: Optional[dict] = None):
         """T env-steps in one launch (state stays in registers).  actions [T,N,A].

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define QR_ABI_VERSION 4
+#define QR_ABI_VERSION 5
 
 /* env kinds */
 #define QR_KIND_QUAD      0 /* QuadEnv            gym_rotor/envs/quad.py:19            */
@@ -175,6 +175,21 @@ int qr_traj_start(const QrEnv* env, const uint8_t* mask, const float* draws, voi
  * path (goal_mode != QR_GOAL_EXTERNAL in qr_step / qr_rollout) does the same at the start of every env-step
  * and after an in-launch reset, exactly as main.py:145-147,226-229 call it. */
 int qr_get_desired(const QrEnv* env, const uint8_t* mask, float* rows, int32_t store_goal, void* stream);
+
+/* Replaces the GAE loop of the reference's PPO (algos/ppo/ppo.py:134-146) for a [T][M] rollout
+ * (M = num_envs * n_agents columns, each an independent time series):
+ *     delta_t = r_t + gamma * Vnext_t * (1 - done_t) - V_t
+ *     A_t     = delta_t + gamma * lambda * (1 - done_t) * A_{t+1},   A_T = 0   (reverse scan)
+ *     target_t = A_t + V_t
+ *   reward [T][M] f32, done [T][M] u8, value [T][M] f32 (or [T+1][M] when next_value is NULL:
+ *   then Vnext_t = value[t+1], row T being the bootstrap value), next_value [T][M] f32 or NULL.
+ *   Outputs advantage, td_target [T][M] f32 and, if `partials` != NULL, per-workgroup
+ *   (sum, sum of squares) of the advantages as double [grid][2] (grid = ceil(M/64)) for the
+ *   normalisation (adv - mean)/(std + 1e-4) (ppo.py:147); summing them on the host side of the
+ *   launch is deterministic (no atomics). */
+int qr_gae(const float* reward, const uint8_t* done, const float* value, const float* next_value,
+           int32_t n_steps, int64_t n_cols, float gamma, float lam,
+           float* advantage, float* td_target, double* partials, void* stream);
 
 /* Host-side helpers (no device work). */
 void qr_default_coeffs(QrCoeffs* c);

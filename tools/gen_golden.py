@@ -17,6 +17,7 @@ Files written (see tests/golden/README.md for the field lists):
   traj_free_{kind}.npz     1000-step free-run (no reset) trajectories, 4 envs per kind
   traj_reset_{kind}.npz    1000-step trajectories with reset-on-done to injected states
   flightlog_modul.npz      first 1200 rows of results/MODUL_log_20250303_120200.dat
+  gae.npz                  the reference's own GAE + normalisation lines (ppo.py:134-147) on synthetic data
   trajgoal_m{0,1}_{kind}.npz  closed loop env + TrajectoryGenerator (modes 0/1) as main.py drives them
 """
 import os
@@ -404,6 +405,38 @@ def gen_trajgoal(kind, mode, n_env=4, T=400, seed=0):
     print(f"trajgoal_m{mode}_{kind}: resets/env={reset_at.sum(0).tolist()} max|Wd3|={np.abs(goals[..., 14]).max():.3f}")
 
 
+def gen_gae(T=64, M=48, seed=0):
+    """Run the reference's OWN GAE lines (algos/ppo/ppo.py: from `td_errors = ...` to the advantage
+    normalisation) on synthetic critic outputs: the source text is read from /root/reference at
+    generation time and executed here; only its inputs and outputs are stored."""
+    import copy, textwrap, types
+    import torch
+    src = open(os.path.join(REF, "algos", "ppo", "ppo.py")).read().split("\n")
+    i0 = next(i for i, l in enumerate(src) if "td_errors = batch_rwd" in l)
+    i1 = next(i for i, l in enumerate(src) if "advantages = (advantages - advantages.mean())" in l)
+    block = textwrap.dedent("\n".join(src[i0:i1 + 1]))
+    rng = np.random.default_rng(4000 + seed)
+    out = {}
+    for name, (gamma, lam) in {"a": (0.99, 0.9), "b": (0.95, 0.97)}.items():
+        rwd = rng.uniform(-1, 1, (T, M)).astype(np.float32)
+        rwd[rng.uniform(size=(T, M)) < 0.05] = -1.0
+        done = (rng.uniform(size=(T, M)) < 0.06)
+        val = rng.normal(0, 2, (T + 1, M)).astype(np.float32)
+        adv = np.zeros((T, M), np.float32); tgt = np.zeros((T, M), np.float32); nrm = np.zeros((T, M), np.float32)
+        for c in range(M):  # the reference processes ONE env's horizon per call
+            ns = {"torch": torch, "copy": copy, "self": types.SimpleNamespace(discount=gamma, GAE_lambda=lam, device="cpu"),
+                  "batch_rwd": torch.tensor(rwd[:, c:c + 1]), "next_V": torch.tensor(val[1:, c:c + 1]),
+                  "batch_done": torch.tensor(done[:, c:c + 1], dtype=torch.float), "current_V": torch.tensor(val[:-1, c:c + 1])}
+            exec(block, ns)
+            nrm[:, c] = ns["advantages"].numpy()[:, 0]
+            tgt[:, c] = ns["td_targets"].numpy()[:, 0]
+            adv[:, c] = tgt[:, c] - val[:-1, c]
+        out.update({f"{name}_reward": rwd, f"{name}_done": done, f"{name}_value": val, f"{name}_gamma_lam": np.array([gamma, lam]),
+                    f"{name}_td_target": tgt, f"{name}_advantage": adv, f"{name}_normalized_per_column": nrm})
+    np.savez_compressed(os.path.join(OUT, "gae.npz"), **out)
+    print("gae golden written")
+
+
 def gen_flightlog(rows=1200):
     log = np.loadtxt(os.path.join(REF, "results", "MODUL_log_20250303_120200.dat"))
     np.savez_compressed(os.path.join(OUT, "flightlog_modul.npz"), log=log[:rows])
@@ -416,6 +449,7 @@ if __name__ == "__main__":
         check_step_template(kind)
     gen_kats()
     gen_flightlog()
+    gen_gae()
     for kind in orc.KINDS:
         gen_onestep(kind)
     for kind in orc.KINDS:
