@@ -766,20 +766,29 @@ __global__ __launch_bounds__(B, (TRAJ ? 1 : QR_WAVES_PER_SIMD)) void step_kernel
   int32_t episode = ((a.flags & QR_FLAG_AUTO_RESET) && active) ? (a.episode + first)[lane] : 0;
   bool params_dirty = false;
 
-  for (int t = 0; t < a.n_steps; ++t) {
-    // ---- action rows [N][A] -> lane registers ----
-    float act[A];
+  // Action rows [N][A] -> lane registers.  A = 4: one 16-byte load per lane.  A = 5: five dword
+  // loads per lane (a wave covers 1280 contiguous bytes; L1 merges the sectors).  In a rollout
+  // the row of step t+1 is requested before the arithmetic of step t, so its latency is hidden.
+  float act_next[A];
+  auto load_action = [&](int t, float (&dst)[A]) {
     const float* abase = a.action + ((int64_t)t * N + first) * A;
     if constexpr (A == 4) {
-      if (active) {
-        const float4 v = reinterpret_cast<const float4*>(abase)[lane];
-        act[0] = v.x; act[1] = v.y; act[2] = v.z; act[3] = v.w;
-      } else {
-        act[0] = act[1] = act[2] = act[3] = 0.f;
-      }
+      const float4 v = reinterpret_cast<const float4*>(abase)[lane];
+      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
     } else {
-      load_rows<B, A>(abase, act, smem, tid, rows);
+#pragma unroll
+      for (int j = 0; j < A; ++j) dst[j] = abase[lane * A + j];
     }
+  };
+#pragma unroll
+  for (int j = 0; j < A; ++j) act_next[j] = 0.f;
+  if (active) load_action(0, act_next);
+
+  for (int t = 0; t < a.n_steps; ++t) {
+    float act[A];
+#pragma unroll
+    for (int j = 0; j < A; ++j) act[j] = act_next[j];
+    if (active && t + 1 < a.n_steps) load_action(t + 1, act_next);
 
 #if QR_ABLATE == 2  // measurement build: memory traffic only (no integration)
     w.x[0] += T(act[0]);
