@@ -630,7 +630,7 @@ __device__ __forceinline__ void traj_goal(Work<T>& w, float (&tr)[8], int goal_m
 }
 
 __device__ __forceinline__ float sq3(const float* v) { return v[0] * v[0] + v[1] * v[1] + v[2] * v[2]; }
-__device__ __forceinline__ bool out3(const float* v) { return !(fabsf(v[0]) < 1.0f) || !(fabsf(v[1]) < 1.0f) || !(fabsf(v[2]) < 1.0f); }
+__device__ __forceinline__ bool out3(const float* v) { return !(fabsf(v[0]) < 1.0f) | !(fabsf(v[1]) < 1.0f) | !(fabsf(v[2]) < 1.0f); }
 __device__ __forceinline__ float interp01(float r, float rmin, float inv_nrmin) { return clampT((r - rmin) * inv_nrmin, 0.0f, 1.0f); }
 
 // ---- SoA access through buffer resources ------------------------------------------------
@@ -843,12 +843,13 @@ __global__ __launch_bounds__(B, (TRAJ ? 1 : QR_WAVES_PER_SIMD)) void step_kernel
       rraw[0] = (float)r;
       rwd[0] = (float)clampT((r - T(c.rmin_mono)) * T(c.inv_nrmin_mono), T(0), T(1));
       // done_wrapper (quad.py:301-318): roll = atan2(R21,R22), pitch = -asin(R20)
+      // (bitwise | on purpose: straight-line compares, no short-circuit branches)
       bool d = false;
 #pragma unroll
       for (int j = 0; j < 3; ++j)
-        d = d || !(fabs(w.x[j]) < T(c.x_lim)) || !(fabs(w.y[j]) < T(c.v_lim)) || !(fabs(w.y[7 + j]) < T(c.W_lim));
-      d = d || !(fabs(R[2]) < T(c.sin_euler_lim));           // |pitch| >= lim
-      d = d || !(fabs(R[5]) < T(c.tan_euler_lim) * R[8]);    // |atan2(R21,R22)| >= lim
+        d = d | !(fabs(w.x[j]) < T(c.x_lim)) | !(fabs(w.y[j]) < T(c.v_lim)) | !(fabs(w.y[7 + j]) < T(c.W_lim));
+      d = d | !(fabs(R[2]) < T(c.sin_euler_lim));           // |pitch| >= lim
+      d = d | !(fabs(R[5]) < T(c.tan_euler_lim) * R[8]);    // |atan2(R21,R22)| >= lim
       dn[0] = d;
     } else {
       error_obs<KIND, T>(w, R, c, o0, o1);
@@ -857,14 +858,14 @@ __global__ __launch_bounds__(B, (TRAJ ? 1 : QR_WAVES_PER_SIMD)) void step_kernel
                         -(float)c.Cb1 * fabsf(o0[18]) + -(float)c.CIb1 * (o0[19] * o0[19]) + -(float)c.CW * sq3(&o0[20]);
         rraw[0] = r;
         rwd[0] = interp01(r, (float)c.rmin_mono, (float)c.inv_nrmin_mono);
-        dn[0] = out3(&o0[0]) || out3(&o0[6]) || out3(&o0[20]);
+        dn[0] = out3(&o0[0]) | out3(&o0[6]) | out3(&o0[20]);
       } else {  // decoupled:92-140
         const float r1 = -(float)c.Cx * sq3(&o0[0]) + -(float)c.CIx * sq3(&o0[3]) + -(float)c.Cv * sq3(&o0[6]) +
                          -(float)c.Cw12 * sq3(&o0[12]);
         const float r2 = -(float)c.Cb1 * fabsf(o1[0]) + -(float)c.CIb1 * (o1[1] * o1[1]) + -(float)c.CW3 * (o1[2] * o1[2]);
         rraw[0] = r1; rraw[NAG - 1] = r2;
         rwd[0] = interp01(r1, (float)c.rmin_1, (float)c.inv_nrmin_1); rwd[NAG - 1] = interp01(r2, (float)c.rmin_2, (float)c.inv_nrmin_2);
-        dn[0] = out3(&o0[0]) || out3(&o0[6]) || out3(&o0[12]);
+        dn[0] = out3(&o0[0]) | out3(&o0[6]) | out3(&o0[12]);
         dn[NAG - 1] = !(fabsf(o1[2]) < 1.0f);
       }
     }
@@ -878,7 +879,7 @@ __global__ __launch_bounds__(B, (TRAJ ? 1 : QR_WAVES_PER_SIMD)) void step_kernel
     const bool trunc = a.max_episode_steps > 0 && steps >= a.max_episode_steps;
     bool any_done = trunc;
 #pragma unroll
-    for (int g = 0; g < NAG; ++g) any_done = any_done || dn[g];
+    for (int g = 0; g < NAG; ++g) any_done = any_done | dn[g];
     const bool need_reset = (a.flags & QR_FLAG_AUTO_RESET) && any_done && active;
     if (__ballot(need_reset)) {  // wave-uniform: skip unless some lane of this wave resets
       if (need_reset) episode += 1;
