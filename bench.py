@@ -52,6 +52,7 @@ def parse():
     p.add_argument("--no-auto-reset", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     p.add_argument("--action-batches", type=int, default=16)
+    p.add_argument("--extras", type=int, default=1, help="0: only the headline measurement (used under rocprofv3)")
     return p.parse_args()
 
 
@@ -215,7 +216,7 @@ def main():
                                  "avg_launch_us = HIP-event time of the K back-to-back launches / K (includes the "
                                  "~1.7 us launch floor of an empty kernel of this grid)"},
         }
-        if n_gpus == 1:
+        if n_gpus == 1 and a.extras:
             # secondary figure: the other reset mode (no reset inside step = the reference's own semantics)
             w2, d2, _, _, _ = run(not auto_reset, False)
             out["config"]["other_reset_mode"] = {"auto_reset": not auto_reset, "env_steps_per_s": N * a.steps / w2,
@@ -232,8 +233,8 @@ def main():
             e0.record(); env.rollout(acts, out=ro); e1.record(); torch.cuda.synchronize(dev)
             out["config"]["rollout_T100"] = {"env_steps_per_s": N * 100 / (e0.elapsed_time(e1) * 1e-3),
                                              "us_per_env_step_batch": e0.elapsed_time(e1) * 10.0}
-            if a.cpu_seconds > 0:
-                out["cpu_baseline"] = cpu_baseline(a.kind, a.cpu_seconds)
+        if n_gpus == 1 and a.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(a.kind, a.cpu_seconds)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -8,10 +8,10 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # (1) per-kernel time: kernel trace + stats only
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --cpu-seconds 0 "$@" > "$OUT/stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --cpu-seconds 0 --extras 0 "$@" > "$OUT/stats.log" 2>&1
 # (2)/(3) HBM traffic counters, each in its own pass, no tracing (FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2)
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 "$ROOT/bench.py" --cpu-seconds 0 "$@" > "$OUT/fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 "$ROOT/bench.py" --cpu-seconds 0 "$@" > "$OUT/write.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 "$ROOT/bench.py" --cpu-seconds 0 --extras 0 "$@" > "$OUT/fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 "$ROOT/bench.py" --cpu-seconds 0 --extras 0 "$@" > "$OUT/write.log" 2>&1
 # calibration of the counters on a copy of known size in torch (16 B/lane vectorised): 256 MiB
 cat > /tmp/calib.py <<'PY'
 import torch
