@@ -193,3 +193,12 @@ def test_all_gather_rows_single_process_is_identity():
     from gym_rotor_amd import all_gather_rows
     x = torch.arange(12.).reshape(3, 4)
     assert all_gather_rows(x, 4) is x
+
+
+def test_torch_custom_ops_are_registered():
+    import gym_rotor_amd  # noqa: F401
+    for name in ("qr_step", "qr_reset", "qr_gae"):
+        assert hasattr(torch.ops.gym_rotor_amd, name)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        torch.ops.gym_rotor_amd.qr_gae(torch.zeros(2, 3), torch.zeros(2, 3, dtype=torch.bool), torch.zeros(3, 3), 0.9, 0.9,
+                                       torch.zeros(2, 3), torch.zeros(2, 3))
