@@ -402,3 +402,47 @@ class QuadVecEnv:
 
     def close(self):
         self._closed = True
+
+
+def as_gymnasium_vector_env(env: "QuadVecEnv"):
+    """Wrap `env` as a `gymnasium.vector.VectorEnv` (SURVEY §8b) when gymnasium is importable;
+    raises ImportError otherwise (the engine itself never needs gymnasium).  Observations,
+    rewards and flags stay torch tensors on the GPU; `reset` follows Gymnasium's signature and
+    returns the first observation (reset -> [goal] -> get_norm_error_state, main.py:126-129)."""
+    import gymnasium as gym
+
+    single_obs = gym.spaces.Box(-np.inf, np.inf, shape=(sum(env.obs_dims),), dtype=np.float32)
+    single_act = gym.spaces.Box(-1.0, 1.0, shape=(env.action_dim,), dtype=np.float32)
+
+    class GymnasiumQuadVecEnv(gym.vector.VectorEnv):
+        metadata = {"render_modes": [], "autoreset_mode": "same_step" if env.auto_reset else "disabled"}
+
+        def __init__(self):
+            self.env = env
+            self.num_envs = env.num_envs
+            self.single_observation_space, self.single_action_space = single_obs, single_act
+            batch = getattr(gym.vector.utils, "batch_space", None)
+            self.observation_space = batch(single_obs, env.num_envs) if batch else single_obs
+            self.action_space = batch(single_act, env.num_envs) if batch else single_act
+
+        def _cat(self, obs):
+            return obs if isinstance(obs, torch.Tensor) else torch.cat(list(obs), 1)
+
+        def reset(self, *, seed=None, options=None):
+            env.reset((options or {}).get("env_type", "train"), seed=seed)
+            if env.kind == "quad":
+                return env.get_current_state().to(torch.float32), {}
+            if env.goal_mode is not None:
+                env.get_desired(store_goal=True)
+            return self._cat(env.get_norm_error_state()), {}
+
+        def step(self, actions):
+            obs, rwd, term, trunc, info = env.step(torch.as_tensor(actions, dtype=torch.float32, device=env.device))
+            if obs is None:
+                obs = env.get_current_state().to(torch.float32)
+            return self._cat(obs), rwd, term, trunc, info
+
+        def close(self, **kwargs):
+            env.close()
+
+    return GymnasiumQuadVecEnv()

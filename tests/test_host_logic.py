@@ -202,3 +202,12 @@ def test_torch_custom_ops_are_registered():
     with pytest.raises(RuntimeError, match="GPU only"):
         torch.ops.gym_rotor_amd.qr_gae(torch.zeros(2, 3), torch.zeros(2, 3, dtype=torch.bool), torch.zeros(3, 3), 0.9, 0.9,
                                        torch.zeros(2, 3), torch.zeros(2, 3))
+
+
+def test_gymnasium_is_optional():
+    """The engine imports and works without gymnasium; the VectorEnv adapter asks for it explicitly."""
+    import importlib.util
+    import gym_rotor_amd
+    if importlib.util.find_spec("gymnasium") is None:
+        with pytest.raises(ImportError):
+            gym_rotor_amd.as_gymnasium_vector_env(None)
