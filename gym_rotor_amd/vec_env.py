@@ -299,6 +299,8 @@ class QuadVecEnv:
 
     def set_goal_state(self, xd, vd, b1d, b1d_dot=None, Wd=None):
         """quad.py:413-418.  b1d_dot is accepted and ignored (unused by the step path)."""
+        if self.goal_mode is not None:
+            raise RuntimeError("this env generates its goals on the device (goal_mode); set_goal_state() would be ignored by step()")
         if self._goal is None:
             self._goal = self._soa(12, torch.float32)
             self._cenv.goal = self._goal.data_ptr()

@@ -165,3 +165,28 @@ def test_fused_goal_auto_reset_runs_and_matches_manual():
                 assert np.abs(_np(first)[hit] - _np(obs)[hit]).max() <= 1e-6
                 assert (_np(env._traj[0])[hit] == 1.0).all()
         assert hits > 0 and torch.isfinite(env.get_current_state()).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])
+def test_rollout_equals_steps_with_fused_goal(mode):
+    """K-step rollout with the goal generator fused is bit-identical to K single steps."""
+    from gym_rotor_amd import QuadVecEnv
+    n, T = 900, 9
+    envs = [QuadVecEnv("decoupled", n, device="cuda", goal_mode=mode, seed=8, auto_reset=True) for _ in range(2)]
+    for e in envs:
+        e.reset("train")
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    acts = torch.rand(T, n, 5, device="cuda", generator=g) * 2 - 1
+    outs = []
+    for t in range(T):
+        (o1, o2), r, d, _, _ = envs[0].step(acts[t])
+        outs.append((o1.clone(), o2.clone(), r.clone(), d.clone()))
+    ro = envs[1].rollout(acts)
+    for t in range(T):
+        assert torch.equal(outs[t][0], ro["obs0"][t]) and torch.equal(outs[t][1], ro["obs1"][t])
+        assert torch.equal(outs[t][2], ro["reward"][t]) and torch.equal(outs[t][3], ro["terminated"][t])
+    assert torch.equal(envs[0].get_current_state(), envs[1].get_current_state())
+    assert torch.equal(envs[0]._traj, envs[1]._traj)
+    with pytest.raises(RuntimeError):
+        envs[0].set_goal_state(np.zeros(3), np.zeros(3), np.array([1.0, 0, 0]))
