@@ -148,12 +148,14 @@ struct Phys {  // what set_random_parameters derives (quad.py:389-404), formed w
 __device__ __forceinline__ void philox4x32_10(uint32_t (&ctr)[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * ctr[0];
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * ctr[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ ctr[1] ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ ctr[3] ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
+    // separate v_mul_hi_u32 / v_mul_lo_u32: the 64-bit product form compiles to v_mad_u64_u32,
+    // which measures ~2x slower than the pair on gfx950
+    const uint32_t hi0 = __umulhi(0xD2511F53u, ctr[0]), lo0 = 0xD2511F53u * ctr[0];
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, ctr[2]), lo1 = 0xCD9E8D57u * ctr[2];
+    const uint32_t n0 = hi1 ^ ctr[1] ^ k0;
+    const uint32_t n1 = lo1;
+    const uint32_t n2 = hi0 ^ ctr[3] ^ k1;
+    const uint32_t n3 = lo0;
     ctr[0] = n0; ctr[1] = n1; ctr[2] = n2; ctr[3] = n3;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
@@ -203,15 +205,19 @@ __device__ __forceinline__ void coop_draw20(Draws& d, bool need, uint64_t seed, 
     philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
     const int r = my_rank - base;
     const bool mine = need && r >= 0 && r < cnt;
-    const int from = mine ? 5 * r : 0;
+    const int from4 = (mine ? 5 * r : 0) << 2;  // ds_bpermute takes a byte address (lane * 4)
+    // All 20 cross-lane reads are issued back to back and waited for once: written as
+    // "read, select, read, select, ..." hipcc puts an s_waitcnt lgkmcnt(0) behind every
+    // ds_bpermute and the ~100-cycle LDS-crossbar latency is paid 20 times in series.
+    int got[20];
 #pragma unroll
     for (int bb = 0; bb < 5; ++bb) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t v = (uint32_t)__shfl((int)ctr[j], from + bb);
-        d.r[4 * bb + j] = mine ? v : d.r[4 * bb + j];
-      }
+      for (int j = 0; j < 4; ++j) got[4 * bb + j] = __builtin_amdgcn_ds_bpermute(from4 + 4 * bb, (int)ctr[j]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int w = 0; w < 20; ++w) d.r[w] = mine ? (uint32_t)got[w] : d.r[w];
     base += cnt;
   }
 }
