@@ -183,6 +183,9 @@ class QuadVecEnv:
         o.done, o.truncated = _ptr(self._done), (_ptr(self._trunc) if self._steps is not None else None)
 
     def _stream(self):
+        # kernels are launched on the env's device: make it current for the call if it is not
+        if torch.cuda.current_device() != self.device.index:
+            torch.cuda.set_device(self.device)
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def _check_actions(self, actions: torch.Tensor, lead=()):
