@@ -16,8 +16,9 @@ LIB_PATH = os.environ.get("QR_LIB", os.path.join(_HERE, "libquadrotor_hip.so"))
 KIND_QUAD, KIND_COUPLED, KIND_DECOUPLED = 0, 1, 2
 KIND_ID = {"quad": KIND_QUAD, "coupled": KIND_COUPLED, "decoupled": KIND_DECOUPLED}
 FLAG_AUTO_RESET, FLAG_EVAL_RESET, FLAG_NO_UDM = 1, 2, 4
-ABI_VERSION = 5
-GOAL_EXTERNAL, GOAL_MODE0, GOAL_MODE1 = 0, 1, 2
+ABI_VERSION = 6
+GOAL_EXTERNAL, GOAL_MODE0, GOAL_MODE1, GOAL_MODE6 = 0, 1, 2, 3
+GOAL_ID = {None: 0, 0: 1, 1: 2, 6: 3}  # TrajectoryGenerator mode -> QR_GOAL_*
 LAYOUT_ID = {"mixed": 0, "f64": 1, "f32": 2}
 
 ERRORS = {-1: "QR_E_NULL: a required pointer is NULL", -2: "QR_E_KIND: bad env kind",
@@ -32,7 +33,8 @@ SYMBOLS = ("qr_step", "qr_rollout", "qr_error_obs", "qr_reset", "qr_get_state", 
 class QrCoeffs(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "Cx", "CIx", "Cv", "Cb1", "CIb1", "CW", "Cw12", "CW3", "alpha", "beta", "dt",
-        "x_lim", "v_lim", "W_lim", "eIx_lim", "eIb1_lim", "euler_lim_deg", "udm_fraction")]
+        "x_lim", "v_lim", "W_lim", "eIx_lim", "eIb1_lim", "euler_lim_deg", "udm_fraction",
+        "eight_T", "eight_A1", "eight_A2", "eight_w_b1d", "eight_alt_d", "eight_eps", "eight_count")]
 
 
 class QrEnv(C.Structure):

@@ -48,6 +48,14 @@ class QuadConstants:
     reward_crash: float = -1.0
     # domain randomisation (args_parse.py:34-35)
     UDM_percentage: float = 10.0
+    # eight-shaped curve of the goal generator (utils/trajectory_generator.py:98-110)
+    eight_T: float = 9.0
+    eight_A1: float = 1.5
+    eight_A2: float = 1.0
+    eight_w_b1d: float = 0.349066
+    eight_alt_d: float = -0.6
+    eight_eps: float = 0.01
+    eight_count: float = 3.0
 
     @property
     def dt(self) -> float:

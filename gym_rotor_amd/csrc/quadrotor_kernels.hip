@@ -51,6 +51,8 @@ struct Coeffs {  // double-precision copy of QrCoeffs + derived reward floors
   double rmin_mono, rmin_1, rmin_2;
   // reciprocals formed once on the host (an f64 division costs ~35 VALU slots on the device)
   double inv_x_lim, inv_v_lim, inv_W_lim, inv_eIx_lim, inv_eIb1_lim, inv_nrmin_mono, inv_nrmin_1, inv_nrmin_2;
+  // eight-shaped curve (trajectory_generator.py:98-110, 418-505)
+  float e8_w1, e8_w2, e8_k, e8_A1, e8_A2, e8_wb, e8_alt, e8_tmax;
 };
 
 struct Args {
@@ -569,7 +571,7 @@ __device__ __forceinline__ void traj_start(const Work<T>& w, float (&tr)[8], int
     sincos_small(theta_init + theta_b1d, sn, cs);  // Rz(theta) (cos th_i, sin th_i, 0)
     tr[2] = cs; tr[3] = sn;
     tr[4] = tr[5] = tr[6] = 0.0f;
-  } else {
+  } else {  // mode 1: x_init + draws; mode 6: eight_shaped_center = x (:430), no draws
     tr[2] = w_b1d;
     tr[3] = 6.907755278982137f / t_traj;  // -ln(0.001) / t_traj
 #pragma unroll
@@ -597,6 +599,25 @@ __device__ __forceinline__ void traj_goal(Work<T>& w, float (&tr)[8], int goal_m
     for (int j = 0; j < 6; ++j) w.goal[j] = 0.0f;
     b1d[0] = tr[2]; b1d[1] = tr[3]; b1d[2] = 0.0f;
     b1d_dot[0] = b1d_dot[1] = b1d_dot[2] = 0.0f;
+  } else if (goal_mode == QR_GOAL_MODE6) {  // eight_shaped_curve (:418-505)
+    const float t = fminf(tr[0] * (float)c.dt, c.e8_tmax);
+    const float ek = expf(-c.e8_k * t);
+    const float e = 1.0f - ek, de = c.e8_k * ek;  // exp_term, d/dt exp_term
+    float s1, c1, s2, c2;
+    sincos_small(c.e8_w1 * t, s1, c1);
+    sincos_small(c.e8_w2 * t, s2, c2);
+    const float za = 0.5f * (tr[6] - c.e8_alt);  // synchronised altitude command (:487-492)
+    w.goal[0] = fmaf(c.e8_A2 * s2, e, tr[4]);
+    w.goal[1] = fmaf(c.e8_A1 * (c1 - 1.0f), e, tr[5]);
+    w.goal[2] = fmaf(za, 1.0f - c1, tr[6]);
+    w.goal[3] = c.e8_A2 * (c.e8_w2 * c2 * e + s2 * de);
+    w.goal[4] = c.e8_A1 * (-c.e8_w1 * s1 * e + (c1 - 1.0f) * de);
+    w.goal[5] = za * c.e8_w1 * s1;
+    const float term = fmaf(c.e8_wb * t, e, tr[1]), dterm = c.e8_wb * (e + t * de);  // yaw (:494-498)
+    float sn, cs;
+    sincos_small(term, sn, cs);
+    b1d[0] = cs; b1d[1] = sn; b1d[2] = 0.0f;
+    b1d_dot[0] = -sn * dterm; b1d_dot[1] = cs * dterm; b1d_dot[2] = 0.0f;
   } else {  // hovering (:268-277), x_goal = 0
     const float t = tr[0] * (float)c.dt;
     const float wb = tr[2], sm = tr[3];
@@ -1208,6 +1229,11 @@ static void fill_coeffs(Coeffs& o, const QrCoeffs& q) {
   o.inv_x_lim = 1.0 / q.x_lim; o.inv_v_lim = 1.0 / q.v_lim; o.inv_W_lim = 1.0 / q.W_lim;
   o.inv_eIx_lim = 1.0 / q.eIx_lim; o.inv_eIb1_lim = 1.0 / q.eIb1_lim;
   o.inv_nrmin_mono = -1.0 / o.rmin_mono; o.inv_nrmin_1 = -1.0 / o.rmin_1; o.inv_nrmin_2 = -1.0 / o.rmin_2;
+  const double T8 = q.eight_T > 0 ? q.eight_T : 9.0;
+  o.e8_w1 = (float)(2.0 * kPi / T8); o.e8_w2 = (float)(4.0 * kPi / T8);                // :102-103
+  o.e8_k = (float)(-log(q.eight_eps > 0 ? q.eight_eps : 0.01) / T8);                   // :107-108
+  o.e8_A1 = (float)q.eight_A1; o.e8_A2 = (float)q.eight_A2; o.e8_wb = (float)q.eight_w_b1d; o.e8_alt = (float)q.eight_alt_d;
+  o.e8_tmax = (float)(q.eight_count * T8);                                             // :436
 }
 
 static int fill_env(Args& a, const QrEnv* e) {
@@ -1215,7 +1241,7 @@ static int fill_env(Args& a, const QrEnv* e) {
   if (e->kind < 0 || e->kind > 2 || e->layout < 0 || e->layout > 2) return QR_E_KIND;
   if (e->num_envs < 0 || (e->field_stride != 0 && (e->field_stride < e->num_envs || (e->field_stride & 3)))) return QR_E_SIZE;
   if ((e->field_stride > 0 ? e->field_stride : e->num_envs) > (int64_t)0x7fffffff / (12 * 8)) return QR_E_SIZE;  // SoA buffers < 2 GiB (32-bit buffer offsets)
-  if (e->goal_mode < 0 || e->goal_mode > 2) return QR_E_KIND;
+  if (e->goal_mode < 0 || e->goal_mode > 3) return QR_E_KIND;
   if (e->goal_mode != QR_GOAL_EXTERNAL && !e->traj) return QR_E_NULL;
   if (!e->pos_vel || !e->att_rate) return QR_E_NULL;
   if ((reinterpret_cast<uintptr_t>(e->pos_vel) | reinterpret_cast<uintptr_t>(e->att_rate)) & 15u) return QR_E_ALIGN;
@@ -1295,7 +1321,8 @@ static int do_rollout(const QrEnv* env, const float* action, int32_t n_steps, in
   if (env->kind != QR_KIND_QUAD && (!env->integ || !out->obs0)) return QR_E_NULL;
   if (env->kind == QR_KIND_DECOUPLED && !out->obs1) return QR_E_NULL;
   if ((env->flags & QR_FLAG_AUTO_RESET) && !env->episode) return QR_E_NULL;
-  if (reinterpret_cast<uintptr_t>(action) & 15u) return QR_E_ALIGN;
+  // action rows: A = 4 is read with one 16-byte load per lane; A = 5 (DECOUPLED) with dword loads
+  if (reinterpret_cast<uintptr_t>(action) & (env->kind == QR_KIND_DECOUPLED ? 3u : 15u)) return QR_E_ALIGN;
   a.action = action; a.obs0 = out->obs0; a.obs1 = out->obs1;
   a.reward = out->reward; a.reward_raw = out->reward_raw; a.done = out->done; a.truncated = out->truncated;
   a.n_steps = n_steps; a.substeps = substeps;
@@ -1318,6 +1345,8 @@ void qr_default_coeffs(QrCoeffs* c) {
   c->dt = 1.0 / 200.0;
   c->x_lim = 1.0; c->v_lim = 4.0; c->W_lim = 2.0 * qr::kPi;
   c->eIx_lim = 3.0; c->eIb1_lim = 3.0; c->euler_lim_deg = 85.0; c->udm_fraction = 0.1;
+  c->eight_T = 9.0; c->eight_A1 = 1.5; c->eight_A2 = 1.0; c->eight_w_b1d = 0.349066; c->eight_alt_d = -0.6;  // trajectory_generator.py:98-110
+  c->eight_eps = 0.01; c->eight_count = 3.0;
 }
 
 int qr_step(const QrEnv* env, const float* action, int32_t substeps, const QrStepOut* out, void* stream) {

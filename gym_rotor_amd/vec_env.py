@@ -52,9 +52,10 @@ class QuadVecEnv:
                     observation is then the first observation of the new episode
     max_episode_steps  >0 sets truncated when an episode reaches that many steps
     env_offset      global index of local env 0 (multi-GPU sharding; part of the RNG key)
-    goal_mode       None: goals come from set_goal_state() (hover default).  0 / 1: the reference's
-                    TrajectoryGenerator mode 0 (idle/warm-up: xd = vd = 0, b1d drawn per episode)
-                    or 1 (hovering: exponential approach of the origin + yaw rate) is evaluated
+    goal_mode       None: goals come from set_goal_state() (hover default).  0 / 1 / 6: the reference's
+                    TrajectoryGenerator mode 0 (idle/warm-up: xd = vd = 0, b1d drawn per episode),
+                    1 (hovering: exponential approach of the origin + yaw rate) or 6 (eight-shaped
+                    curve; parameters eight_* of QuadConstants) is evaluated
                     INSIDE the step launch from the pre-step state, as main.py:145-147 does on the
                     host every step; see mark_traj_start() / get_desired()
     obs_rows        write float32 observation rows [N,D].  Always on for the wrappers.  For
@@ -133,8 +134,8 @@ class QuadVecEnv:
             self._params = self._soa(6, torch.float32)
             self._params.copy_(torch.tensor(c.nominal_params, dtype=torch.float32, device=dev)[:, None].expand(6, N))
         self._goal = None  # default hover goal until set_goal_state is called (quad.py:98-101)
-        if goal_mode not in (None, 0, 1):
-            raise ValueError("goal_mode must be None, 0 or 1 (TrajectoryGenerator modes fused into the step)")
+        if goal_mode not in _lib.GOAL_ID:
+            raise ValueError("goal_mode must be None, 0, 1 or 6 (TrajectoryGenerator modes fused into the step)")
         self.goal_mode = goal_mode
         self._traj = None if goal_mode is None else self._soa(8, torch.float32)
         self._episode = torch.zeros(N, dtype=torch.int32, device=dev)
@@ -158,6 +159,8 @@ class QuadVecEnv:
                      "eIx_lim", "eIb1_lim"):
             setattr(co, name, float(getattr(c, name)))
         co.CW, co.dt, co.euler_lim_deg, co.udm_fraction = c.CW, c.dt, c.euler_lim, self.UDM_percentage / 100.0
+        for name in ("eight_T", "eight_A1", "eight_A2", "eight_w_b1d", "eight_alt_d", "eight_eps", "eight_count"):
+            setattr(co, name, float(getattr(c, name)))
         self._cenv.coeffs = co
         self._sync_structs()
         self._closed = False
@@ -175,7 +178,7 @@ class QuadVecEnv:
         e.pos_vel, e.att_rate = _ptr(self._pos_vel), _ptr(self._att_rate)
         e.integ, e.params, e.goal = _ptr(self._integ), _ptr(self._params), _ptr(self._goal)
         e.traj = _ptr(self._traj)
-        e.goal_mode = _lib.GOAL_EXTERNAL if self.goal_mode is None else self.goal_mode + 1
+        e.goal_mode = _lib.GOAL_ID[self.goal_mode]
         e.episode, e.steps = _ptr(self._episode), _ptr(self._steps)
         e.max_episode_steps = self.max_episode_steps
         e.flags = (_lib.FLAG_AUTO_RESET if self.auto_reset else 0) | (0 if self.use_UDM else _lib.FLAG_NO_UDM)
@@ -198,7 +201,11 @@ class QuadVecEnv:
             raise TypeError(f"actions must be float32, got {actions.dtype}")
         if tuple(actions.shape) != want:
             raise ValueError(f"actions shape {tuple(actions.shape)} != {want}")
-        return actions if actions.is_contiguous() else actions.contiguous()
+        if not actions.is_contiguous():
+            actions = actions.contiguous()
+        if actions.data_ptr() % 16:  # e.g. a row slice of a bigger tensor: the kernel wants 16-byte aligned rows
+            actions = actions.clone()
+        return actions
 
     def _obs(self):
         if self._obs0 is None:  # kind='quad' without observation rows: fetch with get_current_state()

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define QR_ABI_VERSION 5
+#define QR_ABI_VERSION 6
 
 /* env kinds */
 #define QR_KIND_QUAD      0 /* QuadEnv            gym_rotor/envs/quad.py:19            */
@@ -63,6 +63,8 @@ extern "C" {
 #define QR_GOAL_EXTERNAL 0 /* goal buffer set by the caller (set_goal_state), or the hover default    */
 #define QR_GOAL_MODE0    1 /* TrajectoryGenerator mode 0: xd = vd = 0, b1d drawn at episode start     */
 #define QR_GOAL_MODE1    2 /* TrajectoryGenerator mode 1: exponential approach of the origin + yaw rate */
+#define QR_GOAL_MODE6    3 /* TrajectoryGenerator mode 6: eight-shaped (Lissajous) curve (:418-505); after
+                              eight_count periods the last goal is held (the reference switches to manual) */
 
 /* flags */
 #define QR_FLAG_AUTO_RESET   1u /* re-sample a done env inside the same launch (train distribution) */
@@ -80,6 +82,10 @@ typedef struct QrCoeffs {
   double eIx_lim, eIb1_lim;           /* 3.0, 3.0 (coupled_yaw_wrapper.py:23-24)       */
   double euler_lim_deg;               /* 85 (quad.py:107)                              */
   double udm_fraction;                /* UDM_percentage/100 = 0.1 (quad.py:370)        */
+  /* eight-shaped curve of the goal generator (utils/trajectory_generator.py:98-110) */
+  double eight_T, eight_A1, eight_A2; /* period 9 s, amplitudes 1.5 / 1.0                  */
+  double eight_w_b1d, eight_alt_d;    /* yaw rate 0.349066 rad/s, desired altitude -0.6 m  */
+  double eight_eps, eight_count;      /* smoothing epsilon 0.01, number of eights 3        */
 } QrCoeffs;
 
 /* Per-env device buffers owned by the caller (the Python env object). */
@@ -101,7 +107,8 @@ typedef struct QrEnv {
                           0 #get_desired calls since mark_traj_start (t = calls*dt), 1 theta_init,
                           2,3 b1d x,y (mode 0) | w_b1d, smooth_term (mode 1), 4..6 x_init, 7 unused */
   int32_t  goal_mode;  /* QR_GOAL_EXTERNAL (0), or a utils/trajectory_generator.py mode fused into
-                          the step: QR_GOAL_MODE0 idle/warm-up (:141-148), QR_GOAL_MODE1 hovering (:252-277) */
+                          the step: QR_GOAL_MODE0 idle/warm-up (:141-148), QR_GOAL_MODE1 hovering (:252-277),
+                          QR_GOAL_MODE6 eight-shaped curve (:418-505) */
   int32_t  reserved0;
   int32_t* episode;    /* [N]     episode counter (RNG stream id); required for resets     */
   int32_t* steps;      /* [N]     steps since reset; NULL = no time-limit bookkeeping      */
@@ -127,7 +134,7 @@ typedef struct QrStepOut {
  * (ODE solve over dt + get_norm_error_state) -> reward_wrapper -> interp -> done_wrapper ->
  * crash override, for all N envs in one fused launch.
  *   action   [N][A] float32, A = 4 (QUAD, COUPLED) or 5 (DECOUPLED: agents' actions
- *            concatenated, main.py:161).
+ *            concatenated, main.py:161).  16-byte aligned (A = 4) / 4-byte aligned (A = 5).
  *   substeps number of fixed RK4 substeps of h = dt/substeps replacing
  *            scipy.integrate.solve_ivp(DOP853) (quad.py:265); >= 1. */
 int qr_step(const QrEnv* env, const float* action, int32_t substeps, const QrStepOut* out, void* stream);

@@ -33,17 +33,38 @@ def traj_start_batch(state, mode, theta_b1d=None, t_traj=None, w_b1d=None):
         tr["x_init"] = state[:, 0:3].copy()
         tr["smooth"] = -np.log(0.001) / (np.asarray(t_traj, dtype=np.float64) * np.ones(n))
         tr["w_b1d"] = np.asarray(w_b1d, dtype=np.float64) * np.ones(n)
+    elif mode == 6:  # eight_shaped_curve (:427-449): centre = current position, no draws
+        tr["center"] = state[:, 0:3].copy()
     else:
-        raise ValueError("only TrajectoryGenerator modes 0 and 1 are in scope")
+        raise ValueError("only TrajectoryGenerator modes 0, 1 and 6 are in scope")
     return tr
 
 
-def get_desired_batch(tr, state, dt=DT):
+EIGHT = dict(T=9.0, A1=1.5, A2=1.0, w_b1d=0.349066, alt_d=-0.6, eps=0.01, count=3)  # :98-110
+
+
+def get_desired_batch(tr, state, dt=DT, eight=None):
     """get_desired(state, mode) (:113-173): advances t by dt, returns xd, vd, b1d, b1d_dot, Wd [N,3]."""
     state = np.atleast_2d(np.asarray(state, dtype=np.float64))
     n = state.shape[0]
     tr["calls"] = tr["calls"] + 1.0  # update_current_time (:224-229)
-    if tr["mode"] == 0:
+    if tr["mode"] == 6:  # eight_shaped_curve (:451-505)
+        p = dict(EIGHT, **(eight or {}))
+        t = np.minimum(tr["calls"] * dt, p["count"] * p["T"])[:, None]
+        w1, w2, k = 2 * np.pi / p["T"], 4 * np.pi / p["T"], -np.log(p["eps"]) / p["T"]
+        e, de = 1.0 - np.exp(-k * t), k * np.exp(-k * t)
+        c = tr["center"]
+        za = (c[:, 2:3] - p["alt_d"]) / 2
+        xd = np.concatenate([p["A2"] * np.sin(w2 * t) * e + c[:, 0:1], p["A1"] * (np.cos(w1 * t) - 1.0) * e + c[:, 1:2],
+                             za * (1 - np.cos(w1 * t)) + c[:, 2:3]], 1)
+        vd = np.concatenate([p["A2"] * (w2 * np.cos(w2 * t) * e + np.sin(w2 * t) * de),
+                             p["A1"] * (-w1 * np.sin(w1 * t) * e + (np.cos(w1 * t) - 1.0) * de), za * w1 * np.sin(w1 * t)], 1)
+        term = p["w_b1d"] * t * e + tr["theta_init"][:, None]
+        dterm = p["w_b1d"] * (e + t * de)
+        z = np.zeros_like(term)
+        b1d = np.concatenate([np.cos(term), np.sin(term), z], 1)
+        b1d_dot = np.concatenate([-np.sin(term) * dterm, np.cos(term) * dterm, z], 1)
+    elif tr["mode"] == 0:
         xd, vd = np.zeros((n, 3)), np.zeros((n, 3))
         b1d, b1d_dot = tr["b1d"], np.zeros((n, 3))
     else:  # hovering (:268-277), x_goal = 0

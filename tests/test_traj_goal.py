@@ -9,7 +9,11 @@ from conftest import grouped_rel_err
 from oracle import quad_oracle as orc
 from oracle import traj_oracle as trj
 
-CASES = [(k, m) for k in ("coupled", "decoupled") for m in (0, 1)]
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+CASES = [(k, m) for k in ("coupled", "decoupled") for m in (0, 1, 6)]
 
 
 def _draws(d, e, ep):
@@ -63,11 +67,87 @@ def _first_obs(kind, state, goal12, integ):
     return _advance(kind, state, goal12, integ)
 
 
+def _log_goal_inputs(golden):
+    """The reference-owned flight log is an eight-shaped-curve flight (mode 6) recorded with
+    eight_T = 18 s (HEAD has 9 s): its command columns (xd, vd, b1c, Wd) are a pure function of its
+    state columns.  Row i was produced by the (i+2)-th get_desired call (main.py:310-331)."""
+    log = golden("flightlog_modul")["log"]
+    state, cmd = log[:, 5:23], log[:, 28:40]
+    return state, cmd
+
+
+def test_flightlog_commands_oracle(golden):
+    state, cmd = _log_goal_inputs(golden)
+    tr = trj.traj_start_batch(state[0], 6)
+    trj.get_desired_batch(tr, state[0], eight={"T": 18.0})            # call 1: first obs after reset
+    for i in range(len(state)):
+        xd, vd, b1d, b1d_dot, Wd = trj.get_desired_batch(tr, state[i], eight={"T": 18.0})
+        b3 = state[i, 12:15]
+        b1c = b1d[0] - np.dot(b1d[0], b3) * b3                        # what main.py:349-351 logs
+        # the generator was started from the float32 state reset() returns: centre/theta_init ~1e-7 off
+        assert np.abs(xd[0] - cmd[i, 0:3]).max() <= 3e-7 and np.abs(vd[0] - cmd[i, 3:6]).max() <= 1e-7
+        assert np.abs(b1c - cmd[i, 6:9]).max() <= 2e-7 and np.abs(Wd[0] - cmd[i, 9:12]).max() <= 2e-8
+
+
+@pytest.mark.gpu
+def test_flightlog_commands_gpu(golden):
+    """Device goal generator (mode 6, eight_T = 18) on the logged states vs the logged commands."""
+    from gym_rotor_amd import QuadConstants, QuadVecEnv
+    state, cmd = _log_goal_inputs(golden)
+    n = 1
+    env = QuadVecEnv("decoupled", n, device="cuda", goal_mode=6, layout="f64", use_UDM=False,
+                     constants=QuadConstants(eight_T=18.0))
+    env.set_state(state[0:1])
+    env.mark_traj_start()
+    env.get_desired()
+    worst = np.zeros(4)
+    for i in range(400):
+        env.set_state(state[i:i + 1])
+        xd, vd, b1d, _, Wd = (_np(g)[0].astype(np.float64) for g in env.get_desired())
+        b3 = state[i, 12:15]
+        b1c = b1d - np.dot(b1d, b3) * b3
+        for k, (a, b) in enumerate(((xd, cmd[i, 0:3]), (vd, cmd[i, 3:6]), (b1c, cmd[i, 6:9]), (Wd, cmd[i, 9:12]))):
+            worst[k] = max(worst[k], np.abs(a - b).max())
+    print("flight-log commands (xd, vd, b1c, Wd):", worst)
+    assert (worst <= [1e-6, 1e-6, 1e-6, 1e-6]).all()
+
+
+@pytest.mark.gpu
+def test_flightlog_closed_loop_replay(golden):
+    """The whole reference-owned flight (3599 steps = 18 s) on the device: start from the first
+    logged state, feed the logged actions, let the fused goal generator (mode 6, eight_T = 18) and
+    the integrators run, and compare with the log all the way.
+    The state evolves open-loop in the actions, so the log's own print rounding (1e-10 per step) is
+    amplified by the unstable double integrator (~x4 per 600 steps): the float64 DOP853 oracle
+    replays the log with the same 2.7e-8 after 1200 steps and 7.5e-6 after 3599 — the bounds below."""
+    from gym_rotor_amd import QuadConstants, QuadVecEnv
+    log = golden("flightlog_modul")["log"]
+    act, state = log[:, 0:5], log[:, 5:23]
+    env = QuadVecEnv("decoupled", 1, device="cuda", goal_mode=6, layout="f64", use_UDM=False,
+                     constants=QuadConstants(eight_T=18.0))
+    env.set_state(state[0:1], integ=np.zeros((1, 8)))
+    env.mark_traj_start()
+    env.get_desired(store_goal=True)
+    env.get_norm_error_state()                     # first obs after reset (main.py:312-314)
+    a = torch.from_numpy(act.astype(np.float32)).cuda()
+    worst_s = worst_i = worst_b = 0.0
+    for t in range(len(log) - 1):
+        (o1, o2), _, done, _, _ = env.step(a[t:t + 1])
+        assert not bool(done.any())
+        got = _np(env.get_current_state())[0]
+        worst_s = max(worst_s, np.abs(got - state[t + 1]).max())
+        eIx = _np(o1)[0, 3:6].astype(np.float64) * 3.0
+        eb1, eIb1 = float(o2[0, 0]) * np.pi, float(o2[0, 1]) * 3.0
+        worst_i = max(worst_i, np.abs(eIx - log[t + 1, 23:26]).max(), abs(eIb1 - log[t + 1, 27]))
+        worst_b = max(worst_b, abs(eb1 - log[t + 1, 26]))
+        if t == 1198:
+            print(f"closed-loop flight replay, 1199 steps: state {worst_s:.2e} integral terms {worst_i:.2e} eb1 {worst_b:.2e}")
+            assert worst_s <= 1e-7 and worst_i <= 2e-6 and worst_b <= 2e-6
+    print(f"closed-loop flight replay, 3599 steps: state {worst_s:.2e} integral terms {worst_i:.2e} eb1 {worst_b:.2e}")
+    assert worst_s <= 2e-5 and worst_i <= 3e-5 and worst_b <= 1e-5
+
+
 # ---------------------------------------------------------------- GPU ----------------
-def _np(t):
-    return t.detach().cpu().numpy()
-
-
 def _mk(kind, n, mode, **kw):
     from gym_rotor_amd import QuadVecEnv
     return QuadVecEnv(kind, n, device="cuda", goal_mode=mode, layout="f64", **kw)

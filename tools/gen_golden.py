@@ -16,9 +16,9 @@ Files written (see tests/golden/README.md for the field lists):
   onestep_{kind}.npz       512 single-step transitions per env kind
   traj_free_{kind}.npz     1000-step free-run (no reset) trajectories, 4 envs per kind
   traj_reset_{kind}.npz    1000-step trajectories with reset-on-done to injected states
-  flightlog_modul.npz      first 1200 rows of results/MODUL_log_20250303_120200.dat
+  flightlog_modul.npz      all 3600 rows of results/MODUL_log_20250303_120200.dat
   gae.npz                  the reference's own GAE + normalisation lines (ppo.py:134-147) on synthetic data
-  trajgoal_m{0,1}_{kind}.npz  closed loop env + TrajectoryGenerator (modes 0/1) as main.py drives them
+  trajgoal_m{0,1,6}_{kind}.npz  closed loop env + TrajectoryGenerator (modes 0/1/6) as main.py drives them
 """
 import os
 import sys
@@ -366,7 +366,7 @@ def gen_trajgoal(kind, mode, n_env=4, T=400, seed=0):
         def start_episode(state, ep, t):
             inject(env, state, orc.DEFAULT_GOAL, np.zeros(8))
             gen.mark_traj_start(env.state)
-            queue[:] = [draws[e, ep, 0]] if mode == 0 else [draws[e, ep, 1], draws[e, ep, 2]]
+            queue[:] = {0: [draws[e, ep, 0]], 1: [draws[e, ep, 1], draws[e, ep, 2]]}.get(mode, [])
             xd, vd, b1d, b1d_dot, Wd = gen.get_desired(env.state, mode)
             assert not queue
             env.set_goal_state(xd, vd, b1d, b1d_dot, Wd)
@@ -437,7 +437,7 @@ def gen_gae(T=64, M=48, seed=0):
     print("gae golden written")
 
 
-def gen_flightlog(rows=1200):
+def gen_flightlog(rows=3600):
     log = np.loadtxt(os.path.join(REF, "results", "MODUL_log_20250303_120200.dat"))
     np.savez_compressed(os.path.join(OUT, "flightlog_modul.npz"), log=log[:rows])
     print("flightlog rows", rows, "of", log.shape)
@@ -456,5 +456,5 @@ if __name__ == "__main__":
         gen_traj(kind, "free")
         gen_traj(kind, "reset")
     for kind in ("coupled", "decoupled"):
-        for mode in (0, 1):
+        for mode in (0, 1, 6):
             gen_trajgoal(kind, mode)
