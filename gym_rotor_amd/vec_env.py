@@ -31,6 +31,21 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+# Raw handle of torch's current stream / current device with as little Python as possible: step()
+# is called once per env-step and the launch itself is only a few microseconds.
+try:
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+    _get_device = torch._C._cuda_getDevice
+    if not callable(_raw_stream) or not callable(_get_device):
+        raise AttributeError
+except AttributeError:  # pragma: no cover - older/newer torch without the private accessors
+    def _raw_stream(idx):
+        return torch.cuda.current_stream(idx).cuda_stream
+
+    def _get_device():
+        return torch.cuda.current_device()
+
+
 def _field_stride(n: int) -> int:
     """Elements between consecutive fields of the SoA buffers: N rounded up to a multiple of 4.
     (Padding the stride off powers of two was measured on MI355X and makes no difference: the
@@ -187,19 +202,20 @@ class QuadVecEnv:
 
     def _stream(self):
         # kernels are launched on the env's device: make it current for the call if it is not
-        if torch.cuda.current_device() != self.device.index:
+        idx = self.device.index
+        if _get_device() != idx:
             torch.cuda.set_device(self.device)
-        return torch.cuda.current_stream(self.device).cuda_stream
+        return _raw_stream(idx)
 
     def _check_actions(self, actions: torch.Tensor, lead=()):
-        want = tuple(lead) + (self.num_envs, self.action_dim)
         if not isinstance(actions, torch.Tensor):
             raise TypeError("actions must be a torch.Tensor on the env's device")
-        if actions.device != self.device:
-            raise ValueError(f"actions on {actions.device}, env on {self.device}")
         if actions.dtype != torch.float32:
             raise TypeError(f"actions must be float32, got {actions.dtype}")
-        if tuple(actions.shape) != want:
+        if actions.device != self.device:
+            raise ValueError(f"actions on {actions.device}, env on {self.device}")
+        want = tuple(lead) + (self.num_envs, self.action_dim)
+        if actions.shape != want:
             raise ValueError(f"actions shape {tuple(actions.shape)} != {want}")
         if not actions.is_contiguous():
             actions = actions.contiguous()
