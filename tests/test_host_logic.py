@@ -122,6 +122,17 @@ def test_abi_argument_errors_without_gpu():
     e.kind = 0
     assert lib.qr_error_obs(C.byref(e), 0x6000, None, None) == -2            # undefined for Quad-v0
     assert lib.qr_get_state(C.byref(e), None, None) == -1 and lib.qr_set_state(C.byref(e), None, None, None) == -1
+    # empty batch: a no-op that succeeds; oversize batch (32-bit buffer offsets): refused
+    e2, o2 = L.QrEnv(), L.QrStepOut()
+    e2.kind, e2.num_envs, e2.pos_vel, e2.att_rate = 0, 0, 0x1000, 0x2000
+    o2.reward, o2.done = 0x4000, 0x5000
+    assert lib.qr_step(C.byref(e2), 0x3000, 1, C.byref(o2), None) == 0
+    e2.num_envs = 1 << 26
+    assert lib.qr_step(C.byref(e2), 0x3000, 1, C.byref(o2), None) == -3
+    e2.num_envs, e2.field_stride = 100, 50
+    assert lib.qr_step(C.byref(e2), 0x3000, 1, C.byref(o2), None) == -3      # stride < N
+    e2.field_stride, e2.goal_mode = 0, 2
+    assert lib.qr_step(C.byref(e2), 0x3000, 1, C.byref(o2), None) == -1      # fused goals without traj buffer
     with pytest.raises(ValueError):
         L.check(-3, "x")
     with pytest.raises(L.QuadrotorLibError):
