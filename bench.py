@@ -7,9 +7,11 @@
 
 Workload (BASELINE.json configs[1]): Quad-v0, 65 536 envs per GPU, per-env reset-distribution
 states, +-10 % randomised parameters, U(-1,1) actions pre-generated on the device, float32
-I/O.  A "step" is ONE env.step() launch over the whole batch (qr_step through the C-ABI).
-Episodes that terminate are re-sampled inside the same launch (auto-reset, the way a vector
-env is driven in training; the CPU baseline resets on done too).  Envs are sharded over ranks
+I/O.  A "step" is ONE env.step() launch over the whole batch (qr_step through the C-ABI), with
+the reference's step() semantics: no reset inside step (configs[1]/SURVEY 8(d): free-running
+random-action steps from reset-distribution states).  The in-launch auto-reset variant
+(--auto-reset; what a training loop uses, configs[2]) is timed too and reported under
+config.other_reset_mode.  Envs are sharded over ranks
 with NO collective on the step path (weak scaling: 65 536 envs per GPU); `value` = all ranks'
 env-steps / the max-over-ranks time of the K timed steps, inputs resident in HBM.
 
@@ -49,7 +51,9 @@ def parse():
     p.add_argument("--substeps", type=int, default=1)
     p.add_argument("--layout", default="mixed", choices=["mixed", "f64", "f32"])
     p.add_argument("--mode", default="graph", choices=["graph", "eager"])
-    p.add_argument("--no-auto-reset", action="store_true")
+    p.add_argument("--auto-reset", action="store_true",
+                   help="re-sample terminated envs inside the launch (BASELINE configs[2] shape); default off = configs[1] as "
+                        "written: T free-running random-action steps, the reference's own step() semantics")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     p.add_argument("--action-batches", type=int, default=16)
     p.add_argument("--extras", type=int, default=1, help="0: only the headline measurement (used under rocprofv3)")
@@ -122,7 +126,7 @@ def main():
     from gym_rotor_amd import ALGO_BYTES, QuadVecEnv
     from gym_rotor_amd.constants import ALGO_BYTES_PARAMS
     N = a.envs
-    auto_reset = not a.no_auto_reset
+    auto_reset = a.auto_reset
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -160,6 +164,11 @@ def main():
                 torch.cuda.synchronize(dev)
                 if time.perf_counter() - t_w > 0.05:
                     break
+        # the timed steps start from reset-distribution states (configs[1]), not from wherever the
+        # untimed warm-up left the envs
+        env.reset("train")
+        if a.kind != "quad":
+            env.get_norm_error_state()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier() if timed else torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
