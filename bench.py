@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — env-steps/s of the batched quadrotor step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 1 --steps 1000 --warmup 50
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -44,8 +44,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=200)
-    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--steps", type=int, default=1000)   # ~5 ms timed: the post-barrier clock ramp (first ~50 launches
+    p.add_argument("--warmup", type=int, default=50)    # run 5-20 % slow) stays below 1 % of the region
     p.add_argument("--envs", type=int, default=65536, help="envs PER GPU")
     p.add_argument("--kind", default="quad", choices=["quad", "coupled", "decoupled"])
     p.add_argument("--substeps", type=int, default=1)
@@ -55,7 +55,7 @@ def parse():
                    help="re-sample terminated envs inside the launch (BASELINE configs[2] shape); default off = configs[1] as "
                         "written: T free-running random-action steps, the reference's own step() semantics")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
-    p.add_argument("--action-batches", type=int, default=16)
+    p.add_argument("--action-batches", type=int, default=64, help="distinct pre-generated [N,A] action slabs cycled through (64 x 1 MiB > L2: every step streams its actions)")
     p.add_argument("--extras", type=int, default=1, help="0: only the headline measurement (used under rocprofv3)")
     return p.parse_args()
 
