@@ -7,10 +7,12 @@
 
 Workload (BASELINE.json configs[1]): Quad-v0, 65 536 envs per GPU, per-env reset-distribution
 states, +-10 % randomised parameters, U(-1,1) actions pre-generated on the device, float32
-I/O.  A "step" is ONE env.step() launch over the whole batch (qr_step through the C-ABI), with
-the reference's step() semantics: no reset inside step (configs[1]/SURVEY 8(d): free-running
-random-action steps from reset-distribution states).  The in-launch auto-reset variant
-(--auto-reset; what a training loop uses, configs[2]) is timed too and reported under
+I/O.  A "step" is ONE env.step() launch over the whole batch (qr_step through the C-ABI).
+Random actions terminate an episode within ~100 steps, so — like every loop of the reference
+that steps an env (main.py:183-186 resets on done) — terminated envs are re-sampled, here
+inside the same launch (QR_FLAG_AUTO_RESET, ~1.2 % of the envs per step).  The free-running
+variant (--no-auto-reset: step() alone, the population tumbling far beyond termination, where
+the rate-adaptive substep count adds work) is timed too and reported under
 config.other_reset_mode.  Envs are sharded over ranks
 with NO collective on the step path (weak scaling: 65 536 envs per GPU); `value` = all ranks'
 env-steps / the max-over-ranks time of the K timed steps, inputs resident in HBM.
@@ -51,9 +53,9 @@ def parse():
     p.add_argument("--substeps", type=int, default=1)
     p.add_argument("--layout", default="mixed", choices=["mixed", "f64", "f32"])
     p.add_argument("--mode", default="graph", choices=["graph", "eager"])
-    p.add_argument("--auto-reset", action="store_true",
-                   help="re-sample terminated envs inside the launch (BASELINE configs[2] shape); default off = configs[1] as "
-                        "written: T free-running random-action steps, the reference's own step() semantics")
+    p.add_argument("--auto-reset", action=argparse.BooleanOptionalAction, default=True,
+                   help="re-sample terminated envs inside the launch (what a loop that steps the reference's env does on done); "
+                        "--no-auto-reset = T free-running random-action steps from one reset")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     p.add_argument("--action-batches", type=int, default=64, help="distinct pre-generated [N,A] action slabs cycled through (64 x 1 MiB > L2: every step streams its actions)")
     p.add_argument("--extras", type=int, default=1, help="0: only the headline measurement (used under rocprofv3)")
@@ -209,10 +211,11 @@ def main():
             "value": N * n_gpus * a.steps / wall, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if a.layout == "f32" else "f64", "data": "synthetic",
-            "config": {"workload": (f"BASELINE.json configs[1]: Quad-v0 batched {N} envs per GPU, random actions, fp32 I/O"
+            "config": {"workload": (f"BASELINE.json configs[1]: Quad-v0 batched {N} envs per GPU, random actions, fp32 I/O, "
+                                    + ("terminated envs re-sampled in the launch" if auto_reset else "free run from one reset")
                                     if a.kind == "quad" else f"{a.kind} wrapper, {N} envs per GPU, random actions, fp32 I/O"),
                        "kind": a.kind, "envs_per_gpu": N, "global_envs": N * n_gpus, "substeps": a.substeps,
-                       "integrator": "RK4 fixed-step on (v, unit quaternion, W)", "state_layout": a.layout, "io_dtype": "f32",
+                       "integrator": "RK4 on (v, unit quaternion, W), substeps x ceil(max|W|/16 rad/s) per wavefront", "state_layout": a.layout, "io_dtype": "f32",
                        "auto_reset": auto_reset, "done_rate_last_step": done_rate, "launch_mode": a.mode,
                        "parallelism": f"env-shard x{n_gpus}, no collective", "state_finite": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("QR_LIB", os.path.join(_HERE, "libquadrotor_hip.so"))
 KIND_QUAD, KIND_COUPLED, KIND_DECOUPLED = 0, 1, 2
 KIND_ID = {"quad": KIND_QUAD, "coupled": KIND_COUPLED, "decoupled": KIND_DECOUPLED}
 FLAG_AUTO_RESET, FLAG_EVAL_RESET, FLAG_NO_UDM = 1, 2, 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 GOAL_EXTERNAL, GOAL_MODE0, GOAL_MODE1, GOAL_MODE6 = 0, 1, 2, 3
 GOAL_ID = {None: 0, 0: 1, 1: 2, 6: 3}  # TrajectoryGenerator mode -> QR_GOAL_*
 LAYOUT_ID = {"mixed": 0, "f64": 1, "f32": 2}
@@ -34,7 +34,7 @@ class QrCoeffs(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "Cx", "CIx", "Cv", "Cb1", "CIb1", "CW", "Cw12", "CW3", "alpha", "beta", "dt",
         "x_lim", "v_lim", "W_lim", "eIx_lim", "eIb1_lim", "euler_lim_deg", "udm_fraction",
-        "eight_T", "eight_A1", "eight_A2", "eight_w_b1d", "eight_alt_d", "eight_eps", "eight_count")]
+        "eight_T", "eight_A1", "eight_A2", "eight_w_b1d", "eight_alt_d", "eight_eps", "eight_count", "w_adapt")]
 
 
 class QrEnv(C.Structure):

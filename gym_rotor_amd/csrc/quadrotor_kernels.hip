@@ -53,6 +53,7 @@ struct Coeffs {  // double-precision copy of QrCoeffs + derived reward floors
   double inv_x_lim, inv_v_lim, inv_W_lim, inv_eIx_lim, inv_eIb1_lim, inv_nrmin_mono, inv_nrmin_1, inv_nrmin_2;
   // eight-shaped curve (trajectory_generator.py:98-110, 418-505)
   float e8_w1, e8_w2, e8_k, e8_A1, e8_A2, e8_wb, e8_alt, e8_tmax;
+  double inv_w_adapt;  // 1 / w_adapt, 0 = fixed substep count
 };
 
 struct Args {
@@ -735,8 +736,10 @@ __device__ __forceinline__ void idle_work(Work<T>& w) {  // lanes past the ragge
 // The fused step / rollout kernel
 // ------------------------------------------------------------------------------------
 // TRAJ = the goal generator (trajectory_generator.py modes 0/1) is fused into the step; a
-// separate instantiation so that the default path carries none of its registers.
-template <int KIND, typename XV, typename QW, int B, bool TRAJ>
+// separate instantiation so that the default path carries none of its registers.  ADAPT = the
+// rate-adaptive substep count (QrCoeffs::w_adapt); launch_kind() picks the plain instantiation
+// whenever adaptivity provably cannot trigger.
+template <int KIND, typename XV, typename QW, int B, bool TRAJ, bool ADAPT>
 __global__ __launch_bounds__(B, (TRAJ ? 1 : QR_WAVES_PER_SIMD)) void step_kernel(const Args a) {
   using T = QW;  // arithmetic type
   using KT = KindTraits<KIND>;
@@ -829,8 +832,22 @@ __global__ __launch_bounds__(B, (TRAJ ? 1 : QR_WAVES_PER_SIMD)) void step_kernel
     Dyn<T> dyn;
     action_map<KIND, T>(act, w, dyn);
     // ---- observation_wrapper: integrate over dt with zero-order-hold (f, M) ----
-    const T h = T(c.dt / (double)a.substeps);
-    for (int s = 0; s < a.substeps; ++s) rk4_step(w.x, w.y, h, dyn);
+    // The reference's DOP853 is adaptive (6 % of its steps subdivide); the fixed-step stand-in
+    // is made rate-adaptive: RK4's local error grows like (|W| h)^5, so a wave that contains an
+    // env spinning faster than w_adapt takes ceil(max|W_i| / w_adapt) times the substeps.  The
+    // multiplier is the wave's maximum (found with ballots, so the substep loop stays wave-uniform
+    // and in regime — |W| < 2 pi < w_adapt — this costs one ballot): every lane takes at least
+    // the count its own rate asks for.
+    int nsub = a.substeps;
+    if constexpr (ADAPT) {
+      const T wmax = fmax(fmax(fabs(w.y[7]), fabs(w.y[8])), fabs(w.y[9]));
+      const T need = wmax * T(c.inv_w_adapt);
+      int mul = 1;
+      while (mul < 16 && __ballot(need > T(mul))) ++mul;
+      nsub *= mul;
+    }
+    const T h = T(c.dt) * recip(T(nsub));
+    for (int s = 0; s < nsub; ++s) rk4_step(w.x, w.y, h, dyn);
     renorm_quat(&w.y[3]);
     // x, v take their storage precision at every env-step boundary, so that a K-step rollout
     // (state kept in registers) is bit-identical to K single-step launches
@@ -1234,6 +1251,7 @@ static void fill_coeffs(Coeffs& o, const QrCoeffs& q) {
   o.e8_k = (float)(-log(q.eight_eps > 0 ? q.eight_eps : 0.01) / T8);                   // :107-108
   o.e8_A1 = (float)q.eight_A1; o.e8_A2 = (float)q.eight_A2; o.e8_wb = (float)q.eight_w_b1d; o.e8_alt = (float)q.eight_alt_d;
   o.e8_tmax = (float)(q.eight_count * T8);                                             // :436
+  o.inv_w_adapt = q.w_adapt > 0 ? 1.0 / q.w_adapt : 0.0;
 }
 
 static int fill_env(Args& a, const QrEnv* e) {
@@ -1265,8 +1283,16 @@ static inline int pick_block(int64_t) { return 64; }
 template <int KIND, typename XV, typename QW>
 static void launch_kind(const Args& a, hipStream_t s) {
   const dim3 grid((unsigned)((a.n + 63) / 64));
-  if (a.goal_mode == QR_GOAL_EXTERNAL) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false>), grid, dim3(64), 0, s, a);
-  else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true>), grid, dim3(64), 0, s, a);
+  // Rate adaptivity can only trigger when an env starts a step with max|W_i| > w_adapt.  With
+  // AUTO_RESET every env whose rate error left its bound was re-sampled at the end of the step
+  // that took it there (done): Quad-v0 |W_i| < W_lim, Coupled |W_i - Wd_i| < W_lim, Decoupled
+  // |W - Wd| < 2 W_lim (|ew12_i| < W_lim and |eW3| < W_lim).  For goal rates |Wd| <= W_lim / 2
+  // and w_adapt >= 2.5 W_lim (the default 16 rad/s is) the plain kernel computes the same bits.
+  const bool adapt = a.c.inv_w_adapt > 0 &&
+                     (!(a.flags & QR_FLAG_AUTO_RESET) || a.c.inv_w_adapt * a.c.W_lim * 2.5 > 1.0);
+  if (a.goal_mode != QR_GOAL_EXTERNAL) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true>), grid, dim3(64), 0, s, a);
+  else if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true>), grid, dim3(64), 0, s, a);
+  else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false>), grid, dim3(64), 0, s, a);
 }
 
 template <typename XV, typename QW>
@@ -1347,6 +1373,7 @@ void qr_default_coeffs(QrCoeffs* c) {
   c->eIx_lim = 3.0; c->eIb1_lim = 3.0; c->euler_lim_deg = 85.0; c->udm_fraction = 0.1;
   c->eight_T = 9.0; c->eight_A1 = 1.5; c->eight_A2 = 1.0; c->eight_w_b1d = 0.349066; c->eight_alt_d = -0.6;  // trajectory_generator.py:98-110
   c->eight_eps = 0.01; c->eight_count = 3.0;
+  c->w_adapt = 16.0;
 }
 
 int qr_step(const QrEnv* env, const float* action, int32_t substeps, const QrStepOut* out, void* stream) {

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define QR_ABI_VERSION 6
+#define QR_ABI_VERSION 7
 
 /* env kinds */
 #define QR_KIND_QUAD      0 /* QuadEnv            gym_rotor/envs/quad.py:19            */
@@ -86,6 +86,15 @@ typedef struct QrCoeffs {
   double eight_T, eight_A1, eight_A2; /* period 9 s, amplitudes 1.5 / 1.0                  */
   double eight_w_b1d, eight_alt_d;    /* yaw rate 0.349066 rad/s, desired altitude -0.6 m  */
   double eight_eps, eight_count;      /* smoothing epsilon 0.01, number of eights 3        */
+  /* Rate-adaptive substepping (the fixed-step stand-in for DOP853's error control, quad.py:265):
+   * a wavefront (64 consecutive envs) containing an env whose body rate max|W_i| exceeds w_adapt
+   * takes ceil(max|W_i| / w_adapt) times the requested substeps (capped at 16x), so envs that
+   * are stepped on far beyond termination (free run, no AUTO_RESET) keep the 1e-5 trajectory
+   * bar.  Default 16 rad/s ~ 2.5x the termination bound W_lim = 2 pi: in-regime envs always take
+   * exactly `substeps`, and with QR_FLAG_AUTO_RESET (every env is re-sampled when its rate
+   * error leaves its bound; goal rates |Wd| <= W_lim / 2) it can never trigger, so the launcher
+   * then uses the kernel compiled without it.  0 disables it. */
+  double w_adapt;
 } QrCoeffs;
 
 /* Per-env device buffers owned by the caller (the Python env object). */

@@ -136,7 +136,7 @@ def test_torch_custom_ops_match_env_step():
     obs_ref, r_ref, d_ref, _, _ = ref.step(a)
     obs = torch.empty(n, 23, device="cuda"); rwd = torch.empty(n, 1, device="cuda"); done = torch.zeros(n, 1, dtype=torch.bool, device="cuda")
     torch.ops.gym_rotor_amd.qr_step(env._pos_vel, env._att_rate, env._integ, env._params, None, env._episode, a, obs, None, rwd, done,
-                                    _lib.KIND_ID["coupled"], _lib.LAYOUT_ID["mixed"], 1, 0, 6, 0)
+                                    _lib.KIND_ID["coupled"], _lib.LAYOUT_ID[env.layout], 1, 0, 6, 0)
     assert torch.equal(obs, obs_ref) and torch.equal(rwd, r_ref) and torch.equal(done, d_ref)
     assert torch.equal(env.get_current_state(), ref.get_current_state())
     T, M = 16, 300

@@ -415,3 +415,89 @@ def test_compat_single_env_matches_reference_trajectory(golden):
             assert np.abs(np.array(rwd) - d["rewards"][t, 0]).max() <= 1e-5
             assert done == list(d["dones"][t, 0])
         assert np.abs(env.get_current_state() - d["states"][50, 0]).max() <= 1e-7
+
+
+@pytest.mark.parametrize("layout,tol_state,tol_obs", [("mixed", 1e-5, 1e-4), ("f64", 2e-6, 1e-5)])
+@pytest.mark.parametrize("kind", KINDS)
+def test_trajectory_vs_oracle_256_envs_1000_steps(kind, layout, tol_state, tol_obs):
+    """The north-star bar on a larger sample than the reference goldens: 256 envs x 1000 free-run
+    random-action steps, 1 substep, against the float64 DOP853 oracle (itself pinned to the
+    reference at 1e-13 per step).  Default layout (`mixed`: x, v stored as float32): the worst env
+    sits at ~1.6e-6 — in this far-out-of-regime free run |x| reaches 150 m (ulp 1.5e-5) — and
+    single float32 observation elements can be off by ~2e-5 of their own magnitude.  The all-float64
+    layout: 2e-7..1e-6."""
+    n, T = 256, 1000
+    rng = np.random.default_rng(77 + KINDS.index(kind))
+    A = orc.ACTION_DIM[kind]
+    state = _state_roundtrip(orc.sample_reset_state(rng, n).astype(np.float32).astype(np.float64))
+    params = orc.sample_params(rng, n).astype(np.float32).astype(np.float64)
+    acts = rng.uniform(-1, 1, (T, n, A)).astype(np.float32)
+    env = _env(kind, n, layout=layout, obs_rows=True)
+    env.set_state(state, integ=np.zeros((n, 8)), params=params)
+    ro = env.rollout(torch.from_numpy(acts).cuda())      # one launch, bit-identical to 1000 steps
+    got = _np(env.get_current_state())
+    s, integ = state, np.zeros((n, 8))
+    worst_obs, where = 0.0, None
+    for t in range(T):
+        o = orc.step_batch(kind, s, acts[t].astype(np.float64), params, None, integ)
+        s, integ = o["state"], o["integ"]
+        if t % 100 == 99:
+            for k, ob in enumerate(o["obs"]):
+                g = _np(_obs_list(ro["obs"])[k][t]).astype(np.float64)
+                r = np.asarray(ob, dtype=np.float64)
+                e = np.abs(g - r) / np.maximum(np.abs(r), 1.0)
+                if e.max() > worst_obs:
+                    worst_obs, where = float(e.max()), (t, k) + tuple(int(i) for i in np.unravel_index(e.argmax(), e.shape))
+    err = grouped_rel_err(got, s)
+    print(f"256 envs x 1000 steps {kind}/{layout}: final-state grouped error {err:.2e}, obs {worst_obs:.2e} at (t, obs, env, col) = {where}")
+    assert err <= tol_state and worst_obs <= tol_obs
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_free_run_tail_2048_envs_1000_steps(kind):
+    """Default configuration on a population large enough to have a tail: 2048 envs stepped on for
+    1000 random-action steps with no reset — far beyond termination, the fastest spin 35-50 rad/s
+    (the termination bound is 2 pi).  With a fixed substep count the RK4 truncation error of those
+    envs reaches 2e-5..6e-5; the rate-adaptive substep count (w_adapt = 16 rad/s, default) keeps
+    EVERY env inside the 1e-5 bar against the float64 DOP853 oracle."""
+    n, T = 2048, 1000
+    rng = np.random.default_rng(500 + KINDS.index(kind))
+    A = orc.ACTION_DIM[kind]
+    state = _state_roundtrip(orc.sample_reset_state(rng, n).astype(np.float32).astype(np.float64))
+    params = orc.sample_params(rng, n).astype(np.float32).astype(np.float64)
+    acts = rng.uniform(-1, 1, (T, n, A)).astype(np.float32)
+    s, integ = state, np.zeros((n, 8))
+    for t in range(T):
+        o = orc.step_batch(kind, s, acts[t].astype(np.float64), params, None, integ)
+        s, integ = o["state"], o["integ"]
+    wmax = np.abs(s[:, 15:18]).max()
+    acts_d = torch.from_numpy(acts).cuda()
+    errs = {}
+    for w_adapt in (16.0, 0.0):
+        env = _env(kind, n, obs_rows=True, w_adapt=w_adapt)
+        assert env.layout == "mixed" and env.substeps == 1
+        env.set_state(state, integ=np.zeros((n, 8)), params=params)
+        env.rollout(acts_d)
+        errs[w_adapt] = grouped_rel_err(_np(env.get_current_state()), s)
+    print(f"2048-env free run {kind}: max|W| {wmax:.1f} rad/s, grouped error adaptive {errs[16.0]:.2e}, fixed {errs[0.0]:.2e}")
+    assert errs[16.0] <= 1e-5
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_adaptive_kernel_is_the_plain_kernel_in_regime(kind):
+    """In regime (|W| below w_adapt) the rate-adaptive kernel takes exactly `substeps` substeps:
+    its results are bit-identical to the kernel compiled without adaptivity — free run from reset
+    for 40 steps, and 300 auto-reset steps (where the launcher itself picks the plain kernel)."""
+    n = 1000
+    A = orc.ACTION_DIM[kind]
+    for auto_reset, T in ((False, 40), (True, 300)):
+        acts = (torch.rand(T, n, A, device="cuda", generator=torch.Generator("cuda").manual_seed(9)) * 2 - 1) * 0.3
+        out = []
+        for w_adapt in (16.0, 0.0):
+            env = _env(kind, n, seed=4, auto_reset=auto_reset, w_adapt=w_adapt)
+            env.reset("train")
+            ro = env.rollout(acts)
+            out.append((_np(env.get_current_state()), _np(ro["reward"]), _np(ro["terminated"])))
+        assert np.abs(out[0][0][:, 15:18]).max() < 16.0
+        for x, y in zip(*out):
+            assert np.array_equal(x, y)

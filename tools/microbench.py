@@ -59,7 +59,7 @@ for n in map(int, a.envs.split(",")):
     for kind in a.kinds.split(","):
         for ar in map(int, a.auto_reset.split(",")):
             T = 100
-            env = QuadVecEnv(kind, n, device=dev, substeps=1, auto_reset=bool(ar), layout="mixed",
+            env = QuadVecEnv(kind, n, device=dev, substeps=1, auto_reset=bool(ar), layout=a.layouts.split(",")[0],
                              obs_rows=True if kind != "quad" else bool(a.obs_rows))
             env.reset("train")
             acts = torch.rand(T, n, env.action_dim, device=dev) * 2 - 1
