@@ -740,7 +740,16 @@ __device__ __forceinline__ void idle_work(Work<T>& w) {  // lanes past the ragge
 // rate-adaptive substep count (QrCoeffs::w_adapt); launch_kind() picks the plain instantiation
 // whenever adaptivity provably cannot trigger.
 template <int KIND, typename XV, typename QW, int B, bool TRAJ, bool ADAPT>
-__global__ __launch_bounds__(B, (TRAJ ? 1 : QR_WAVES_PER_SIMD)) void step_kernel(const Args a) {
+__global__ __launch_bounds__(B, (TRAJ ? 1 : QR_WAVES_PER_SIMD))
+void step_kernel(void* pos_vel, void* att_rate, const float* action, float* params, float* integ, int64_t n_envs,
+                 int64_t ld_envs, const Args a_in) {
+  // The leading scalar arguments duplicate the fields of Args the first loads depend on: as
+  // plain kernel arguments they are preloaded into SGPRs by the dispatcher (gfx950 kernarg
+  // preload, -mllvm -amdgpu-kernarg-preload-count), so the state loads are issued without first
+  // waiting for a scalar-load round trip to the kernarg segment.
+  Args a = a_in;
+  a.pos_vel = pos_vel; a.att_rate = att_rate; a.action = action; a.params = params; a.integ = integ;
+  a.n = n_envs; a.ld = ld_envs;
   using T = QW;  // arithmetic type
   using KT = KindTraits<KIND>;
   constexpr int A = KT::A, D0 = KT::D0, D1 = KT::D1 ? KT::D1 : 1, NAG = KT::NAG;
@@ -1290,9 +1299,11 @@ static void launch_kind(const Args& a, hipStream_t s) {
   // and w_adapt >= 2.5 W_lim (the default 16 rad/s is) the plain kernel computes the same bits.
   const bool adapt = a.c.inv_w_adapt > 0 &&
                      (!(a.flags & QR_FLAG_AUTO_RESET) || a.c.inv_w_adapt * a.c.W_lim * 2.5 > 1.0);
-  if (a.goal_mode != QR_GOAL_EXTERNAL) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true>), grid, dim3(64), 0, s, a);
-  else if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true>), grid, dim3(64), 0, s, a);
-  else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false>), grid, dim3(64), 0, s, a);
+#define QR_STEP_ARGS a.pos_vel, a.att_rate, a.action, a.params, a.integ, a.n, a.ld, a
+  if (a.goal_mode != QR_GOAL_EXTERNAL) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+  else if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+  else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+#undef QR_STEP_ARGS
 }
 
 template <typename XV, typename QW>
