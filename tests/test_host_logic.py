@@ -222,3 +222,40 @@ def test_gymnasium_is_optional():
     if importlib.util.find_spec("gymnasium") is None:
         with pytest.raises(ImportError):
             gym_rotor_amd.as_gymnasium_vector_env(None)
+
+
+def _integration_snippet():
+    """The first python block of INTEGRATION.md §2 (the binding a maintainer would add)."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(import ctypes as C, torch\n.*?)```", text, re.S).group(1)
+    return block
+
+
+def test_integration_md_binding_matches_the_abi():
+    """The ctypes structs printed in INTEGRATION.md are the ABI a reader will copy: they must be
+    field-for-field the ones gym_rotor_amd/_lib.py (checked against the header above) uses."""
+    from gym_rotor_amd import _lib
+    block = _integration_snippet()
+    assert f"qr_abi_version() == {_lib.ABI_VERSION}" in block
+    decl = block[block.index("class QrCoeffs"):block.index("N = 65536")]
+    ns = {"C": C}
+    exec(decl, ns)
+    for name in ("QrCoeffs", "QrEnv", "QrStepOut"):
+        doc, real = ns[name], getattr(_lib, name)
+        assert C.sizeof(doc) == C.sizeof(real), name
+        assert [(n, getattr(doc, n).offset, getattr(doc, n).size) for n, *_ in doc._fields_] == \
+               [(n, getattr(real, n).offset, getattr(real, n).size) for n, *_ in real._fields_], name
+
+
+@pytest.mark.gpu
+def test_integration_md_binding_runs():
+    """Run that snippet as written (raw ctypes, no gym_rotor_amd import) on the GPU."""
+    from gym_rotor_amd import _lib
+    block = _integration_snippet().replace('C.CDLL("libquadrotor_hip.so")', f"C.CDLL({_lib.LIB_PATH!r})")
+    ns = {}
+    exec(block, ns)
+    torch.cuda.synchronize()
+    obs, rew, done = ns["obs"], ns["rew"], ns["done"]
+    assert torch.isfinite(obs).all() and obs.abs().max() <= 1.5
+    assert ((rew >= 0) & (rew <= 1) | (rew == -1)).all()
+    assert 0 < done.float().mean() < 0.2 or done.sum() == 0
