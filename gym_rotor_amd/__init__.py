@@ -10,6 +10,7 @@ from .sharding import shard_range, make_sharded_env, all_gather_rows  # noqa: F4
 from .vec_env import QuadVecEnv, as_gymnasium_vector_env  # noqa: F401
 from .compat import QuadEnv, CoupledWrapper, DecoupledWrapper  # noqa: F401
 from .rollout import RolloutStorage  # noqa: F401
+from .policy import ActorParams, random_actors  # noqa: F401
 from . import torch_ops  # noqa: F401  (registers torch.ops.gym_rotor_amd.*)
 
 __all__ = ["QuadVecEnv", "QuadEnv", "CoupledWrapper", "DecoupledWrapper", "QuadConstants", "Box",

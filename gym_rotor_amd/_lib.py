@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("QR_LIB", os.path.join(_HERE, "libquadrotor_hip.so"))
 KIND_QUAD, KIND_COUPLED, KIND_DECOUPLED = 0, 1, 2
 KIND_ID = {"quad": KIND_QUAD, "coupled": KIND_COUPLED, "decoupled": KIND_DECOUPLED}
 FLAG_AUTO_RESET, FLAG_EVAL_RESET, FLAG_NO_UDM = 1, 2, 4
-ABI_VERSION = 7
+ABI_VERSION = 8
 GOAL_EXTERNAL, GOAL_MODE0, GOAL_MODE1, GOAL_MODE6 = 0, 1, 2, 3
 GOAL_ID = {None: 0, 0: 1, 1: 2, 6: 3}  # TrajectoryGenerator mode -> QR_GOAL_*
 LAYOUT_ID = {"mixed": 0, "f64": 1, "f32": 2}
@@ -25,7 +25,7 @@ ERRORS = {-1: "QR_E_NULL: a required pointer is NULL", -2: "QR_E_KIND: bad env k
           -3: "QR_E_SIZE: bad num_envs / substeps / n_steps", -4: "QR_E_ALIGN: buffer not 16-byte aligned"}
 
 # every symbol include/quadrotor_hip.h declares
-SYMBOLS = ("qr_step", "qr_rollout", "qr_error_obs", "qr_reset", "qr_get_state", "qr_set_state",
+SYMBOLS = ("qr_step", "qr_rollout", "qr_rollout_actor", "qr_error_obs", "qr_reset", "qr_get_state", "qr_set_state",
            "qr_traj_start", "qr_get_desired", "qr_gae",
            "qr_default_coeffs", "qr_abi_version", "qr_step_kernel_info")
 
@@ -50,6 +50,18 @@ class QrEnv(C.Structure):
 class QrStepOut(C.Structure):
     _fields_ = [("obs0", C.c_void_p), ("obs1", C.c_void_p), ("reward", C.c_void_p),
                 ("reward_raw", C.c_void_p), ("done", C.c_void_p), ("truncated", C.c_void_p)]
+
+
+class QrActor(C.Structure):
+    _fields_ = [("fc1_w", C.c_void_p), ("fc1_b", C.c_void_p), ("fc2_w", C.c_void_p), ("fc2_b", C.c_void_p),
+                ("mean_w", C.c_void_p), ("mean_b", C.c_void_p), ("log_std", C.c_void_p),
+                ("obs_dim", C.c_int32), ("hidden_dim", C.c_int32), ("action_dim", C.c_int32), ("reserved0", C.c_int32)]
+
+
+class QrPolicyRollout(C.Structure):
+    _fields_ = [("actors", C.POINTER(QrActor)), ("obs0_in", C.c_void_p), ("obs1_in", C.c_void_p), ("noise", C.c_void_p),
+                ("noise_seed", C.c_uint64), ("step_base", C.c_uint64), ("max_action", C.c_float), ("deterministic", C.c_int32),
+                ("action_out", C.c_void_p), ("logprob_out", C.c_void_p)]
 
 
 class QuadrotorLibError(RuntimeError):
@@ -81,6 +93,8 @@ def load():
     lib.qr_step.argtypes = [P(QrEnv), C.c_void_p, C.c_int32, P(QrStepOut), C.c_void_p]
     lib.qr_rollout.restype = C.c_int
     lib.qr_rollout.argtypes = [P(QrEnv), C.c_void_p, C.c_int32, C.c_int32, P(QrStepOut), C.c_void_p]
+    lib.qr_rollout_actor.restype = C.c_int
+    lib.qr_rollout_actor.argtypes = [P(QrEnv), P(QrPolicyRollout), C.c_int32, C.c_int32, P(QrStepOut), C.c_void_p]
     lib.qr_error_obs.restype = C.c_int
     lib.qr_error_obs.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p, C.c_void_p]
     lib.qr_reset.restype = C.c_int

@@ -56,6 +56,10 @@ struct Coeffs {  // double-precision copy of QrCoeffs + derived reward floors
   double inv_w_adapt;  // 1 / w_adapt, 0 = fixed substep count
 };
 
+struct ActorW {  // QrActor's tensors (torch.nn.Linear layout: weight [out][in])
+  const float *fc1_w, *fc1_b, *fc2_w, *fc2_b, *mean_w, *mean_b, *log_std;
+};
+
 struct Args {
   // per-env buffers
   void* pos_vel;
@@ -89,6 +93,17 @@ struct Args {
   int32_t substeps;
   int32_t max_episode_steps;
   uint32_t flags;
+  // qr_rollout_actor: the policy in the loop
+  ActorW actor[2];
+  const float* obs0_in;
+  const float* obs1_in;
+  const float* noise;
+  float* act_out;
+  float* logp_out;
+  uint64_t noise_seed;
+  uint64_t step_base;
+  float max_action;
+  int32_t deterministic;
   Coeffs c;
 };
 
@@ -733,14 +748,184 @@ __device__ __forceinline__ void idle_work(Work<T>& w) {  // lanes past the ragge
 }
 
 // ------------------------------------------------------------------------------------
+// PPO actor in the loop (qr_rollout_actor)
+// ------------------------------------------------------------------------------------
+// tanh for the action mean: (1 - e) / (1 + e), e = exp(-2|x|), sign restored.  Absolute error
+// <= 2e-7 (v_exp_f32 + v_rcp_f32); branch-free, unlike the OCML tanhf (three regimes).
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float e = __expf(-2.0f * fabsf(x));
+  const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+  return copysignf(t, x);
+}
+
+// MLP_Actor_PPO.forward (ppo_mlp.py:30-43): tanh(mean_linear(relu(fc2(relu(fc1(x)))))).  One lane
+// = one env = one row of the batch.  The weights are wave-uniform: they are copied once per launch
+// into LDS, TRANSPOSED to [in][out] (out padded to a multiple of 4), and every lane reads the
+// same address — broadcast ds_read_b128, no bank conflicts, 4 weights per LDS instruction.
+// A layer is evaluated input-major: for each input k, all `out` accumulators take one FMA, so
+// consecutive FMAs are independent (16 chains in flight).  Output-major — each neuron's 23-term
+// dot product as one dependent FMA chain — measures 3x slower here: with one wave per SIMD
+// nothing hides the ~10-cycle dependent-FMA latency.
+template <int D, int H, int A>
+struct ActorLds {
+  static constexpr int HP = (H + 3) & ~3, AP = (A + 3) & ~3;
+  static constexpr int O_FC1W = 0, O_FC1B = O_FC1W + D * HP, O_FC2W = O_FC1B + HP, O_FC2B = O_FC2W + H * HP,
+                       O_MW = O_FC2B + HP, O_MB = O_MW + H * AP, O_LS = O_MB + AP, SIZE = O_LS + AP;
+
+  __device__ static void fill(float* sm, const ActorW& p, int tid) {  // sm[k][j] = W[j][k]
+    for (int i = tid; i < D * HP; i += 64) { const int k = i / HP, j = i - k * HP; sm[O_FC1W + i] = j < H ? p.fc1_w[j * D + k] : 0.0f; }
+    for (int i = tid; i < H * HP; i += 64) { const int k = i / HP, j = i - k * HP; sm[O_FC2W + i] = j < H ? p.fc2_w[j * H + k] : 0.0f; }
+    for (int i = tid; i < H * AP; i += 64) { const int k = i / AP, j = i - k * AP; sm[O_MW + i] = j < A ? p.mean_w[j * H + k] : 0.0f; }
+    if (tid < HP) { sm[O_FC1B + tid] = tid < H ? p.fc1_b[tid] : 0.0f; sm[O_FC2B + tid] = tid < H ? p.fc2_b[tid] : 0.0f; }
+    if (tid < AP) { sm[O_MB + tid] = tid < A ? p.mean_b[tid] : 0.0f; sm[O_LS + tid] = tid < A ? p.log_std[tid] : 0.0f; }
+  }
+
+  template <int NI, int NO, int NOP>
+  __device__ __forceinline__ static void layer(const float* w, const float* bias, const float (&x)[NI], float (&y)[NO]) {
+#pragma unroll
+    for (int j = 0; j < NO; ++j) y[j] = bias[j];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+#pragma unroll
+      for (int j = 0; j < NO; ++j) y[j] = fmaf(w[k * NOP + j], x[k], y[j]);
+    }
+  }
+
+  __device__ __forceinline__ static void mean(const float* sm, const float (&x)[D], float (&out)[A]) {
+    float h1[H], h2[H];
+    layer<D, H, HP>(sm + O_FC1W, sm + O_FC1B, x, h1);
+#pragma unroll
+    for (int j = 0; j < H; ++j) h1[j] = fmaxf(h1[j], 0.0f);
+    layer<H, H, HP>(sm + O_FC2W, sm + O_FC2B, h1, h2);
+#pragma unroll
+    for (int j = 0; j < H; ++j) h2[j] = fmaxf(h2[j], 0.0f);
+    layer<H, A, AP>(sm + O_MW, sm + O_MB, h2, out);
+#pragma unroll
+    for (int j = 0; j < A; ++j) out[j] = tanh_fast(out[j]);
+  }
+};
+
+// The 16-wide actor on the matrix cores.  Evaluated per-lane on the VALU the three layers are
+// 688 FMAs per env-step whose 744 wave-uniform weights have to be re-delivered every step
+// (LDS broadcast reads or scalar loads): with the step kernel at its VGPR limit only two
+// ds_read_b128 fit in flight and the evaluation measures 3.8 us, LDS-latency-bound.  As a
+// transposed GEMM  H^T[16 x 64 envs] = W[16 x K] . X^T[K x 64]  on v_mfma_f32_16x16x4_f32 (exact f32)
+// the weights are the A operand and stay RESIDENT in 14 registers per lane for the whole
+// rollout; only the observations move (one LDS read per MFMA for the first layer).
+//   lane l: c = l & 15, g = l >> 4.   A: lane supplies A[c][k = g].  B: B[k = g][c].
+//   D: lane holds D[4 g + r][c], r = 0..3.  The 64 envs are 4 column blocks b of 16.
+//   layer 1: A = W1[c][4 s + g] (k-step s), B = X[env 16 b + c][4 s + g] from the LDS obs tile,
+//            D_b = h1[b][r] = H1[4 g + r][env 16 b + c].
+//   layer 2: the lane's h1[b][s] IS a B operand if k-step s is given the hidden units
+//            k(s, g) = 4 g + s, so A = W2[c][4 g + s]: no data movement between layers.
+//   layer 3: block b uses A_b = W3 placed in rows 4 b .. 4 b + 3 (zero elsewhere) and all blocks
+//            accumulate into ONE D: lane (g, c) then holds mean[r] of env 16 g + c — its own env.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int D>  // obs_dim 23 (COUPLED) or 15 (DECOUPLED agent 1); hidden 16, 4 actions
+struct ActorMfma {
+  static constexpr int KS = (D + 3) / 4;
+  float a1[KS], a2[4], w3[4], bias1[4], bias2[4], bias3[4], log_std[4];
+
+  __device__ __forceinline__ void load(const ActorW& p, int lane) {
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) a1[s] = (4 * s + g < D) ? p.fc1_w[c * D + 4 * s + g] : 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { a2[s] = p.fc2_w[c * 16 + 4 * g + s]; w3[s] = p.mean_w[(c & 3) * 16 + 4 * g + s]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      bias1[r] = p.fc1_b[4 * g + r]; bias2[r] = p.fc2_b[4 * g + r]; bias3[r] = p.mean_b[r]; log_std[r] = p.log_std[r];
+    }
+  }
+
+  // xs: LDS tile [64 envs][D] of the wave's observations (row = lane)
+  __device__ __forceinline__ void mean(const float* xs, int lane, float (&out)[4]) const {
+    const int c = lane & 15, g = lane >> 4;
+    f32x4 h1[4], h2[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      h1[b] = f32x4{bias1[0], bias1[1], bias1[2], bias1[3]};
+      h2[b] = f32x4{bias2[0], bias2[1], bias2[2], bias2[3]};
+    }
+    // all B operands of the first layer are requested before the first MFMA (the reads are
+    // unconditional: past the last feature the address is clamped and the weight a1 is 0)
+    float x[KS][4];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = (4 * s + g < D) ? 4 * s + g : D - 1;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) x[s][b] = xs[(16 * b + c) * D + k];
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) h1[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], x[s][b], h1[b], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) h2[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[s], fmaxf(h1[b][s], 0.0f), h2[b], 0, 0, 0);
+    }
+    f32x4 m0 = f32x4{bias3[0], bias3[1], bias3[2], bias3[3]}, m1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};  // two chains
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float w = ((c >> 2) == b) ? w3[s] : 0.0f;
+        f32x4& m = (b & 1) ? m1 : m0;
+        m = __builtin_amdgcn_mfma_f32_16x16x4f32(w, fmaxf(h2[b][s], 0.0f), m, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = tanh_fast(m0[r] + m1[r]);
+  }
+};
+
+// PPO.choose_action (ppo.py:93-101): a = clamp(mean + exp(log_std) eps, +-max_action) and the
+// per-component Normal(mean, std).log_prob of the clamped action (ppo.py:97-98).
+template <int A>
+__device__ __forceinline__ void actor_sample(const float* log_std, const float (&mean)[A], const float* eps, bool deterministic,
+                                             float max_action, float* act, float* logp) {
+#pragma unroll
+  for (int j = 0; j < A; ++j) {
+    const float ls = log_std[j];
+    const float sd = __expf(ls);
+    const float raw = deterministic ? mean[j] : fmaf(sd, eps[j], mean[j]);
+    const float aj = fminf(fmaxf(raw, -max_action), max_action);
+    const float z = (aj - mean[j]) * __expf(-ls);
+    act[j] = aj;
+    logp[j] = fmaf(-0.5f * z, z, -ls - 0.91893853320467274f);
+  }
+}
+
+// 4 standard normals per Philox block (Box-Muller).  Stream: (noise_seed, global env id, global
+// step, 0x80000000 | block) — the top bit keeps it apart from the reset stream (seed, id, episode, b).
+__device__ __forceinline__ void normal4(float (&z)[4], uint64_t seed, uint64_t gid, uint64_t step, uint32_t block) {
+  uint32_t ctr[4] = {(uint32_t)gid, (uint32_t)(gid >> 32) ^ (uint32_t)(step >> 32), (uint32_t)step, 0x80000000u | block};
+  philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float u1 = fmaf((float)(ctr[2 * h] >> 8), 0x1p-24f, 0x1p-25f);   // (0, 1)
+    const float u2 = fmaf((float)(ctr[2 * h + 1] >> 8), 0x1p-24f, 0x1p-25f);
+    const float r = sqrtf(-2.0f * __logf(u1));
+    float sn, cs;
+    sincos_small(6.283185307179586f * u2, sn, cs);
+    z[2 * h] = r * cs; z[2 * h + 1] = r * sn;
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // The fused step / rollout kernel
 // ------------------------------------------------------------------------------------
 // TRAJ = the goal generator (trajectory_generator.py modes 0/1) is fused into the step; a
 // separate instantiation so that the default path carries none of its registers.  ADAPT = the
 // rate-adaptive substep count (QrCoeffs::w_adapt); launch_kind() picks the plain instantiation
 // whenever adaptivity provably cannot trigger.
-template <int KIND, typename XV, typename QW, int B, bool TRAJ, bool ADAPT>
-__global__ __launch_bounds__(B, (TRAJ ? 1 : QR_WAVES_PER_SIMD))
+// POLICY = qr_rollout_actor: the action of every step comes from the PPO actor(s) evaluated on the
+// env's current observation, which stays in registers from one step to the next.
+template <int KIND, typename XV, typename QW, int B, bool TRAJ, bool ADAPT, bool POLICY = false>
+__global__ __launch_bounds__(B, ((TRAJ || POLICY) ? 1 : QR_WAVES_PER_SIMD))
 void step_kernel(void* pos_vel, void* att_rate, const float* action, float* params, float* integ, int64_t n_envs,
                  int64_t ld_envs, const Args a_in) {
   // The leading scalar arguments duplicate the fields of Args the first loads depend on: as
@@ -821,13 +1006,86 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   };
 #pragma unroll
   for (int j = 0; j < A; ++j) act_next[j] = 0.f;
-  if (active) load_action(0, act_next);
+  if constexpr (!POLICY) {
+    if (active) load_action(0, act_next);
+  }
+  // POLICY: the observation the next action is computed from (rows -> lane registers once, then
+  // carried from step to step)
+  float po0[D0], po1[D1];
+  // agent 0 (23 / 15 -> 16 -> 16 -> 4, args_parse.py:40, main.py:68-73) on the matrix cores, weights
+  // resident in registers; agent 1 of DECOUPLED (3 -> 4 -> 4 -> 1: 32 FMAs) per lane from LDS
+  ActorMfma<D0> actor0;
+  using Actor1 = ActorLds<3, 4, 1>;
+  __shared__ __attribute__((aligned(16))) float wsm[POLICY ? Actor1::SIZE : 4];
+  if constexpr (POLICY) {
+    load_rows<B, D0>(a.obs0_in + first * D0, po0, smem, tid, rows);
+    if constexpr (KT::D1 > 0) load_rows<B, D1>(a.obs1_in + first * D1, po1, smem, tid, rows);
+    actor0.load(a.actor[0], tid);
+    if constexpr (KT::D1 > 0) Actor1::fill(wsm, a.actor[1], tid);
+    __syncthreads();
+  }
 
   for (int t = 0; t < a.n_steps; ++t) {
     float act[A];
+    if constexpr (POLICY) {
+      float mean[A], eps[A], logp[A];
+      // the wave's observation rows -> LDS tile [lane][D0] (B operands of the first layer)
 #pragma unroll
-    for (int j = 0; j < A; ++j) act[j] = act_next[j];
-    if (active && t + 1 < a.n_steps) load_action(t + 1, act_next);
+      for (int j = 0; j < D0; ++j) smem[tid * D0 + j] = po0[j];
+      __syncthreads();
+      if constexpr (KIND == QR_KIND_COUPLED) {
+        actor0.mean(smem, tid, mean);
+      } else {
+        float m0[4], m1[1];
+        actor0.mean(smem, tid, m0);
+        Actor1::mean(wsm, po1, m1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mean[j] = m0[j];
+        mean[A - 1] = m1[0];
+      }
+#pragma unroll
+      for (int j = 0; j < A; ++j) eps[j] = 0.0f;
+      if (!a.deterministic) {
+        if (a.noise != nullptr) {  // injected draws [T][N][A]
+          if (active) {
+            const float* nbase = a.noise + ((int64_t)t * N + first) * A;
+#pragma unroll
+            for (int j = 0; j < A; ++j) eps[j] = nbase[lane * A + j];
+          }
+        } else {
+          float z[4];
+          normal4(z, a.noise_seed, (uint64_t)(a.env_offset + i), a.step_base + (uint64_t)t, 0u);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) eps[j] = z[j];
+          if constexpr (A > 4) {
+            normal4(z, a.noise_seed, (uint64_t)(a.env_offset + i), a.step_base + (uint64_t)t, 1u);
+            eps[A - 1] = z[0];
+          }
+        }
+      }
+      __syncthreads();  // the tile is reused by the row stores below
+      actor_sample<4>(actor0.log_std, *reinterpret_cast<const float(*)[4]>(&mean[0]), &eps[0], a.deterministic != 0, a.max_action, &act[0], &logp[0]);
+      if constexpr (A > 4)
+        actor_sample<1>(wsm + Actor1::O_LS, *reinterpret_cast<const float(*)[1]>(&mean[A - 1]), &eps[A - 1], a.deterministic != 0, a.max_action,
+                        &act[A - 1], &logp[A - 1]);
+      if (active) {
+        const int64_t arow = ((int64_t)t * N + first) * A;
+        if constexpr (A == 4) {
+          reinterpret_cast<float4*>(a.act_out + arow)[lane] = make_float4(act[0], act[1], act[2], act[3]);
+          if (a.logp_out) reinterpret_cast<float4*>(a.logp_out + arow)[lane] = make_float4(logp[0], logp[1], logp[2], logp[3]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < A; ++j) {
+            (a.act_out + arow)[lane * A + j] = act[j];
+            if (a.logp_out) (a.logp_out + arow)[lane * A + j] = logp[j];
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < A; ++j) act[j] = act_next[j];
+      if (active && t + 1 < a.n_steps) load_action(t + 1, act_next);
+    }
 
 #if QR_ABLATE == 2  // measurement build: memory traffic only (no integration)
     w.x[0] += T(act[0]);
@@ -989,6 +1247,12 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       store_rows<B, D0>(a.obs0 + row0 * D0, o0, smem, tid, rows);
     }
     if constexpr (KT::D1 > 0) store_rows<B, D1>(a.obs1 + row0 * D1, o1, smem, tid, rows);
+    if constexpr (POLICY) {
+#pragma unroll
+      for (int j = 0; j < D0; ++j) po0[j] = o0[j];
+#pragma unroll
+      for (int j = 0; j < D1; ++j) po1[j] = o1[j];
+    }
     if (active) {
       if constexpr (NAG == 1) {
         (a.reward + row0)[lane] = rwd[0];
@@ -1300,6 +1564,13 @@ static void launch_kind(const Args& a, hipStream_t s) {
   const bool adapt = a.c.inv_w_adapt > 0 &&
                      (!(a.flags & QR_FLAG_AUTO_RESET) || a.c.inv_w_adapt * a.c.W_lim * 2.5 > 1.0);
 #define QR_STEP_ARGS a.pos_vel, a.att_rate, a.action, a.params, a.integ, a.n, a.ld, a
+  if constexpr (KIND != QR_KIND_QUAD) {
+    if (a.act_out != nullptr) {  // qr_rollout_actor
+      if (a.goal_mode != QR_GOAL_EXTERNAL) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+      else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+      return;
+    }
+  }
   if (a.goal_mode != QR_GOAL_EXTERNAL) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
   else if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
   else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false>), grid, dim3(64), 0, s, QR_STEP_ARGS);
@@ -1350,16 +1621,44 @@ static void launch_get_desired(const Args& a, unsigned grid, hipStream_t s) {
   hipLaunchKernelGGL((get_desired_kernel<XV, QW>), dim3(grid), dim3(64), 0, s, a);
 }
 
-static int do_rollout(const QrEnv* env, const float* action, int32_t n_steps, int32_t substeps, const QrStepOut* out, void* stream) {
+static int fill_actor(ActorW& w, const QrActor& q, int obs_dim, int hidden, int action_dim) {
+  if (q.obs_dim != obs_dim || q.hidden_dim != hidden || q.action_dim != action_dim) return QR_E_SIZE;
+  if (!q.fc1_w || !q.fc1_b || !q.fc2_w || !q.fc2_b || !q.mean_w || !q.mean_b || !q.log_std) return QR_E_NULL;
+  w.fc1_w = q.fc1_w; w.fc1_b = q.fc1_b; w.fc2_w = q.fc2_w; w.fc2_b = q.fc2_b;
+  w.mean_w = q.mean_w; w.mean_b = q.mean_b; w.log_std = q.log_std;
+  return 0;
+}
+
+static int do_rollout(const QrEnv* env, const float* action, const QrPolicyRollout* pol, int32_t n_steps, int32_t substeps,
+                      const QrStepOut* out, void* stream) {
   Args a{};
   if (int rc = fill_env(a, env)) return rc;
-  if (!action || !out || !out->reward || !out->done) return QR_E_NULL;
+  if ((!action && !pol) || !out || !out->reward || !out->done) return QR_E_NULL;
   if (substeps < 1 || n_steps < 1) return QR_E_SIZE;
   if (env->kind != QR_KIND_QUAD && (!env->integ || !out->obs0)) return QR_E_NULL;
   if (env->kind == QR_KIND_DECOUPLED && !out->obs1) return QR_E_NULL;
   if ((env->flags & QR_FLAG_AUTO_RESET) && !env->episode) return QR_E_NULL;
-  // action rows: A = 4 is read with one 16-byte load per lane; A = 5 (DECOUPLED) with dword loads
-  if (reinterpret_cast<uintptr_t>(action) & (env->kind == QR_KIND_DECOUPLED ? 3u : 15u)) return QR_E_ALIGN;
+  if (pol) {
+    if (env->kind == QR_KIND_QUAD) return QR_E_KIND;
+    if (!pol->actors || !pol->obs0_in || !pol->action_out) return QR_E_NULL;
+    if (env->kind == QR_KIND_COUPLED) {
+      if (int rc = fill_actor(a.actor[0], pol->actors[0], 23, 16, 4)) return rc;
+    } else {
+      if (!pol->obs1_in) return QR_E_NULL;
+      if (int rc = fill_actor(a.actor[0], pol->actors[0], 15, 16, 4)) return rc;
+      if (int rc = fill_actor(a.actor[1], pol->actors[1], 3, 4, 1)) return rc;
+    }
+    const uintptr_t amask = env->kind == QR_KIND_DECOUPLED ? 3u : 15u;  // A = 4: one 16-byte store per lane
+    if ((reinterpret_cast<uintptr_t>(pol->action_out) | reinterpret_cast<uintptr_t>(pol->logprob_out)) & amask) return QR_E_ALIGN;
+    if (!(pol->max_action > 0.0f)) return QR_E_SIZE;
+    a.obs0_in = pol->obs0_in; a.obs1_in = pol->obs1_in; a.noise = pol->noise;
+    a.act_out = pol->action_out; a.logp_out = pol->logprob_out;
+    a.noise_seed = pol->noise_seed; a.step_base = pol->step_base;
+    a.max_action = pol->max_action; a.deterministic = pol->deterministic;
+  } else {
+    // action rows: A = 4 is read with one 16-byte load per lane; A = 5 (DECOUPLED) with dword loads
+    if (reinterpret_cast<uintptr_t>(action) & (env->kind == QR_KIND_DECOUPLED ? 3u : 15u)) return QR_E_ALIGN;
+  }
   a.action = action; a.obs0 = out->obs0; a.obs1 = out->obs1;
   a.reward = out->reward; a.reward_raw = out->reward_raw; a.done = out->done; a.truncated = out->truncated;
   a.n_steps = n_steps; a.substeps = substeps;
@@ -1388,11 +1687,17 @@ void qr_default_coeffs(QrCoeffs* c) {
 }
 
 int qr_step(const QrEnv* env, const float* action, int32_t substeps, const QrStepOut* out, void* stream) {
-  return qr::do_rollout(env, action, 1, substeps, out, stream);
+  return qr::do_rollout(env, action, nullptr, 1, substeps, out, stream);
 }
 
 int qr_rollout(const QrEnv* env, const float* action, int32_t n_steps, int32_t substeps, const QrStepOut* out, void* stream) {
-  return qr::do_rollout(env, action, n_steps, substeps, out, stream);
+  return qr::do_rollout(env, action, nullptr, n_steps, substeps, out, stream);
+}
+
+int qr_rollout_actor(const QrEnv* env, const QrPolicyRollout* policy, int32_t n_steps, int32_t substeps, const QrStepOut* out,
+                     void* stream) {
+  if (!policy) return QR_E_NULL;
+  return qr::do_rollout(env, nullptr, policy, n_steps, substeps, out, stream);
 }
 
 int qr_error_obs(const QrEnv* env, float* obs0, float* obs1, void* stream) {

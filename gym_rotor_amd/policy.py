@@ -1,0 +1,85 @@
+"""PPO actor parameters for the policy-in-the-loop rollout (`QuadVecEnv.rollout_actor`).
+
+The network is the reference's `MLP_Actor_PPO` (algos/ppo/ppo_mlp.py:6-58): fc1 -> relu -> fc2 ->
+relu -> mean_linear -> tanh, plus a state-independent `log_std`; sizes are the reference's
+defaults (args_parse.py:40 `actor_hidden_dim=[16, 4]`, obs/action dims of the wrappers).  The
+tensors are used by the kernel in place, in torch.nn.Linear layout — `ActorParams.from_module`
+takes a live module, so an optimiser step is seen by the next rollout without any copy.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Sequence
+
+import torch
+
+from . import _lib
+
+# (obs_dim, hidden_dim, action_dim) per agent: main.py:68-73 + args_parse.py:40
+ACTOR_DIMS = {"coupled": ((23, 16, 4),), "decoupled": ((15, 16, 4), (3, 4, 1))}
+
+
+@dataclass
+class ActorParams:
+    fc1_w: torch.Tensor
+    fc1_b: torch.Tensor
+    fc2_w: torch.Tensor
+    fc2_b: torch.Tensor
+    mean_w: torch.Tensor
+    mean_b: torch.Tensor
+    log_std: torch.Tensor
+
+    NAMES = ("fc1_w", "fc1_b", "fc2_w", "fc2_b", "mean_w", "mean_b", "log_std")
+
+    @property
+    def dims(self):
+        return (self.fc1_w.shape[1], self.fc1_w.shape[0], self.mean_w.shape[0])
+
+    @classmethod
+    def from_module(cls, actor) -> "ActorParams":
+        """From a reference-style actor module (attributes fc1, fc2, mean_linear, log_std)."""
+        return cls(actor.fc1.weight.data, actor.fc1.bias.data, actor.fc2.weight.data, actor.fc2.bias.data,
+                   actor.mean_linear.weight.data, actor.mean_linear.bias.data, actor.log_std.data.reshape(-1))
+
+    @classmethod
+    def random(cls, obs_dim: int, hidden: int, action_dim: int, device, generator=None, log_std: float = 0.0) -> "ActorParams":
+        """Same initial distribution as the reference module: torch.nn.Linear's default
+        U(+-1/sqrt(fan_in)), mean_linear weight x0.1 and bias 0 (ppo_mlp.py:26-28)."""
+        def lin(o, i, wscale=1.0, bscale=1.0):
+            k = i ** -0.5
+            w = (torch.rand(o, i, device=device, generator=generator) * 2 - 1) * k * wscale
+            b = (torch.rand(o, device=device, generator=generator) * 2 - 1) * k * bscale
+            return w, b
+        w1, b1 = lin(hidden, obs_dim)
+        w2, b2 = lin(hidden, hidden)
+        w3, b3 = lin(action_dim, hidden, 0.1, 0.0)
+        return cls(w1, b1, w2, b2, w3, b3, torch.full((action_dim,), float(log_std), device=device))
+
+    def check(self, dims, device):
+        if self.dims != tuple(dims):
+            raise ValueError(f"actor sizes {self.dims} do not match {tuple(dims)} (obs, hidden, action)")
+        shapes = {"fc1_w": (dims[1], dims[0]), "fc1_b": (dims[1],), "fc2_w": (dims[1], dims[1]), "fc2_b": (dims[1],),
+                  "mean_w": (dims[2], dims[1]), "mean_b": (dims[2],), "log_std": (dims[2],)}
+        for n in self.NAMES:
+            t = getattr(self, n)
+            if tuple(t.shape) != shapes[n] or t.dtype != torch.float32 or t.device != device or not t.is_contiguous():
+                raise ValueError(f"actor tensor {n} must be a contiguous float32 {shapes[n]} tensor on {device}")
+
+    def as_c(self) -> _lib.QrActor:
+        q = _lib.QrActor()
+        for n in self.NAMES:
+            setattr(q, n, getattr(self, n).data_ptr())
+        q.obs_dim, q.hidden_dim, q.action_dim = self.dims
+        return q
+
+
+def c_actor_array(actors: Sequence[ActorParams]):
+    arr = (_lib.QrActor * len(actors))()
+    for k, a in enumerate(actors):
+        arr[k] = a.as_c()
+    return arr
+
+
+def random_actors(kind: str, device, generator=None, log_std: float = 0.0) -> List[ActorParams]:
+    return [ActorParams.random(*d, device=device, generator=generator, log_std=log_std) for d in ACTOR_DIMS[kind]]

@@ -40,8 +40,12 @@ class RolloutStorage:
         self.action_dims = list(action_dims)
         T, N = self.T, self.N
         self.obs = [torch.zeros(T + 1, N, d, **f32) for d in env.obs_dims]
-        self.act = [torch.zeros(T, N, a, **f32) for a in self.action_dims]
-        self.logprob = [torch.zeros(T, N, a, **f32) for a in self.action_dims]
+        # agents' actions / log-probs concatenated along the last axis (main.py:161), which is the row
+        # layout qr_rollout_actor writes; act[k] / logprob[k] are per-agent views into them
+        self.act_all = torch.zeros(T, N, env.action_dim, **f32)
+        self.logprob_all = torch.zeros(T, N, env.action_dim, **f32)
+        self.act = list(torch.split(self.act_all, self.action_dims, dim=-1))
+        self.logprob = list(torch.split(self.logprob_all, self.action_dims, dim=-1))
         self.reward = torch.zeros(T, N, self.n_agents, **f32)
         self.done = torch.zeros(T, N, self.n_agents, dtype=torch.bool, device=self.device)
         self.truncated = torch.zeros(T, N, dtype=torch.bool, device=self.device)
@@ -62,6 +66,23 @@ class RolloutStorage:
         if len(self.obs) > 1:
             out["obs1"] = self.obs[1][t + 1]
         return out
+
+    def horizon(self) -> dict:
+        """Output tensors of one whole horizon for `env.rollout_actor(actors, T, out=storage.horizon())`."""
+        out = {"obs0": self.obs[0][1:], "action": self.act_all, "logprob": self.logprob_all, "reward": self.reward,
+               "terminated": self.done, "truncated": self.truncated}
+        if len(self.obs) > 1:
+            out["obs1"] = self.obs[1][1:]
+        return out
+
+    def collect(self, env, actors, **kw) -> dict:
+        """One horizon with the actor(s) inside the step kernel (qr_rollout_actor): obs row 0 is the
+        env's current observation, everything else is written by the single launch."""
+        cur = env._last_obs
+        if cur is None:
+            raise ValueError("no current observation: call env.get_norm_error_state() or env.step() first")
+        self.set_initial_obs(cur)
+        return env.rollout_actor(actors, self.T, obs=[o[0] for o in self.obs], out=self.horizon(), **kw)
 
     def insert(self, t: int, act=None, logprob=None, value=None):
         """Learner-side quantities of step t (actions taken, their log-probs, V(obs[t]))."""

@@ -171,6 +171,8 @@ class QuadVecEnv:
         self._reward = torch.empty(N, self.n_agents, dtype=torch.float32, device=dev)
         self._reward_raw = torch.empty(N, self.n_agents, dtype=torch.float32, device=dev) if want_raw_reward else None
         self._done = torch.zeros(N, self.n_agents, dtype=torch.bool, device=dev)
+        self._last_obs = None    # observation rows the next policy action is computed from (rollout_actor)
+        self._policy_steps = 0   # global step index of the in-kernel action-noise stream
         self._trunc = torch.zeros(N, dtype=torch.bool, device=dev)
 
         # ---- C structs (pointers refreshed lazily) ----
@@ -246,7 +248,8 @@ class QuadVecEnv:
         if out is None:
             rc = self._lib.qr_step(C.byref(self._cenv), a.data_ptr(), self.substeps, C.byref(self._cout), self._stream())
             _lib.check(rc, "qr_step")
-            return self._obs(), self._reward, self._done, self._trunc, {}
+            self._last_obs = self._obs()
+            return self._last_obs, self._reward, self._done, self._trunc, {}
         o = _lib.QrStepOut()
         for k in ("obs0", "obs1", "reward", "terminated", "truncated"):
             t = out.get(k)
@@ -258,6 +261,7 @@ class QuadVecEnv:
         rc = self._lib.qr_step(C.byref(self._cenv), a.data_ptr(), self.substeps, C.byref(o), self._stream())
         _lib.check(rc, "qr_step")
         obs = out.get("obs0") if "obs1" not in out else (out["obs0"], out["obs1"])
+        self._last_obs = obs
         return obs, out["reward"], out["terminated"], out.get("truncated", self._trunc), {}
 
     def rollout(self, actions: torch.Tensor, out: Optional[dict] = None):
@@ -282,6 +286,75 @@ class QuadVecEnv:
         rc = self._lib.qr_rollout(C.byref(self._cenv), a.data_ptr(), T, self.substeps, C.byref(o), self._stream())
         _lib.check(rc, "qr_rollout")
         out["obs"] = out["obs0"] if self._obs1 is None else (out["obs0"], out["obs1"])
+        if out["obs0"] is not None:
+            self._last_obs = out["obs0"][T - 1] if self._obs1 is None else (out["obs0"][T - 1], out["obs1"][T - 1])
+        return out
+
+    def rollout_actor(self, actors, n_steps: int, obs=None, noise: Optional[torch.Tensor] = None,
+                      deterministic: bool = False, max_action: float = 1.0, noise_seed: Optional[int] = None,
+                      out: Optional[dict] = None):
+        """`n_steps` env-steps in ONE launch with the PPO actor(s) inside the loop — the collection
+        loop of main.py:141-166 with PPO.choose_action (ppo.py:82-101): per step every env's
+        actor is evaluated on its current observation, the action sampled (mean + std eps),
+        clamped and stepped.  actors: one `policy.ActorParams` per agent.  obs: the
+        observation(s) the first action is computed from (default: what the last step /
+        get_norm_error_state / rollout_actor returned).  noise: optional [T,N,A] standard normals
+        (default: drawn in the kernel, stream (noise_seed, global env id, global step)).
+        Returns dict(obs0[, obs1], action[T,N,A], logprob[T,N,A], reward, terminated, truncated);
+        obs0[t] is the observation after step t.  out: the same dict with preallocated tensors
+        (e.g. views of a RolloutStorage)."""
+        from . import policy as _policy
+        if self.kind == "quad":
+            raise ValueError("rollout_actor needs kind 'coupled' or 'decoupled' (the reference trains on the wrappers)")
+        if not self.obs_rows:
+            raise ValueError("rollout_actor needs obs_rows=True")
+        actors = list(actors)
+        dims = _policy.ACTOR_DIMS[self.kind]
+        if len(actors) != len(dims):
+            raise ValueError(f"kind {self.kind!r} needs {len(dims)} actor(s)")
+        for a_, d in zip(actors, dims):
+            a_.check(d, self.device)
+        T, N, A, dev = int(n_steps), self.num_envs, self.action_dim, self.device
+        if T < 1:
+            raise ValueError("n_steps must be >= 1")
+        if obs is None:
+            obs = self._last_obs
+            if obs is None:
+                raise ValueError("no current observation: call get_norm_error_state() / step() first or pass obs=")
+        obs = [obs] if isinstance(obs, torch.Tensor) else list(obs)
+        for o_, d in zip(obs, self.obs_dims):
+            if tuple(o_.shape) != (N, d) or o_.dtype != torch.float32 or o_.device != dev or not o_.is_contiguous():
+                raise ValueError(f"obs must be contiguous float32 [{N}, {d}] on {dev}")
+        if noise is not None:
+            if tuple(noise.shape) != (T, N, A) or noise.dtype != torch.float32 or noise.device != dev or not noise.is_contiguous():
+                raise ValueError(f"noise must be contiguous float32 [{T}, {N}, {A}] on {dev}")
+        if out is None:
+            out = {"obs0": torch.empty(T, N, self.obs_dims[0], dtype=torch.float32, device=dev),
+                   "action": torch.empty(T, N, A, dtype=torch.float32, device=dev),
+                   "logprob": torch.empty(T, N, A, dtype=torch.float32, device=dev),
+                   "reward": torch.empty(T, N, self.n_agents, dtype=torch.float32, device=dev),
+                   "terminated": torch.zeros(T, N, self.n_agents, dtype=torch.bool, device=dev),
+                   "truncated": torch.zeros(T, N, dtype=torch.bool, device=dev)}
+            if len(self.obs_dims) > 1:
+                out["obs1"] = torch.empty(T, N, self.obs_dims[1], dtype=torch.float32, device=dev)
+        arr = _policy.c_actor_array(actors)
+        pol = _lib.QrPolicyRollout()
+        pol.actors = arr
+        pol.obs0_in, pol.obs1_in = obs[0].data_ptr(), (obs[1].data_ptr() if len(obs) > 1 else None)
+        pol.noise = _ptr(noise)
+        pol.noise_seed = (self.seed if noise_seed is None else int(noise_seed)) & (2 ** 64 - 1)
+        pol.step_base = self._policy_steps
+        pol.max_action, pol.deterministic = float(max_action), int(bool(deterministic))
+        pol.action_out, pol.logprob_out = out["action"].data_ptr(), _ptr(out.get("logprob"))
+        o = _lib.QrStepOut()
+        o.obs0, o.obs1, o.reward = _ptr(out.get("obs0")), _ptr(out.get("obs1")), _ptr(out["reward"])
+        o.reward_raw, o.done = _ptr(out.get("reward_raw")), _ptr(out["terminated"])
+        o.truncated = _ptr(out["truncated"]) if self._steps is not None else None
+        rc = self._lib.qr_rollout_actor(C.byref(self._cenv), C.byref(pol), T, self.substeps, C.byref(o), self._stream())
+        _lib.check(rc, "qr_rollout_actor")
+        self._policy_steps += T
+        self._last_obs = out["obs0"][T - 1] if len(self.obs_dims) == 1 else (out["obs0"][T - 1], out["obs1"][T - 1])
+        out["obs"] = out["obs0"] if len(self.obs_dims) == 1 else (out["obs0"], out["obs1"])
         return out
 
     def reset(self, env_type: str = "train", seed: Optional[int] = None, options: Optional[dict] = None,
@@ -320,6 +393,7 @@ class QuadVecEnv:
             raise ValueError(f"env kind {self.kind!r} produces {self.framework} observations, not {framework}")
         rc = self._lib.qr_error_obs(C.byref(self._cenv), _ptr(self._obs0), _ptr(self._obs1), self._stream())
         _lib.check(rc, "qr_error_obs")
+        self._last_obs = self._obs()
         return [self._obs0] if self._obs1 is None else [self._obs0, self._obs1]
 
     # ------------------------------------------------------------------------------

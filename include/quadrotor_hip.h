@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define QR_ABI_VERSION 7
+#define QR_ABI_VERSION 8
 
 /* env kinds */
 #define QR_KIND_QUAD      0 /* QuadEnv            gym_rotor/envs/quad.py:19            */
@@ -153,6 +153,48 @@ int qr_step(const QrEnv* env, const float* action, int32_t substeps, const QrSte
  *   per-step strides are the full [N][..] extents).  Same maths as K calls of qr_step. */
 int qr_rollout(const QrEnv* env, const float* action, int32_t n_steps, int32_t substeps,
                const QrStepOut* out, void* stream);
+
+/* One PPO actor, MLP_Actor_PPO (algos/ppo/ppo_mlp.py:6-58): mean = tanh(mean_linear(relu(fc2(
+ * relu(fc1(obs)))))), std = exp(log_std).  Device pointers to float32 tensors in torch.nn.Linear
+ * layout (weight [out][in] row-major), i.e. `actor.fc1.weight.data_ptr()` etc. as they are. */
+typedef struct QrActor {
+  const float* fc1_w;   const float* fc1_b;   /* [hidden][obs_dim], [hidden]        */
+  const float* fc2_w;   const float* fc2_b;   /* [hidden][hidden],  [hidden]        */
+  const float* mean_w;  const float* mean_b;  /* [action_dim][hidden], [action_dim] */
+  const float* log_std;                        /* [action_dim]                       */
+  int32_t obs_dim, hidden_dim, action_dim, reserved0;
+} QrActor;
+
+/* Caller side of a PPO collection loop (main.py:141-166 with PPO.choose_action, ppo.py:82-101)
+ * for qr_rollout_actor. */
+typedef struct QrPolicyRollout {
+  const QrActor* actors;  /* host array, one per agent with the reference's default sizes
+                             (args_parse.py:40): COUPLED 1 actor 23->16->16->4; DECOUPLED 2 actors
+                             15->16->16->4 and 3->4->4->1.  Other sizes: QR_E_SIZE.             */
+  const float* obs0_in;   /* [N][D0] observation the FIRST action is computed from (what the
+                             last step / reset + get_norm_error_state returned)                */
+  const float* obs1_in;   /* [N][3], DECOUPLED only                                            */
+  const float* noise;     /* optional [K][N][A] standard-normal draws eps (action = mean + std
+                             eps: reproduces a given torch sample; tests).  NULL = drawn in the
+                             kernel: Philox4x32-10 keyed by (noise_seed, global env id,
+                             step_base + t) + Box-Muller, independent of the sharding.         */
+  uint64_t noise_seed;
+  uint64_t step_base;     /* global step index of t = 0 (advance by K per call)               */
+  float max_action;       /* clamp (args_parse.py:45: 1.0)                                    */
+  int32_t deterministic;  /* != 0: action = clamp(mean) (is_eval, ppo.py:100-101)             */
+  float* action_out;      /* [K][N][A] actions taken (agents concatenated, main.py:161)       */
+  float* logprob_out;     /* [K][N][A] Normal(mean, std).log_prob(action) per component of the
+                             CLAMPED action (ppo.py:97-98); NULL allowed                      */
+} QrPolicyRollout;
+
+/* K env-steps in ONE launch with the policy inside the loop: per step, each env's actor(s) are
+ * evaluated on its current observation (registers), the action is sampled, clamped and stepped,
+ * and obs / action / logprob / reward / done rows are written as [K][N][..] (what
+ * algos/replay_buffer.py:20-39 stores per step).  `out` as in qr_rollout (obs rows required):
+ * out->obs0[t] is the observation AFTER step t, i.e. the input of step t+1.  COUPLED and
+ * DECOUPLED only (the reference trains on the wrappers). */
+int qr_rollout_actor(const QrEnv* env, const QrPolicyRollout* policy, int32_t n_steps, int32_t substeps,
+                     const QrStepOut* out, void* stream);
 
 /* Replaces QuadEnv.get_norm_error_state(framework) (quad.py:421-466): normalised error
  * observation of the CURRENT state; advances both trapezoid integrators (same side

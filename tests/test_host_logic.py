@@ -76,8 +76,7 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_structs_mirror_the_header(tmp_path):
     """Compile a C program against include/quadrotor_hip.h and compare sizeof/offsetof."""
     L = _lib()
-    fields = {"QrEnv": [f[0] for f in L.QrEnv._fields_], "QrStepOut": [f[0] for f in L.QrStepOut._fields_],
-              "QrCoeffs": [f[0] for f in L.QrCoeffs._fields_]}
+    fields = {n: [f[0] for f in getattr(L, n)._fields_] for n in ("QrEnv", "QrStepOut", "QrCoeffs", "QrActor", "QrPolicyRollout")}
     lines = []
     for sname, fl in fields.items():
         lines.append(f'printf("{sname} %zu\\n", sizeof({sname}));')
@@ -133,6 +132,29 @@ def test_abi_argument_errors_without_gpu():
     assert lib.qr_step(C.byref(e2), 0x3000, 1, C.byref(o2), None) == -3      # stride < N
     e2.field_stride, e2.goal_mode = 0, 2
     assert lib.qr_step(C.byref(e2), 0x3000, 1, C.byref(o2), None) == -1      # fused goals without traj buffer
+    # qr_rollout_actor: argument checks before any launch
+    e3, o3, pol = L.QrEnv(), L.QrStepOut(), L.QrPolicyRollout()
+    e3.kind, e3.num_envs, e3.pos_vel, e3.att_rate, e3.integ = 0, 64, 0x1000, 0x2000, 0x7000
+    o3.reward, o3.done, o3.obs0, o3.obs1 = 0x4000, 0x5000, 0x8000, 0x9000
+    assert lib.qr_rollout_actor(C.byref(e3), None, 1, 1, C.byref(o3), None) == -1
+    assert lib.qr_rollout_actor(C.byref(e3), C.byref(pol), 1, 1, C.byref(o3), None) == -2     # Quad-v0 has no actor
+    e3.kind = 1
+    assert lib.qr_rollout_actor(C.byref(e3), C.byref(pol), 1, 1, C.byref(o3), None) == -1     # no actors / obs / outputs
+    acts = (L.QrActor * 2)()
+    pol.actors, pol.obs0_in, pol.obs1_in, pol.action_out, pol.max_action = acts, 0xa000, 0xb000, 0xc000, 1.0
+    assert lib.qr_rollout_actor(C.byref(e3), C.byref(pol), 1, 1, C.byref(o3), None) == -3     # sizes are not 23 -> 16 -> 4
+    acts[0].obs_dim, acts[0].hidden_dim, acts[0].action_dim = 23, 16, 4
+    assert lib.qr_rollout_actor(C.byref(e3), C.byref(pol), 1, 1, C.byref(o3), None) == -1     # weight pointers missing
+    for n in ("fc1_w", "fc1_b", "fc2_w", "fc2_b", "mean_w", "mean_b", "log_std"):
+        setattr(acts[0], n, 0xd000); setattr(acts[1], n, 0xd000)
+    pol.action_out = 0xc004
+    assert lib.qr_rollout_actor(C.byref(e3), C.byref(pol), 1, 1, C.byref(o3), None) == -4     # action rows misaligned
+    pol.action_out, pol.max_action = 0xc000, 0.0
+    assert lib.qr_rollout_actor(C.byref(e3), C.byref(pol), 1, 1, C.byref(o3), None) == -3     # max_action <= 0
+    pol.max_action = 1.0
+    assert lib.qr_rollout_actor(C.byref(e3), C.byref(pol), 0, 1, C.byref(o3), None) == -3     # n_steps < 1
+    e3.kind = 2
+    assert lib.qr_rollout_actor(C.byref(e3), C.byref(pol), 1, 1, C.byref(o3), None) == -3     # decoupled wants 15->16->4, 3->4->1
     with pytest.raises(ValueError):
         L.check(-3, "x")
     with pytest.raises(L.QuadrotorLibError):

@@ -170,3 +170,59 @@ def test_reset_sampler_distribution():
     p = orc.sample_params(rng, 20000)
     assert (np.abs(p / orc.NOMINAL_PARAMS - 1) <= np.array([.1, .1, .1, .1, .1, .05]) + 1e-12).all()
     assert np.array_equal(orc.sample_params(rng, 3, "eval"), np.tile(orc.NOMINAL_PARAMS, (3, 1)))
+
+
+# ---------------------------------------------------------------------------------------
+# PPO actor (caller side of the collection loop fused by qr_rollout_actor)
+# ---------------------------------------------------------------------------------------
+ACTOR_TAGS = {"coupled": ["coupled0"], "decoupled": ["decoupled0", "decoupled1"]}
+ACTOR_FIELDS = ("fc1_w", "fc1_b", "fc2_w", "fc2_b", "mean_w", "mean_b", "log_std")
+
+
+@pytest.mark.parametrize("tag", ["coupled0", "decoupled0", "decoupled1"])
+def test_actor_oracle_vs_reference_module(golden, tag):
+    """oracle/actor_oracle.py against the reference's MLP_Actor_PPO + Normal (torch float32)."""
+    from oracle import actor_oracle as ao
+    d = golden("actor_ppo")
+    p = {n: d[f"{tag}_{n}"] for n in ACTOR_FIELDS}
+    action, logprob, mean = ao.choose_action(p, d[f"{tag}_obs"], d[f"{tag}_eps"])
+    assert np.abs(mean - d[f"{tag}_mean"]).max() <= 5e-7
+    assert np.abs(action - d[f"{tag}_action"]).max() <= 5e-7
+    assert (np.abs(action) == 1.0).sum() == (np.abs(d[f"{tag}_action"]) == 1.0).sum() > 0   # the clamp is exercised
+    assert np.abs(logprob - d[f"{tag}_logprob"]).max() <= 2e-5   # (a - mean)^2 / (2 std^2) in float32, |z| up to 16
+    det, none, _ = ao.choose_action(p, d[f"{tag}_obs"], None)
+    assert none is None and np.abs(det - np.clip(d[f"{tag}_mean"], -1, 1)).max() <= 5e-7
+
+
+@pytest.mark.parametrize("kind", ["coupled", "decoupled"])
+def test_actor_loop_oracle_vs_reference(golden, kind):
+    """Closed loop: oracle env + oracle actor against the reference env stepped by the reference's
+    actor modules (main.py:141-166), 4 envs x 200 steps, injected action noise."""
+    from oracle import actor_oracle as ao
+    d = golden(f"actorloop_{kind}")
+    nag = orc.N_AGENTS[kind]
+    actors = [{n: d[f"actor{k}_{n}"] for n in ACTOR_FIELDS} for k in range(nag)]
+    adims = [a["mean_w"].shape[0] for a in actors]
+    T, n = d["eps"].shape[:2]
+    s, integ = d["init_state"].copy(), np.zeros((n, 8))
+    o = orc.error_obs_batch(kind, s, d["goal"], integ)
+    obs, integ = o["obs"], o["integ"]
+    worst = {"obs": 0.0, "act": 0.0, "logp": 0.0, "rwd": 0.0, "state": 0.0}
+    for t in range(T):
+        col, act, logp = 0, [], []
+        for k in range(nag):
+            worst["obs"] = max(worst["obs"], np.abs(np.asarray(obs[k], np.float64) - d[f"obs{k}"][t]).max())
+            a_, l_, _ = ao.choose_action(actors[k], np.asarray(obs[k], np.float32), d["eps"][t, :, col:col + adims[k]])
+            act.append(a_); logp.append(l_); col += adims[k]
+        act, logp = np.concatenate(act, -1), np.concatenate(logp, -1)
+        worst["act"] = max(worst["act"], np.abs(act - d["actions"][t]).max())
+        worst["logp"] = max(worst["logp"], np.abs(logp - d["logprobs"][t]).max())
+        # feed the REFERENCE's float32 action (what its env saw) so that the env parity is not
+        # polluted by float32-vs-float64 actor rounding
+        o = orc.step_batch(kind, s, d["actions"][t].astype(np.float64), d["params"], d["goal"], integ)
+        s, integ, obs = o["state"], o["integ"], o["obs"]
+        worst["rwd"] = max(worst["rwd"], np.abs(o["reward"] - d["rewards"][t]).max())
+        worst["state"] = max(worst["state"], np.abs(s - d["states"][t + 1]).max())
+        assert np.array_equal(o["done"], d["dones"][t])
+    assert worst["state"] <= 1e-9 and worst["obs"] <= 1e-6 and worst["rwd"] <= 1e-6, worst
+    assert worst["act"] <= 2e-6 and worst["logp"] <= 5e-5, worst

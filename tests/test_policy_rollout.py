@@ -1,0 +1,206 @@
+"""qr_rollout_actor: the PPO collection loop (env + actor) in one launch, against the reference's
+own actor modules and env (tests/golden/actor_ppo.npz, actorloop_*.npz) and against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import grouped_rel_err
+from oracle import actor_oracle as ao
+from oracle import quad_oracle as orc
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("fc1_w", "fc1_b", "fc2_w", "fc2_b", "mean_w", "mean_b", "log_std")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _env(kind, n, **kw):
+    from gym_rotor_amd import QuadVecEnv
+    return QuadVecEnv(kind, n, device="cuda", obs_rows=True, **kw)
+
+
+def _actor(d, prefix):
+    from gym_rotor_amd import ActorParams
+    return ActorParams(*[torch.from_numpy(np.ascontiguousarray(d[f"{prefix}_{n}"], dtype=np.float32)).cuda() for n in FIELDS])
+
+
+def _round_trip(env, state):
+    env.set_state(state)
+    return _np(env.get_current_state())
+
+
+@pytest.mark.parametrize("kind", ["coupled", "decoupled"])
+def test_actor_in_kernel_vs_reference_module(golden, kind):
+    """One policy step on the reference's recorded (obs, eps): the in-kernel MLP, sampling, clamp
+    and log-prob against torch's MLP_Actor_PPO / Normal (float32), 256 rows per agent."""
+    d = golden("actor_ppo")
+    tags = [f"{kind}0"] if kind == "coupled" else [f"{kind}0", f"{kind}1"]
+    n = d[f"{tags[0]}_obs"].shape[0]
+    env = _env(kind, n)
+    env.reset("train")
+    actors = [_actor(d, t) for t in tags]
+    obs = [torch.from_numpy(d[f"{t}_obs"]).cuda() for t in tags]
+    eps = torch.from_numpy(np.concatenate([d[f"{t}_eps"] for t in tags], 1)[None].copy()).cuda()
+    out = env.rollout_actor(actors, 1, obs=obs, noise=eps)
+    act, logp = _np(out["action"][0]), _np(out["logprob"][0])
+    want_a = np.concatenate([d[f"{t}_action"] for t in tags], 1)
+    want_l = np.concatenate([d[f"{t}_logprob"] for t in tags], 1)
+    assert np.abs(act - want_a).max() <= 1e-6
+    assert np.array_equal(np.abs(act) == 1.0, np.abs(want_a) == 1.0)
+    assert np.abs(logp - want_l).max() <= 5e-5      # (a - mean)^2 / (2 std^2) with |z| up to 16 in float32
+    det = env.rollout_actor(actors, 1, obs=obs, deterministic=True)
+    want_m = np.clip(np.concatenate([d[f"{t}_mean"] for t in tags], 1), -1, 1)
+    assert np.abs(_np(det["action"][0]) - want_m).max() <= 1e-6
+    ls = np.concatenate([d[f"{t}_log_std"] for t in tags])
+    assert np.abs(_np(det["logprob"][0]) - (-ls - ao.LOG_SQRT_2PI)).max() <= 1e-6
+
+
+@pytest.mark.parametrize("kind", ["coupled", "decoupled"])
+def test_closed_loop_vs_reference_env_and_actor(golden, kind):
+    """The whole loop against the reference: its wrapper env stepped by its actor modules for 200
+    steps (4 envs, injected noise), reproduced by ONE qr_rollout_actor launch."""
+    d = golden(f"actorloop_{kind}")
+    nag = orc.N_AGENTS[kind]
+    T, n = d["eps"].shape[:2]
+    env = _env(kind, n, layout="f64", want_raw_reward=False)
+    env.set_state(d["init_state"], integ=np.zeros((n, 8)), params=d["params"])
+    env.get_norm_error_state()
+    actors = [_actor(d, f"actor{k}") for k in range(nag)]
+    out = env.rollout_actor(actors, T, noise=torch.from_numpy(d["eps"]).cuda())
+    obs = [out["obs0"]] if nag == 1 else [out["obs0"], out["obs1"]]
+    for k in range(nag):
+        assert np.abs(_np(obs[k]) - d[f"obs{k}"][1:]).max() <= 2e-5   # |ex| reaches 5 (free run): 5e-7 x magnitude
+    assert np.abs(_np(out["action"]) - d["actions"]).max() <= 2e-6
+    assert np.abs(_np(out["logprob"]) - d["logprobs"]).max() <= 5e-5
+    assert np.abs(_np(out["reward"]) - d["rewards"]).max() <= 1e-5
+    assert np.array_equal(_np(out["terminated"]), d["dones"])
+    assert grouped_rel_err(_np(env.get_current_state()), d["states"][T]) <= 1e-6
+
+
+@pytest.mark.parametrize("kind", ["coupled", "decoupled"])
+def test_closed_loop_vs_oracle_1000_envs(kind):
+    """1000 envs x 64 steps, random actors, injected noise: GPU loop vs oracle env + oracle actor."""
+    from gym_rotor_amd import random_actors
+    n, T = 1000, 64
+    rng = np.random.default_rng(31 + len(kind))
+    env = _env(kind, n, layout="f64")
+    state = _round_trip(env, orc.sample_reset_state(rng, n).astype(np.float32).astype(np.float64))
+    params = orc.sample_params(rng, n).astype(np.float32).astype(np.float64)
+    env.set_state(state, integ=np.zeros((n, 8)), params=params)
+    env.get_norm_error_state()
+    gen = torch.Generator("cuda").manual_seed(5)
+    actors = random_actors(kind, "cuda", generator=gen, log_std=-1.0)
+    for a in actors:
+        a.mean_w.mul_(10.0)
+    A = env.action_dim
+    eps = rng.standard_normal((T, n, A)).astype(np.float32)
+    out = env.rollout_actor(actors, T, noise=torch.from_numpy(eps).cuda())
+    pw = [{f: _np(getattr(a, f)).astype(np.float64) for f in FIELDS} for a in actors]
+    adims = [p["mean_w"].shape[0] for p in pw]
+    o = orc.error_obs_batch(kind, state, None, np.zeros((n, 8)))
+    s, integ, obs = state, o["integ"], o["obs"]
+    worst_a = 0.0
+    for t in range(T):
+        col, acts = 0, []
+        for k, p in enumerate(pw):
+            a_, _, _ = ao.choose_action(p, obs[k], eps[t, :, col:col + adims[k]])
+            acts.append(a_); col += adims[k]
+        act = np.concatenate(acts, 1).astype(np.float32)
+        worst_a = max(worst_a, np.abs(act - _np(out["action"][t])).max())
+        o = orc.step_batch(kind, s, act.astype(np.float64), params, None, integ)
+        s, integ, obs = o["state"], o["integ"], o["obs"]
+    assert worst_a <= 2e-5                                           # closed loop: actor rounding feeds back
+    assert grouped_rel_err(_np(env.get_current_state()), s) <= 2e-6
+    assert np.abs(_np(out["obs0"][T - 1]) - obs[0]).max() <= 2e-5
+
+
+def test_in_kernel_noise_statistics_and_streams():
+    """Philox + Box-Muller action noise: standard normal, independent across envs / steps /
+    components, reproducible, independent of sharding and of how a horizon is split into calls."""
+    from gym_rotor_amd import random_actors
+    n, T = 4096, 32
+    actors = random_actors("decoupled", "cuda", generator=torch.Generator("cuda").manual_seed(1), log_std=0.0)
+    for a in actors:
+        a.mean_w.zero_(); a.mean_b.zero_()       # mean = 0, std = 1: the unclamped action IS the noise
+
+    def run(n_envs, offset=0, splits=(T,), seed=3):
+        env = _env("decoupled", n_envs, seed=seed, env_offset=offset)
+        env.reset("train")
+        env.get_norm_error_state()
+        acts = [env.rollout_actor(actors, k, max_action=1e6)["action"] for k in splits]
+        return _np(torch.cat(acts, 0))
+
+    z = run(n)
+    assert z.shape == (T, n, 5)
+    assert abs(z.mean()) < 4 / np.sqrt(z.size) and abs(z.var() - 1) < 6 * np.sqrt(2 / z.size)
+    assert abs((z ** 3).mean()) < 0.02 and abs((z ** 4).mean() - 3) < 0.06
+    assert np.abs(z).max() < 6.5
+    c = np.corrcoef(np.stack([z[:-1, :, 0].ravel(), z[1:, :, 0].ravel(), z[:-1, :, 1].ravel(), z[:-1, :, 4].ravel(),
+                              np.roll(z[:-1, :, 0], 1, axis=1).ravel()]))
+    assert np.abs(c - np.eye(5)).max() < 0.02
+    assert np.array_equal(z, run(n))                                   # reproducible
+    assert not np.array_equal(z, run(n, seed=4))                       # seeded
+    assert np.array_equal(z[:, 1000:1600], run(600, offset=1000))      # a shard draws its global envs' numbers
+    assert np.array_equal(z, run(n, splits=(8, 24)))                   # step_base advances across calls
+
+
+def test_policy_rollout_with_auto_reset_and_storage():
+    """PPO-shaped use: auto-reset on, rows written straight into a RolloutStorage horizon; the
+    rollout equals the same loop driven from the host (torch actor + env.step) bit-for-bit in the
+    env outputs given the same actions."""
+    from gym_rotor_amd import random_actors
+    n, T = 2048, 96
+    actors = random_actors("coupled", "cuda", generator=torch.Generator("cuda").manual_seed(2), log_std=-0.5)
+    from gym_rotor_amd import RolloutStorage
+    env = _env("coupled", n, seed=11, auto_reset=True)
+    env.reset("train")
+    first_obs = env.get_norm_error_state()[0].clone()
+    st = RolloutStorage(env, T)
+    out = st.collect(env, actors)
+    assert out["obs0"].data_ptr() == st.obs[0][1].data_ptr() and out["action"].data_ptr() == st.act[0].data_ptr()
+    assert torch.equal(st.obs[0][0], first_obs)
+    assert torch.isfinite(out["obs0"]).all() and torch.isfinite(out["logprob"]).all()
+    assert (out["action"].abs() <= 1).all()
+    done = out["terminated"][..., 0]
+    assert 2e-4 < done.float().mean() < 0.2          # episodes end and restart inside the launch
+    assert (out["reward"][..., 0][done] == -1).all()
+    # replay the recorded actions through qr_rollout on a twin env: identical env outputs
+    twin = _env("coupled", n, seed=11, auto_reset=True)
+    twin.reset("train")
+    twin.get_norm_error_state()
+    ro = twin.rollout(out["action"])
+    for k in ("obs0", "reward", "terminated"):
+        assert torch.equal(ro[k], out[k]), k
+    assert torch.equal(twin.get_current_state(), env.get_current_state())
+    # the actor saw obs[t-1]: recompute the means with torch from the stored observations
+    a = actors[0]
+    x = st.obs[0][:-1]
+    h = torch.relu(x @ a.fc1_w.T + a.fc1_b); h = torch.relu(h @ a.fc2_w.T + a.fc2_b)
+    mean = torch.tanh(h @ a.mean_w.T + a.mean_b)
+    z = (out["action"] - mean) / a.log_std.exp()
+    inside = out["action"].abs() < 1
+    lp = -0.5 * z * z - a.log_std - ao.LOG_SQRT_2PI
+    assert (lp - out["logprob"])[inside].abs().max() <= 2e-4
+    assert abs(float(z[inside].mean())) < 0.01          # (the variance is that of a normal truncated by the clamp)
+
+
+def test_rollout_actor_api_errors():
+    from gym_rotor_amd import QuadVecEnv, random_actors
+    env = _env("coupled", 64)
+    env.reset("train")
+    actors = random_actors("coupled", "cuda")
+    with pytest.raises(ValueError):
+        env.rollout_actor(actors, 4)                                   # no current observation yet
+    env.get_norm_error_state()
+    with pytest.raises(ValueError):
+        env.rollout_actor(random_actors("decoupled", "cuda"), 4)       # wrong number / sizes of actors
+    with pytest.raises(ValueError):
+        env.rollout_actor(actors, 0)
+    with pytest.raises(ValueError):
+        env.rollout_actor(actors, 4, noise=torch.zeros(4, 64, 5, device="cuda"))
+    with pytest.raises(ValueError):
+        QuadVecEnv("quad", 64, device="cuda", obs_rows=True).rollout_actor(actors, 4)
+    out = env.rollout_actor(actors, 4)
+    assert out["action"].shape == (4, 64, 4) and out["obs0"].shape == (4, 64, 23)

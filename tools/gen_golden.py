@@ -19,6 +19,8 @@ Files written (see tests/golden/README.md for the field lists):
   flightlog_modul.npz      all 3600 rows of results/MODUL_log_20250303_120200.dat
   gae.npz                  the reference's own GAE + normalisation lines (ppo.py:134-147) on synthetic data
   trajgoal_m{0,1,6}_{kind}.npz  closed loop env + TrajectoryGenerator (modes 0/1/6) as main.py drives them
+  actor_ppo.npz            the reference's MLP_Actor_PPO (torch): weights, obs -> mean, injected-noise action, log_prob
+  actorloop_{kind}.npz     closed loop: reference wrapper env stepped by the reference's actor(s), 4 envs x 200 steps
 """
 import os
 import sys
@@ -33,6 +35,7 @@ sys.path.insert(0, os.path.join(HERE, "_gymnasium_shim"))
 sys.path.insert(0, REF)
 sys.path.insert(0, REPO)
 
+ARGV = sys.argv[1:]
 sys.argv = ["gen_golden"]
 import gym_rotor.envs.quad as refquad  # noqa: E402
 from gym_rotor.envs import quad_utils as refutils  # noqa: E402
@@ -437,6 +440,109 @@ def gen_gae(T=64, M=48, seed=0):
     print("gae golden written")
 
 
+ACTOR_DIMS = {"coupled": [(23, 16, 4)], "decoupled": [(15, 16, 4), (3, 4, 1)]}  # main.py:68-73, args_parse.py:40
+
+
+def make_actors(kind, seed):
+    """The reference's own actor modules (algos/ppo/ppo_mlp.py), default init, then log_std and the
+    mean bias moved off their zero defaults so that every term is exercised."""
+    import types
+    import torch
+    from algos.ppo.ppo_mlp import MLP_Actor_PPO
+    dims = ACTOR_DIMS[kind]
+    args = types.SimpleNamespace(obs_dim_n=[d[0] for d in dims], actor_hidden_dim=[d[1] for d in dims],
+                                 action_dim_n=[d[2] for d in dims])
+    torch.manual_seed(seed)
+    actors = []
+    for k in range(len(dims)):
+        a = MLP_Actor_PPO(args, k)
+        with torch.no_grad():
+            a.log_std.copy_(torch.linspace(-1.6, -0.9, dims[k][2]).reshape(1, -1))
+            a.mean_linear.bias.uniform_(-0.2, 0.2)
+            a.mean_linear.weight.mul_(8.0)  # default x0.1 keeps tanh in its linear part; reach |mean| ~ 0.8 too
+        actors.append(a)
+    return actors
+
+
+def actor_weights(a):
+    return {"fc1_w": a.fc1.weight, "fc1_b": a.fc1.bias, "fc2_w": a.fc2.weight, "fc2_b": a.fc2.bias,
+            "mean_w": a.mean_linear.weight, "mean_b": a.mean_linear.bias, "log_std": a.log_std.reshape(-1)}
+
+
+def ref_choose_action(actor, obs, eps, max_action=1.0):
+    """PPO.choose_action (ppo.py:93-99) with the noise made explicit: Normal.sample() is
+    mean + std * eps; everything else is the reference's module."""
+    import torch
+    with torch.no_grad():
+        dist = actor.get_dist(torch.as_tensor(obs, dtype=torch.float32))
+        action = torch.clamp(dist.mean + dist.stddev * torch.as_tensor(eps, dtype=torch.float32), -max_action, max_action)
+        return action.numpy(), dist.log_prob(action).numpy(), dist.mean.numpy()
+
+
+def gen_actor(seed=0, n=256):
+    rng = np.random.default_rng(6000 + seed)
+    out = {}
+    for kind in ("coupled", "decoupled"):
+        for k, a in enumerate(make_actors(kind, 100 + seed)):
+            D, H, A = ACTOR_DIMS[kind][k]
+            obs = rng.uniform(-1.5, 1.5, (n, D)).astype(np.float32)
+            eps = rng.standard_normal((n, A)).astype(np.float32)
+            eps[: n // 8] *= 4.0  # push some samples into the clamp
+            action, logprob, mean = ref_choose_action(a, obs, eps)
+            tag = f"{kind}{k}"
+            for name, w in actor_weights(a).items():
+                out[f"{tag}_{name}"] = w.detach().numpy().copy()
+            out.update({f"{tag}_obs": obs, f"{tag}_eps": eps, f"{tag}_mean": mean, f"{tag}_action": action, f"{tag}_logprob": logprob})
+            print(f"actor {tag}: |mean| max {np.abs(mean).max():.3f}, clamped {np.mean(np.abs(action) == 1.0):.3f}")
+    np.savez_compressed(os.path.join(OUT, "actor_ppo.npz"), **out)
+
+
+def gen_actorloop(kind, n_env=4, T=200, seed=0):
+    """The collection loop of main.py:141-166 with the reference's env AND the reference's actor(s):
+    obs_t -> choose_action (injected noise) -> concatenate -> env.step -> obs_{t+1}.  Free run."""
+    rng = np.random.default_rng(7000 + seed + 13 * orc.KINDS.index(kind))
+    dims = ACTOR_DIMS[kind]
+    A = sum(d[2] for d in dims)
+    nag = len(dims)
+    actors = make_actors(kind, 200 + seed)
+    params = f32r(random_params(rng, n_env)); params[0] = orc.NOMINAL_PARAMS
+    params = f32r(params)
+    goal = np.tile(orc.DEFAULT_GOAL, (n_env, 1))
+    init = state_in(orc.sample_reset_state(rng, n_env, "train"))
+    eps = rng.standard_normal((T, n_env, A)).astype(np.float32)
+    states = np.zeros((T + 1, n_env, 18)); integs = np.zeros((T + 1, n_env, 8))
+    obs_out = [np.zeros((T + 1, n_env, d[0]), np.float32) for d in dims]
+    actions = np.zeros((T, n_env, A), np.float32); logprobs = np.zeros((T, n_env, A), np.float32)
+    rewards = np.zeros((T, n_env, nag)); dones = np.zeros((T, n_env, nag), bool)
+    for e in range(n_env):
+        env = make_env(kind)
+        inject_params(env, params[e])
+        inject(env, init[e], goal[e], np.zeros(8))
+        obs = env.get_norm_error_state(env.framework)  # first obs after reset (main.py:129)
+        for t in range(T):
+            states[t, e], integs[t, e] = env.state, read_integ(env)
+            col = 0
+            for k, a in enumerate(actors):
+                obs_out[k][t, e] = obs[k]
+                act, lp, _ = ref_choose_action(a, np.asarray(obs[k])[None], eps[t, e, col:col + dims[k][2]][None])
+                actions[t, e, col:col + dims[k][2]], logprobs[t, e, col:col + dims[k][2]] = act[0], lp[0]
+                col += dims[k][2]
+            _, _, _, obs, _, rwd, done = ref_step(env, kind, actions[t, e].astype(np.float64))
+            rewards[t, e], dones[t, e] = rwd, done
+        states[T, e], integs[T, e] = env.state, read_integ(env)
+        for k in range(nag):
+            obs_out[k][T, e] = obs[k]
+    out = dict(params=params, goal=goal, init_state=init, eps=eps, states=states, integs=integs, actions=actions,
+               logprobs=logprobs, rewards=rewards, dones=dones)
+    for k, a in enumerate(actors):
+        out[f"obs{k}"] = obs_out[k]
+        for name, w in actor_weights(a).items():
+            out[f"actor{k}_{name}"] = w.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, f"actorloop_{kind}.npz"), **out)
+    print(f"actorloop_{kind}: first done at {[int(np.argmax(dones[:, e].any(-1))) if dones[:, e].any() else -1 for e in range(n_env)]}, "
+          f"max|x| {np.abs(states[..., 0:3]).max():.2f}, |action| mean {np.abs(actions).mean():.3f}")
+
+
 def gen_flightlog(rows=3600):
     log = np.loadtxt(os.path.join(REF, "results", "MODUL_log_20250303_120200.dat"))
     np.savez_compressed(os.path.join(OUT, "flightlog_modul.npz"), log=log[:rows])
@@ -445,6 +551,11 @@ def gen_flightlog(rows=3600):
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if ARGV[:1] == ["actor"]:  # only the actor files
+        gen_actor()
+        for kind in ("coupled", "decoupled"):
+            gen_actorloop(kind)
+        sys.exit(0)
     for kind in ("coupled", "decoupled"):
         check_step_template(kind)
     gen_kats()
@@ -458,3 +569,6 @@ if __name__ == "__main__":
     for kind in ("coupled", "decoupled"):
         for mode in (0, 1, 6):
             gen_trajgoal(kind, mode)
+    gen_actor()
+    for kind in ("coupled", "decoupled"):
+        gen_actorloop(kind)
