@@ -1,0 +1,265 @@
+// qr_dynamics.h — part of the gfx950 quadrotor step library (included by quadrotor_kernels.hip, in this order).
+// Attitude helpers, quaternion-form dynamics + RK4, LDS row transposes, action maps, error observations.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "quadrotor_hip.h"
+#include "qr_rng.h"
+
+namespace qr {
+
+// ------------------------------------------------------------------------------------
+// Attitude helpers
+// ------------------------------------------------------------------------------------
+// R(q), column-major like the reference's vec_F(R): R[3c + r].
+template <typename T>
+__device__ __forceinline__ void quat_to_R(const T* q, T (&R)[9]) {
+  const T w = q[0], x = q[1], y = q[2], z = q[3];
+  const T xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+  R[0] = T(1) - T(2) * (yy + zz); R[1] = T(2) * (xy + wz);        R[2] = T(2) * (xz - wy);
+  R[3] = T(2) * (xy - wz);        R[4] = T(1) - T(2) * (xx + zz); R[5] = T(2) * (yz + wx);
+  R[6] = T(2) * (xz + wy);        R[7] = T(2) * (yz - wx);        R[8] = T(1) - T(2) * (xx + yy);
+}
+
+// ensure_SO3 (quad_utils.py:123-142) + attitude import.  The reference replaces R by the
+// nearest rotation U V^T (SVD) when R^T R or det R is off by more than 1e-5; since the
+// internal attitude is a unit quaternion, the nearest rotation is taken always (for an R
+// that is orthonormal to round-off this changes nothing).  The polar factor is computed by
+// the Newton iteration X <- (X + X^-T)/2, which converges quadratically to U V^T (det R > 0).
+__device__ void R_to_quat(const double* Rin, double (&q)[4]) {
+  double X[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) X[i] = Rin[i];
+  for (int it = 0; it < 40; ++it) {
+    double C[9];  // C = cof(X), column-major like X; X^-T = C / det X
+    C[0] = X[4] * X[8] - X[5] * X[7]; C[1] = X[5] * X[6] - X[3] * X[8]; C[2] = X[3] * X[7] - X[4] * X[6];
+    C[3] = X[2] * X[7] - X[1] * X[8]; C[4] = X[0] * X[8] - X[2] * X[6]; C[5] = X[1] * X[6] - X[0] * X[7];
+    C[6] = X[1] * X[5] - X[2] * X[4]; C[7] = X[2] * X[3] - X[0] * X[5]; C[8] = X[0] * X[4] - X[1] * X[3];
+    const double dd = X[0] * C[0] + X[1] * C[1] + X[2] * C[2];
+    if (!(fabs(dd) > 1e-300)) break;
+    const double inv = 1.0 / dd;
+    double delta = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const double xn = 0.5 * (X[i] + C[i] * inv);
+      delta = fmax(delta, fabs(xn - X[i]));
+      X[i] = xn;
+    }
+    if (delta < 4e-16) break;
+  }
+  // Shepperd's method on the (now orthonormal) X; X[3c + r] = R(r, c)
+  const double r00 = X[0], r11 = X[4], r22 = X[8];
+  const double tr = r00 + r11 + r22;
+  double w, x, y, z;
+  if (tr >= r00 && tr >= r11 && tr >= r22) {
+    w = 1.0 + tr; x = X[5] - X[7]; y = X[6] - X[2]; z = X[1] - X[3];
+  } else if (r00 >= r11 && r00 >= r22) {
+    w = X[5] - X[7]; x = 1.0 + r00 - r11 - r22; y = X[3] + X[1]; z = X[6] + X[2];
+  } else if (r11 >= r22) {
+    w = X[6] - X[2]; x = X[3] + X[1]; y = 1.0 - r00 + r11 - r22; z = X[7] + X[5];
+  } else {
+    w = X[1] - X[3]; x = X[6] + X[2]; y = X[7] + X[5]; z = 1.0 - r00 - r11 + r22;
+  }
+  const double inv = 1.0 / sqrt(w * w + x * x + y * y + z * z);
+  q[0] = w * inv; q[1] = x * inv; q[2] = y * inv; q[3] = z * inv;
+}
+
+// ------------------------------------------------------------------------------------
+// Dynamics (quad.py:321-335) in quaternion form.
+// ------------------------------------------------------------------------------------
+template <typename T>
+struct Dyn {
+  T c;           // f/m
+  T A1;          // (J2-J3)/J1 with J2 = J1; the W2' coefficient (J3-J1)/J2 is -A1
+  T U1, U2, U3;  // M_i / J_i
+};
+
+template <typename T>
+__device__ __forceinline__ void rhs(const T* __restrict__ y, T* __restrict__ k, const Dyn<T>& p) {
+  const T qw = y[3], qx = y[4], qy = y[5], qz = y[6];
+  const T W1 = y[7], W2 = y[8], W3 = y[9];
+  // v' = g e3 - (f/m) R e3,  R e3 = (2(xz + wy), 2(yz - wx), 1 - 2(xx + yy))
+  const T c2 = T(2) * p.c;
+  k[0] = -c2 * (qx * qz + qw * qy);
+  k[1] = -c2 * (qy * qz - qw * qx);
+  k[2] = (T(kG) - p.c) + c2 * (qx * qx + qy * qy);
+  // q' = q (0, W) / 2   (<=> R' = R hat(W))
+  const T h = T(0.5);
+  k[3] = -h * (qx * W1 + qy * W2 + qz * W3);
+  k[4] = h * (qw * W1 + qy * W3 - qz * W2);
+  k[5] = h * (qw * W2 + qz * W1 - qx * W3);
+  k[6] = h * (qw * W3 + qx * W2 - qy * W1);
+  // W' = J^-1 (-W x JW + M), J = diag(J1, J1, J3): the (J1 - J2) W1 W2 term of W3' vanishes
+  k[7] = p.A1 * W2 * W3 + p.U1;
+  k[8] = p.U2 - p.A1 * W3 * W1;
+  k[9] = p.U3;
+}
+
+template <typename T>
+__device__ __forceinline__ void rk4_step(T (&x)[3], T (&y)[10], T h, const Dyn<T>& p) {
+  T k[10], acc[10], yt[10], xs[3];
+  const T h2 = T(0.5) * h, h6 = h * T(1.0 / 6.0);
+  rhs(y, k, p);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) { acc[i] = k[i]; yt[i] = y[i] + h2 * k[i]; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) xs[i] = y[i];
+  rhs(yt, k, p);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) xs[i] += T(2) * yt[i];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) { acc[i] += T(2) * k[i]; yt[i] = y[i] + h2 * k[i]; }
+  rhs(yt, k, p);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) xs[i] += T(2) * yt[i];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) { acc[i] += T(2) * k[i]; yt[i] = y[i] + h * k[i]; }
+  rhs(yt, k, p);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) x[i] += h6 * (xs[i] + yt[i]);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) y[i] += h6 * (acc[i] + k[i]);
+}
+
+// The flow keeps |q| = 1; RK4 only to truncation order.  Restore it to first order.
+template <typename T>
+__device__ __forceinline__ void renorm_quat(T* q) {
+  const T r = T(1.5) - T(0.5) * (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] *= r;
+}
+
+// ------------------------------------------------------------------------------------
+// LDS transposes between lane-per-env registers and AoS rows in global memory.
+// The workgroup's rows [first, first+rows) x D floats are contiguous in global memory.
+// ------------------------------------------------------------------------------------
+template <int B, int D>
+__device__ __forceinline__ void store_rows(float* __restrict__ gbase, const float (&vals)[D], float* smem, int tid, int rows) {
+#pragma unroll
+  for (int j = 0; j < D; ++j) smem[tid * D + j] = vals[j];
+  __syncthreads();
+  if (rows == B && (reinterpret_cast<uintptr_t>(gbase) & 15u) == 0) {
+    constexpr int nvec = B * D / 4;  // B is a multiple of 4
+    const float4* s4 = reinterpret_cast<const float4*>(smem);
+    float4* g4 = reinterpret_cast<float4*>(gbase);
+#pragma unroll
+    for (int idx = tid; idx < nvec; idx += B) g4[idx] = s4[idx];
+  } else {
+    const int total = rows * D;
+    for (int idx = tid; idx < total; idx += B) gbase[idx] = smem[idx];
+  }
+  __syncthreads();
+}
+
+template <int B, int D>
+__device__ __forceinline__ void load_rows(const float* __restrict__ gbase, float (&vals)[D], float* smem, int tid, int rows) {
+  if (rows == B && (reinterpret_cast<uintptr_t>(gbase) & 15u) == 0) {
+    constexpr int nvec = B * D / 4;
+    float4* s4 = reinterpret_cast<float4*>(smem);
+    const float4* g4 = reinterpret_cast<const float4*>(gbase);
+#pragma unroll
+    for (int idx = tid; idx < nvec; idx += B) s4[idx] = g4[idx];
+  } else {
+    const int total = rows * D;
+    for (int idx = tid; idx < total; idx += B) smem[idx] = gbase[idx];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < D; ++j) vals[j] = tid < rows ? smem[tid * D + j] : 0.f;
+  __syncthreads();
+}
+
+template <int KIND> struct KindTraits;
+template <> struct KindTraits<QR_KIND_QUAD>      { static constexpr int A = 4, D0 = 18, D1 = 0, NAG = 1; };
+template <> struct KindTraits<QR_KIND_COUPLED>   { static constexpr int A = 4, D0 = 23, D1 = 0, NAG = 1; };
+template <> struct KindTraits<QR_KIND_DECOUPLED> { static constexpr int A = 5, D0 = 15, D1 = 3, NAG = 2; };
+
+// action_wrapper of the three kinds (quad.py:225-242, coupled:44-53, decoupled:49-59 + 68-73)
+template <int KIND, typename T>
+__device__ __forceinline__ void action_map(const float* a, const Work<T>& w, Dyn<T>& p) {
+  const Phys<T> ph(w);
+  T f, M1, M2, M3;
+  if constexpr (KIND == QR_KIND_QUAD) {
+    T t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = clampT(ph.scale_act * T(a[j]) + ph.avrg_act, T(kMinForce), ph.max_force);
+    f = ((t[0] + t[1]) + t[2]) + t[3];
+    M1 = ph.d * (t[3] - t[1]);
+    M2 = ph.d * (t[0] - t[2]);
+    M3 = ph.ctf * ((t[1] - t[0]) + (t[3] - t[2]));
+  } else {
+    f = clampT(T(4) * (ph.scale_act * T(a[0]) + ph.avrg_act), T(4) * T(kMinForce), T(4) * ph.max_force);
+    if constexpr (KIND == QR_KIND_COUPLED) {
+      M1 = T(a[1]); M2 = T(a[2]); M3 = T(a[3]);
+    } else {  // M1 = b1.tau + J3 W3 W2, M2 = b2.tau - J3 W3 W1 from (R, W) at step start
+      const T t1 = T(a[1]), t2 = T(a[2]), t3 = T(a[3]);
+      const T qw = w.y[3], qx = w.y[4], qy = w.y[5], qz = w.y[6];  // b1, b2 = first two columns of R(q)
+      const T b1t = (T(1) - T(2) * (qy * qy + qz * qz)) * t1 + T(2) * (qx * qy + qw * qz) * t2 + T(2) * (qx * qz - qw * qy) * t3;
+      const T b2t = T(2) * (qx * qy - qw * qz) * t1 + (T(1) - T(2) * (qx * qx + qz * qz)) * t2 + T(2) * (qy * qz + qw * qx) * t3;
+      M1 = b1t + ph.J3 * w.y[9] * w.y[8];
+      M2 = b2t - ph.J3 * w.y[9] * w.y[7];
+      M3 = T(a[4]);
+    }
+  }
+  const T iJ1 = recip(ph.J1), iJ3 = recip(ph.J3);
+  p.c = f * recip(ph.m);
+  p.A1 = (ph.J1 - ph.J3) * iJ1;
+  p.U1 = M1 * iJ1; p.U2 = M2 * iJ1; p.U3 = M3 * iJ3;
+}
+
+// get_norm_error_state (quad.py:421-466): fills the float32 observation rows and advances
+// the trapezoid integrators (quad_utils.py:38-63).
+template <int KIND, typename T>
+__device__ __forceinline__ void error_obs(Work<T>& w, const T (&R)[9], const Coeffs& c, float (&o0)[KindTraits<KIND>::D0],
+                                          float (&o1)[KindTraits<KIND>::D1 ? KindTraits<KIND>::D1 : 1]) {
+  const T xl = T(c.x_lim), ixl = T(c.inv_x_lim), ivl = T(c.inv_v_lim), iWl = T(c.inv_W_lim);
+  T ex[3], ev[3], eW[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {  // x/x_lim - xd/x_lim etc. (quad.py:423-434)
+    ex[j] = w.x[j] * ixl - T(w.goal[j]) * ixl;
+    ev[j] = w.y[j] * ivl - T(w.goal[3 + j]) * ivl;
+    eW[j] = w.y[7 + j] * iWl - T(w.goal[9 + j]) * iWl;
+  }
+  const T* b1 = &R[0]; const T* b2 = &R[3]; const T* b3 = &R[6];
+  const T b1d[3] = {T(w.goal[6]), T(w.goal[7]), T(w.goal[8])};
+  const T db3 = b1d[0] * b3[0] + b1d[1] * b3[1] + b1d[2] * b3[2];
+  T b1c[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) b1c[j] = b1d[j] - db3 * b3[j];
+  const T sn = -(b1c[0] * b2[0] + b1c[1] * b2[1] + b1c[2] * b2[2]);
+  const T cs = b1c[0] * b1[0] + b1c[1] * b1[1] + b1c[2] * b1[2];
+  const float eb1 = atan2f((float)sn, (float)cs);  // [rad]
+  const float eb1n = eb1 * (float)(1.0 / kPi);
+  // integrators: I += (g_prev + g) dt/2 ; g uses I before the update.  They are float32 words
+  // (stored and held), advanced in float32.
+  const float hdt = (float)(c.dt * 0.5);
+  float eIxn[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float g = fmaf(-(float)c.alpha, w.integ[j], (float)(ex[j] * xl));
+    w.integ[j] = fmaf(w.integ[3 + j] + g, hdt, w.integ[j]);
+    w.integ[3 + j] = g;
+    eIxn[j] = clampT(w.integ[j] * (float)c.inv_eIx_lim, -1.0f, 1.0f);
+  }
+  const float gb = fmaf(-(float)c.beta, w.integ[6], eb1);
+  w.integ[6] = fmaf(w.integ[7] + gb, hdt, w.integ[6]);
+  w.integ[7] = gb;
+  const float eIb1n = clampT(w.integ[6] * (float)c.inv_eIb1_lim, -1.0f, 1.0f);
+  if constexpr (KIND == QR_KIND_COUPLED) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { o0[j] = (float)ex[j]; o0[3 + j] = eIxn[j]; o0[6 + j] = (float)ev[j]; o0[20 + j] = (float)eW[j]; }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) o0[9 + j] = (float)R[j];
+    o0[18] = eb1n; o0[19] = eIb1n;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      o0[j] = (float)ex[j]; o0[3 + j] = eIxn[j]; o0[6 + j] = (float)ev[j]; o0[9 + j] = (float)b3[j];
+      o0[12 + j] = (float)(eW[0] * b1[j] + eW[1] * b2[j]);
+    }
+    o1[0] = eb1n; o1[1] = eIb1n; o1[2] = (float)eW[2];
+  }
+}
+
+}  // namespace qr

@@ -1,0 +1,191 @@
+// qr_traj.h — part of the gfx950 quadrotor step library (included by quadrotor_kernels.hip, in this order).
+// Goal generation (utils/trajectory_generator.py modes 0/1/6) and the SoA buffer accessor.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "quadrotor_hip.h"
+#include "qr_dynamics.h"
+
+namespace qr {
+
+// ------------------------------------------------------------------------------------
+// Goal generation: utils/trajectory_generator.py modes 0 and 1, per env.
+// tr[8] = {calls, theta_init, b1d_x | w_b1d, b1d_y | smooth_term, x_init[3], -}
+// ------------------------------------------------------------------------------------
+// mark_traj_start(state) (:176-204) + the episode-start branch of calculate_desired:
+//   mode 0 (:141-148): b1d = Rz(theta) b1_proj, theta ~ U(+-25 deg)
+//   mode 1 (:253-266): x_init = x, t_traj ~ U(2,5), smooth = -ln(0.001)/t_traj, w_b1d ~ U(+-0.15 pi)
+template <typename T>
+__device__ __forceinline__ void traj_start(const Work<T>& w, float (&tr)[8], int goal_mode, float theta_b1d, float t_traj, float w_b1d) {
+  const T qw = w.y[3], qx = w.y[4], qy = w.y[5], qz = w.y[6];
+  const float b1x = (float)(T(1) - T(2) * (qy * qy + qz * qz)), b1y = (float)(T(2) * (qx * qy + qw * qz));
+  const float theta_init = atan2f(b1y, b1x);  // update_initial_state (:199-204)
+  tr[0] = 0.0f;
+  tr[1] = theta_init;
+  if (goal_mode == QR_GOAL_MODE0) {
+    float sn, cs;
+    sincos_small(theta_init + theta_b1d, sn, cs);  // Rz(theta) (cos th_i, sin th_i, 0)
+    tr[2] = cs; tr[3] = sn;
+    tr[4] = tr[5] = tr[6] = 0.0f;
+  } else {  // mode 1: x_init + draws; mode 6: eight_shaped_center = x (:430), no draws
+    tr[2] = w_b1d;
+    tr[3] = 6.907755278982137f / t_traj;  // -ln(0.001) / t_traj
+#pragma unroll
+    for (int j = 0; j < 3; ++j) tr[4 + j] = (float)w.x[j];
+  }
+  tr[7] = 0.0f;
+}
+
+// Draws of an episode start that the reset sampler leaves unused (word 19 of the env's Philox
+// stream): mode 0 takes 24 bits for theta; mode 1 splits it 16/16 into t_traj and w_b1d.
+__device__ __forceinline__ void traj_draws(uint32_t r19, float& theta_b1d, float& t_traj, float& w_b1d) {
+  theta_b1d = (float)(25.0 * kPi / 180.0) * fmaf((float)(r19 >> 8), 0x1p-23f, 0x1p-24f - 1.0f);
+  t_traj = 2.0f + 3.0f * fmaf((float)(r19 >> 16), 0x1p-16f, 0x1p-17f);
+  w_b1d = (float)(0.15 * kPi) * fmaf((float)(r19 & 0xFFFFu), 0x1p-15f, 0x1p-16f - 1.0f);
+}
+
+// get_desired(state, mode) (:113-173) for the state in w: advances the call counter, fills
+// w.goal = (xd, vd, b1d, Wd) and returns b1d_dot.
+template <typename T>
+__device__ __forceinline__ void traj_goal(Work<T>& w, float (&tr)[8], int goal_mode, const Coeffs& c, float (&b1d_dot)[3]) {
+  tr[0] += 1.0f;  // update_current_time (:224-229): t = t + dt on every call
+  float b1d[3];
+  if (goal_mode == QR_GOAL_MODE0) {  // set_desired_states_to_zero + the b1d drawn at episode start
+#pragma unroll
+    for (int j = 0; j < 6; ++j) w.goal[j] = 0.0f;
+    b1d[0] = tr[2]; b1d[1] = tr[3]; b1d[2] = 0.0f;
+    b1d_dot[0] = b1d_dot[1] = b1d_dot[2] = 0.0f;
+  } else if (goal_mode == QR_GOAL_MODE6) {  // eight_shaped_curve (:418-505)
+    const float t = fminf(tr[0] * (float)c.dt, c.e8_tmax);
+    const float ek = expf(-c.e8_k * t);
+    const float e = 1.0f - ek, de = c.e8_k * ek;  // exp_term, d/dt exp_term
+    float s1, c1, s2, c2;
+    sincos_small(c.e8_w1 * t, s1, c1);
+    sincos_small(c.e8_w2 * t, s2, c2);
+    const float za = 0.5f * (tr[6] - c.e8_alt);  // synchronised altitude command (:487-492)
+    w.goal[0] = fmaf(c.e8_A2 * s2, e, tr[4]);
+    w.goal[1] = fmaf(c.e8_A1 * (c1 - 1.0f), e, tr[5]);
+    w.goal[2] = fmaf(za, 1.0f - c1, tr[6]);
+    w.goal[3] = c.e8_A2 * (c.e8_w2 * c2 * e + s2 * de);
+    w.goal[4] = c.e8_A1 * (-c.e8_w1 * s1 * e + (c1 - 1.0f) * de);
+    w.goal[5] = za * c.e8_w1 * s1;
+    const float term = fmaf(c.e8_wb * t, e, tr[1]), dterm = c.e8_wb * (e + t * de);  // yaw (:494-498)
+    float sn, cs;
+    sincos_small(term, sn, cs);
+    b1d[0] = cs; b1d[1] = sn; b1d[2] = 0.0f;
+    b1d_dot[0] = -sn * dterm; b1d_dot[1] = cs * dterm; b1d_dot[2] = 0.0f;
+  } else {  // hovering (:268-277), x_goal = 0
+    const float t = tr[0] * (float)c.dt;
+    const float wb = tr[2], sm = tr[3];
+    const float e = expf(-sm * t);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { w.goal[j] = tr[4 + j] * e; w.goal[3 + j] = -tr[4 + j] * sm * e; }
+    float sn, cs;
+    sincos_small(fmaf(wb, t, tr[1]), sn, cs);
+    b1d[0] = cs; b1d[1] = sn; b1d[2] = 0.0f;
+    b1d_dot[0] = -wb * sn; b1d_dot[1] = wb * cs; b1d_dot[2] = 0.0f;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) w.goal[6 + j] = b1d[j];
+  // Wd = (0, 0, b3 . (b1c x b1c_dot)) with b3' = R hat(W) e3 = W2 b1 - W1 b2 (:165-172)
+  T R[9];
+  quat_to_R(&w.y[3], R);
+  const T W1 = w.y[7], W2 = w.y[8];
+  T b3d[3], b1c[3], b1cd[3];
+  const T d0 = T(b1d[0]), d1 = T(b1d[1]), d2 = T(b1d[2]);
+  const T dd0 = T(b1d_dot[0]), dd1 = T(b1d_dot[1]), dd2 = T(b1d_dot[2]);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) b3d[j] = W2 * R[j] - W1 * R[3 + j];
+  const T b1d_b3 = d0 * R[6] + d1 * R[7] + d2 * R[8];
+  const T b1dd_b3 = dd0 * R[6] + dd1 * R[7] + dd2 * R[8];
+  const T b1d_b3d = d0 * b3d[0] + d1 * b3d[1] + d2 * b3d[2];
+  const T dv[3] = {d0, d1, d2}, ddv[3] = {dd0, dd1, dd2};
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    b1c[j] = dv[j] - b1d_b3 * R[6 + j];
+    b1cd[j] = ddv[j] - (b1dd_b3 * R[6 + j] + b1d_b3d * R[6 + j] + b1d_b3 * b3d[j]);
+  }
+  const T oc0 = b1c[1] * b1cd[2] - b1c[2] * b1cd[1];
+  const T oc1 = b1c[2] * b1cd[0] - b1c[0] * b1cd[2];
+  const T oc2 = b1c[0] * b1cd[1] - b1c[1] * b1cd[0];
+  w.goal[9] = 0.0f; w.goal[10] = 0.0f;
+  w.goal[11] = (float)(R[6] * oc0 + R[7] * oc1 + R[8] * oc2);
+}
+
+__device__ __forceinline__ float sq3(const float* v) { return v[0] * v[0] + v[1] * v[1] + v[2] * v[2]; }
+__device__ __forceinline__ bool out3(const float* v) { return !(fabsf(v[0]) < 1.0f) | !(fabsf(v[1]) < 1.0f) | !(fabsf(v[2]) < 1.0f); }
+__device__ __forceinline__ float interp01(float r, float rmin, float inv_nrmin) { return clampT((r - rmin) * inv_nrmin, 0.0f, 1.0f); }
+
+// ---- SoA access through buffer resources ------------------------------------------------
+// Field f of env (first + lane) of a [F][L] buffer lives at byte (f*L + first + lane)*sizeof(E).
+// `first` and L are wave-uniform, so the access is issued as
+//     buffer_load/store  vdata, voffset = lane*sizeof(E), s[rsrc], soffset = (f*L + first)*sizeof(E)
+// with the 128-bit descriptor and soffset in SGPRs (built once per wave by the SALU).  The
+// equivalent global_load through a pointer makes hipcc chain 64-bit VALU address arithmetic
+// per access (v_mad_u64_u32 / v_lshl_add_u64: ~110 of the ~1100 instructions of the step).
+// soffset is 32-bit: every SoA buffer must be < 4 GiB (checked on the host, QR_E_SIZE).
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+
+template <typename E>
+struct SoA {
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned L;  // elements between fields
+  __device__ __forceinline__ SoA(const void* base, int fields, int64_t ld)
+      : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)((int64_t)fields * ld * (int64_t)sizeof(E) > 0x7fffffffLL ? 0x7fffffffLL : (int64_t)fields * ld * (int64_t)sizeof(E)), 0x00020000)),
+        L((unsigned)ld) {}
+  __device__ __forceinline__ unsigned soff(int f, unsigned first) const { return ((unsigned)f * L + first) * (unsigned)sizeof(E); }
+  __device__ __forceinline__ E load(int f, unsigned first, unsigned lane) const {
+    if constexpr (sizeof(E) == 4) {
+      return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4u, soff(f, first), 0));
+    } else {
+      return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane * 8u, soff(f, first), 0));
+    }
+  }
+  __device__ __forceinline__ void store(int f, unsigned first, unsigned lane, E v) const {
+    if constexpr (sizeof(E) == 4) {
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsrc, lane * 4u, soff(f, first), 0);
+    } else {
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_t, v), rsrc, lane * 8u, soff(f, first), 0);
+    }
+  }
+};
+
+template <typename XV, typename QW, typename T>
+__device__ __forceinline__ void load_state(const Args& a, int64_t first64, unsigned lane, Work<T>& w) {
+  const SoA<XV> pv(a.pos_vel, 6, a.ld);
+  const SoA<QW> ar(a.att_rate, 7, a.ld);
+  const unsigned first = (unsigned)first64;
+#pragma unroll
+  for (int f = 0; f < 3; ++f) { w.x[f] = T(pv.load(f, first, lane)); w.y[f] = T(pv.load(3 + f, first, lane)); }
+#pragma unroll
+  for (int f = 0; f < 7; ++f) w.y[3 + f] = T(ar.load(f, first, lane));
+}
+
+template <typename XV, typename QW, typename T>
+__device__ __forceinline__ void store_state(const Args& a, int64_t first64, unsigned lane, const Work<T>& w) {
+  const SoA<XV> pv(a.pos_vel, 6, a.ld);
+  const SoA<QW> ar(a.att_rate, 7, a.ld);
+  const unsigned first = (unsigned)first64;
+#pragma unroll
+  for (int f = 0; f < 3; ++f) { pv.store(f, first, lane, (XV)w.x[f]); pv.store(3 + f, first, lane, (XV)w.y[f]); }
+#pragma unroll
+  for (int f = 0; f < 7; ++f) ar.store(f, first, lane, (QW)w.y[3 + f]);
+}
+
+template <typename T>
+__device__ __forceinline__ void idle_work(Work<T>& w) {  // lanes past the ragged tail
+#pragma unroll
+  for (int f = 0; f < 3; ++f) w.x[f] = T(0);
+#pragma unroll
+  for (int f = 0; f < 10; ++f) w.y[f] = T(f == 3 ? 1 : 0);
+#pragma unroll
+  for (int f = 0; f < 12; ++f) w.goal[f] = f == 6 ? 1.0f : 0.0f;
+#pragma unroll
+  for (int f = 0; f < 8; ++f) w.integ[f] = 0.0f;
+#pragma unroll
+  for (int f = 0; f < 6; ++f) w.prm[f] = 0.0f;
+  w.nominal = true;
+}
+
+}  // namespace qr

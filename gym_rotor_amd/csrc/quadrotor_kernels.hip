@@ -20,11 +20,21 @@
 //     env-steps: HBM is touched once in and once out.
 // Per-env SoA buffers are read/written with lane-contiguous accesses; caller-facing AoS
 // rows (actions, observations) go through LDS so global traffic is linear 16-byte-per-lane
-// stores.  There is no contraction larger than 3x3 anywhere, so no MFMA.
+// stores.  The physics has no contraction larger than 3x3, so no MFMA there; the one real
+// contraction on the path — the 16-wide PPO actor of qr_rollout_actor — does run on the
+// matrix cores (qr_actor.h).
 //
 // Written directly for CDNA4: 64-lane wavefronts, one wavefront per workgroup (N = 65 536 ->
 // 1024 workgroups = one per SIMD; no cross-wave barriers), <= 256 VGPRs so that two waves fit
 // per SIMD at large N.
+//
+// Files (included in this order):
+//   qr_args.h      kernel argument block, constants, per-env working set
+//   qr_rng.h       Philox4x32-10, wave-cooperative reset draws, reset sampling
+//   qr_dynamics.h  attitude helpers, quaternion-form RHS + RK4, row transposes, action maps, error obs
+//   qr_traj.h      goal generator (trajectory_generator.py modes 0/1/6), SoA buffer accessor
+//   qr_actor.h     PPO actor (MFMA / LDS forms), action sampling
+//   this file      step / rollout kernel, auxiliary kernels, host launchers and the C-ABI
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -39,881 +49,13 @@
 #define QR_WAVES_PER_SIMD 2  // 2nd __launch_bounds__ argument of the step kernel (<= 256 VGPRs)
 #endif
 
+#include "qr_args.h"
+#include "qr_rng.h"
+#include "qr_dynamics.h"
+#include "qr_traj.h"
+#include "qr_actor.h"
+
 namespace qr {
-
-// ------------------------------------------------------------------------------------
-// Kernel argument block (passed by value in kernarg memory)
-// ------------------------------------------------------------------------------------
-struct Coeffs {  // double-precision copy of QrCoeffs + derived reward floors
-  double Cx, CIx, Cv, Cb1, CIb1, CW, Cw12, CW3, alpha, beta, dt;
-  double x_lim, v_lim, W_lim, eIx_lim, eIb1_lim;
-  double sin_euler_lim, tan_euler_lim, udm;
-  double rmin_mono, rmin_1, rmin_2;
-  // reciprocals formed once on the host (an f64 division costs ~35 VALU slots on the device)
-  double inv_x_lim, inv_v_lim, inv_W_lim, inv_eIx_lim, inv_eIb1_lim, inv_nrmin_mono, inv_nrmin_1, inv_nrmin_2;
-  // eight-shaped curve (trajectory_generator.py:98-110, 418-505)
-  float e8_w1, e8_w2, e8_k, e8_A1, e8_A2, e8_wb, e8_alt, e8_tmax;
-  double inv_w_adapt;  // 1 / w_adapt, 0 = fixed substep count
-};
-
-struct ActorW {  // QrActor's tensors (torch.nn.Linear layout: weight [out][in])
-  const float *fc1_w, *fc1_b, *fc2_w, *fc2_b, *mean_w, *mean_b, *log_std;
-};
-
-struct Args {
-  // per-env buffers
-  void* pos_vel;
-  void* att_rate;
-  float* integ;
-  float* params;
-  float* goal;
-  float* traj;
-  int32_t* episode;
-  int32_t* steps;
-  // per-call
-  const float* action;
-  float* obs0;
-  float* obs1;
-  float* reward;
-  float* reward_raw;
-  uint8_t* done;
-  uint8_t* truncated;
-  const uint8_t* mask;
-  double* rows_out;       // qr_get_state
-  const double* rows_in;  // qr_set_state
-  const float* draws;     // qr_traj_start: injected [3][N] theta_b1d, t_traj, w_b1d
-  float* goal_rows;       // qr_get_desired: [N][15]
-  int32_t goal_mode;
-  int32_t store_goal;
-  int64_t n;
-  int64_t ld;             // elements between consecutive fields of every SoA buffer (>= n)
-  int64_t env_offset;
-  uint64_t seed;
-  int32_t n_steps;
-  int32_t substeps;
-  int32_t max_episode_steps;
-  uint32_t flags;
-  // qr_rollout_actor: the policy in the loop
-  ActorW actor[2];
-  const float* obs0_in;
-  const float* obs1_in;
-  const float* noise;
-  float* act_out;
-  float* logp_out;
-  uint64_t noise_seed;
-  uint64_t step_base;
-  float max_action;
-  int32_t deterministic;
-  Coeffs c;
-};
-
-// Nominal parameters (quad.py:28-33)
-constexpr double kMnom = 2.15, kDnom = 0.23, kJ1nom = 0.022, kJ3nom = 0.035, kCtfNom = 0.0135,
-                 kCtwNom = 2.2, kG = 9.81, kMinForce = 0.5;
-constexpr double kPi = 3.14159265358979323846;
-
-template <typename T> __device__ __forceinline__ T clampT(T v, T lo, T hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
-// 1/a for well-scaled positive a (masses, inertias): hardware seed + Newton steps instead of
-// the ~35-instruction IEEE f64 division expansion.  Relative error <= 2 ulp.
-__device__ __forceinline__ double recip(double a) {
-  double x = __builtin_amdgcn_rcp(a);
-  x = fma(fma(-a, x, 1.0), x, x);
-  x = fma(fma(-a, x, 1.0), x, x);
-  return x;
-}
-__device__ __forceinline__ float recip(float a) {
-  float x = __builtin_amdgcn_rcpf(a);
-  return fmaf(fmaf(-a, x, 1.0f), x, x);
-}
-
-// Per-env working set held in VGPRs.  y = (v[0..2], q[3..6] = w,x,y,z, W[7..9]) is the RK4
-// vector; x' = v is integrated from the stage velocities.  Everything that is STORED as
-// float32 is also HELD as float32 (converted at use): the step kernel is register-bound —
-// two waves per SIMD need <= 256 VGPRs — and a float64 copy of 26 words costs 26 registers.
-template <typename T>
-struct Work {
-  T x[3];
-  T y[10];
-  float prm[6];    // m, d, J1(=J2), J3, c_tf, c_tw (quad.py:359-387); kNominal[] when not randomised
-  float goal[12];  // xd, vd, b1d, Wd
-  float integ[8];  // eIx, g_x prev, eIb1, g_b prev
-  bool nominal;    // parameters are the exact float64 nominal values, not prm[]
-};
-
-template <typename T>
-struct Phys {  // what set_random_parameters derives (quad.py:389-404), formed when needed
-  T m, d, J1, J3, ctf, ctw;
-  T max_force, avrg_act, scale_act;
-  template <typename W>
-  __device__ __forceinline__ explicit Phys(const W& w) {
-    if (w.nominal) {
-      m = T(kMnom); d = T(kDnom); J1 = T(kJ1nom); J3 = T(kJ3nom); ctf = T(kCtfNom); ctw = T(kCtwNom);
-    } else {
-      m = T(w.prm[0]); d = T(w.prm[1]); J1 = T(w.prm[2]); J3 = T(w.prm[3]); ctf = T(w.prm[4]); ctw = T(w.prm[5]);
-    }
-    const T hover = m * T(kG * 0.25);
-    max_force = ctw * hover;
-    avrg_act = (T(kMinForce) + max_force) * T(0.5);
-    scale_act = max_force - avrg_act;
-  }
-};
-
-// ------------------------------------------------------------------------------------
-// Philox4x32-10 counter-based RNG (Salmon et al., SC'11): stateless, keyed by
-// (seed, global env id, episode) so that resets do not depend on launch geometry.
-// ------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t (&ctr)[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    // separate v_mul_hi_u32 / v_mul_lo_u32: the 64-bit product form compiles to v_mad_u64_u32,
-    // which measures ~2x slower than the pair on gfx950
-    const uint32_t hi0 = __umulhi(0xD2511F53u, ctr[0]), lo0 = 0xD2511F53u * ctr[0];
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, ctr[2]), lo1 = 0xCD9E8D57u * ctr[2];
-    const uint32_t n0 = hi1 ^ ctr[1] ^ k0;
-    const uint32_t n1 = lo1;
-    const uint32_t n2 = hi0 ^ ctr[3] ^ k1;
-    const uint32_t n3 = lo0;
-    ctr[0] = n0; ctr[1] = n1; ctr[2] = n2; ctr[3] = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-}
-
-struct Draws {  // 20 x 32 random bits -> uniforms (24-bit mantissa: these are random draws, float is plenty)
-  uint32_t r[20];
-  __device__ __forceinline__ float u01(int i) const { return fmaf((float)(r[i] >> 8), 0x1p-24f, 0x1p-25f); }
-  __device__ __forceinline__ float sym(int i) const { return fmaf((float)(r[i] >> 8), 0x1p-23f, 0x1p-24f - 1.0f); }
-};
-
-__device__ __forceinline__ void draw20(Draws& d, uint64_t seed, uint64_t gid, uint32_t episode) {
-#pragma unroll
-  for (int b = 0; b < 5; ++b) {
-    uint32_t ctr[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), episode, (uint32_t)b};
-    philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) d.r[4 * b + j] = ctr[j];
-  }
-}
-
-// Wave-cooperative form for the in-step auto-reset.  Only ~1 % of the envs reset in a given
-// step, but a wave runs the reset path if ANY of its 64 lanes needs it and the kernel ends with
-// its slowest wave, so what counts is the instruction count of the path — and Philox is the
-// bulk of it (v_mul_hi/lo_u32 are quarter-rate).  Instead of each resetting lane grinding
-// through 5 Philox blocks with the rest of the wave idle, ONE Philox pass serves up to 12
-// resetting envs: lane 5k+b computes block b of the k-th resetting env, then each owner pulls
-// its 20 words with ds_bpermute.  Same draws as draw20.
-__device__ __forceinline__ void coop_draw20(Draws& d, bool need, uint64_t seed, uint64_t gid, uint32_t episode) {
-  const int lane = (int)__lane_id();
-  const int glo = (int)(uint32_t)gid, ghi = (int)(uint32_t)(gid >> 32), ep = (int)episode;
-#pragma unroll
-  for (int j = 0; j < 20; ++j) d.r[j] = 0u;
-  unsigned long long m = __ballot(need);
-  const int my_rank = __popcll(m & ((1ull << lane) - 1ull));  // rank among the resetting lanes
-  const int k = lane / 5, b = lane - 5 * k;                   // slot / block of this lane (k = 12: idle)
-  int base = 0;
-  while (m) {  // wave-uniform; one pass unless > 12 lanes of this wave reset
-    int src = lane, cnt = 0;
-    for (int s = 0; s < 12 && m; ++s) {  // lane index of the s-th resetting env -> lanes of slot s
-      const int l = __builtin_ctzll(m);
-      m &= m - 1;
-      if (k == s) src = l;
-      ++cnt;
-    }
-    uint32_t ctr[4] = {(uint32_t)__shfl(glo, src), (uint32_t)__shfl(ghi, src), (uint32_t)__shfl(ep, src), (uint32_t)b};
-    philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
-    const int r = my_rank - base;
-    const bool mine = need && r >= 0 && r < cnt;
-    const int from4 = (mine ? 5 * r : 0) << 2;  // ds_bpermute takes a byte address (lane * 4)
-    // All 20 cross-lane reads are issued back to back and waited for once: written as
-    // "read, select, read, select, ..." hipcc puts an s_waitcnt lgkmcnt(0) behind every
-    // ds_bpermute and the ~100-cycle LDS-crossbar latency is paid 20 times in series.
-    int got[20];
-#pragma unroll
-    for (int bb = 0; bb < 5; ++bb) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) got[4 * bb + j] = __builtin_amdgcn_ds_bpermute(from4 + 4 * bb, (int)ctr[j]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int w = 0; w < 20; ++w) d.r[w] = mine ? (uint32_t)got[w] : d.r[w];
-    base += cnt;
-  }
-}
-
-// sin and cos of a float angle of moderate size (|x| < ~1e3): Cody-Waite reduction by pi/2 and
-// the cephes minimax polynomials on [-pi/4, pi/4]; ~1e-7 absolute.  Branch-free and small: the
-// OCML sincosf drags its Payne-Hanek slow path (and its registers) into every kernel using it.
-__device__ __forceinline__ void sincos_small(float x, float& sn, float& cs) {
-  const float k = rintf(x * 0.63661977236758134f);
-  float r = fmaf(-k, 1.5707962512969971f, x);
-  r = fmaf(-k, 7.5497894158615964e-08f, r);
-  const float r2 = r * r;
-  const float ps = fmaf(r * r2, fmaf(r2, fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
-  const float pc = fmaf(r2 * r2, fmaf(r2, fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
-                        fmaf(-0.5f, r2, 1.0f));
-  const int q = (int)k;
-  const float s0 = (q & 1) ? pc : ps, c0 = (q & 1) ? ps : pc;
-  sn = (q & 2) ? -s0 : s0;
-  cs = ((q + 1) & 2) ? -c0 : c0;
-}
-
-// sin/cos of a random angle re-normalised in f64, so every factor, hence q, has unit norm to
-// f64 round-off.
-__device__ __forceinline__ void unit_sincos(float ang, double& s, double& c) {
-  float sf, cf;
-  sincos_small(ang, sf, cf);
-  s = (double)sf; c = (double)cf;
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {  // r = 1/sqrt(n2) to first order around 1: 1e-6 -> 1e-12 -> 1e-24
-    const double r = 1.5 - 0.5 * (s * s + c * c);
-    s *= r; c *= r;
-  }
-}
-
-// QuadEnv.reset + sample_init_error + set_random_parameters (quad.py:171-222, 338-404).
-// Draw order: 0..5 m,d,J1,J3,c_tf,c_tw; 6 yaw; 7 zero-error branch; 8..10 x; 11..13 v;
-// 14..16 W; 17,18 roll,pitch.  R = Rz(yaw) Ry(pitch) Rx(roll) (scipy 'xyz' extrinsic,
-// quad.py:199)  <=>  q = qz(yaw) qy(pitch) qx(roll).
-template <typename T>
-__device__ void sample_reset(Work<T>& w, const Draws& d, bool randomise, bool eval, const Coeffs& c) {
-  if (randomise) {  // float32 values: that is how the params buffer stores them
-    const float p = (float)c.udm;
-    w.prm[0] = (float)kMnom * fmaf(p, d.sym(0), 1.0f);
-    w.prm[1] = (float)kDnom * fmaf(p, d.sym(1), 1.0f);
-    w.prm[2] = (float)kJ1nom * fmaf(p, d.sym(2), 1.0f);
-    w.prm[3] = (float)kJ3nom * fmaf(p, d.sym(3), 1.0f);
-    w.prm[4] = (float)kCtfNom * fmaf(p, d.sym(4), 1.0f);
-    w.prm[5] = (float)kCtwNom * fmaf(0.5f * p, d.sym(5), 1.0f);
-    w.nominal = false;
-  } else {
-    w.prm[0] = (float)kMnom; w.prm[1] = (float)kDnom; w.prm[2] = (float)kJ1nom;
-    w.prm[3] = (float)kJ3nom; w.prm[4] = (float)kCtfNom; w.prm[5] = (float)kCtwNom;
-    w.nominal = true;
-  }
-  const float yaw = (float)kPi * d.sym(6);
-  float ix, iv, iR, iW;
-  if (eval) {  // quad.py:352-356
-    ix = 0.4f; iv = 0.0f; iR = 0.0f; iW = 0.0f;
-  } else if (d.u01(7) < 0.2f) {  // quad.py:342-346
-    ix = 0.0f; iv = 0.0f; iR = 0.0f; iW = 0.0f;
-  } else {  // quad.py:348-351
-    ix = 0.6f; iv = (float)(c.v_lim * 0.5); iR = (float)(50.0 * kPi / 180.0); iW = (float)(c.W_lim * 0.5);
-  }
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    w.x[j] = T(ix * d.sym(8 + j));
-    w.y[j] = T(iv * d.sym(11 + j));
-    w.y[7 + j] = T(iW * d.sym(14 + j));
-  }
-  double sr, cr, sp, cp, sy, cy;
-  unit_sincos(0.5f * iR * d.sym(17), sr, cr);
-  unit_sincos(0.5f * iR * d.sym(18), sp, cp);
-  unit_sincos(0.5f * yaw, sy, cy);
-  w.y[3] = T(cr * cp * cy + sr * sp * sy);
-  w.y[4] = T(sr * cp * cy - cr * sp * sy);
-  w.y[5] = T(cr * sp * cy + sr * cp * sy);
-  w.y[6] = T(cr * cp * sy - sr * sp * cy);
-}
-
-// ------------------------------------------------------------------------------------
-// Attitude helpers
-// ------------------------------------------------------------------------------------
-// R(q), column-major like the reference's vec_F(R): R[3c + r].
-template <typename T>
-__device__ __forceinline__ void quat_to_R(const T* q, T (&R)[9]) {
-  const T w = q[0], x = q[1], y = q[2], z = q[3];
-  const T xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
-  R[0] = T(1) - T(2) * (yy + zz); R[1] = T(2) * (xy + wz);        R[2] = T(2) * (xz - wy);
-  R[3] = T(2) * (xy - wz);        R[4] = T(1) - T(2) * (xx + zz); R[5] = T(2) * (yz + wx);
-  R[6] = T(2) * (xz + wy);        R[7] = T(2) * (yz - wx);        R[8] = T(1) - T(2) * (xx + yy);
-}
-
-// ensure_SO3 (quad_utils.py:123-142) + attitude import.  The reference replaces R by the
-// nearest rotation U V^T (SVD) when R^T R or det R is off by more than 1e-5; since the
-// internal attitude is a unit quaternion, the nearest rotation is taken always (for an R
-// that is orthonormal to round-off this changes nothing).  The polar factor is computed by
-// the Newton iteration X <- (X + X^-T)/2, which converges quadratically to U V^T (det R > 0).
-__device__ void R_to_quat(const double* Rin, double (&q)[4]) {
-  double X[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) X[i] = Rin[i];
-  for (int it = 0; it < 40; ++it) {
-    double C[9];  // C = cof(X), column-major like X; X^-T = C / det X
-    C[0] = X[4] * X[8] - X[5] * X[7]; C[1] = X[5] * X[6] - X[3] * X[8]; C[2] = X[3] * X[7] - X[4] * X[6];
-    C[3] = X[2] * X[7] - X[1] * X[8]; C[4] = X[0] * X[8] - X[2] * X[6]; C[5] = X[1] * X[6] - X[0] * X[7];
-    C[6] = X[1] * X[5] - X[2] * X[4]; C[7] = X[2] * X[3] - X[0] * X[5]; C[8] = X[0] * X[4] - X[1] * X[3];
-    const double dd = X[0] * C[0] + X[1] * C[1] + X[2] * C[2];
-    if (!(fabs(dd) > 1e-300)) break;
-    const double inv = 1.0 / dd;
-    double delta = 0.0;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      const double xn = 0.5 * (X[i] + C[i] * inv);
-      delta = fmax(delta, fabs(xn - X[i]));
-      X[i] = xn;
-    }
-    if (delta < 4e-16) break;
-  }
-  // Shepperd's method on the (now orthonormal) X; X[3c + r] = R(r, c)
-  const double r00 = X[0], r11 = X[4], r22 = X[8];
-  const double tr = r00 + r11 + r22;
-  double w, x, y, z;
-  if (tr >= r00 && tr >= r11 && tr >= r22) {
-    w = 1.0 + tr; x = X[5] - X[7]; y = X[6] - X[2]; z = X[1] - X[3];
-  } else if (r00 >= r11 && r00 >= r22) {
-    w = X[5] - X[7]; x = 1.0 + r00 - r11 - r22; y = X[3] + X[1]; z = X[6] + X[2];
-  } else if (r11 >= r22) {
-    w = X[6] - X[2]; x = X[3] + X[1]; y = 1.0 - r00 + r11 - r22; z = X[7] + X[5];
-  } else {
-    w = X[1] - X[3]; x = X[6] + X[2]; y = X[7] + X[5]; z = 1.0 - r00 - r11 + r22;
-  }
-  const double inv = 1.0 / sqrt(w * w + x * x + y * y + z * z);
-  q[0] = w * inv; q[1] = x * inv; q[2] = y * inv; q[3] = z * inv;
-}
-
-// ------------------------------------------------------------------------------------
-// Dynamics (quad.py:321-335) in quaternion form.
-// ------------------------------------------------------------------------------------
-template <typename T>
-struct Dyn {
-  T c;           // f/m
-  T A1;          // (J2-J3)/J1 with J2 = J1; the W2' coefficient (J3-J1)/J2 is -A1
-  T U1, U2, U3;  // M_i / J_i
-};
-
-template <typename T>
-__device__ __forceinline__ void rhs(const T* __restrict__ y, T* __restrict__ k, const Dyn<T>& p) {
-  const T qw = y[3], qx = y[4], qy = y[5], qz = y[6];
-  const T W1 = y[7], W2 = y[8], W3 = y[9];
-  // v' = g e3 - (f/m) R e3,  R e3 = (2(xz + wy), 2(yz - wx), 1 - 2(xx + yy))
-  const T c2 = T(2) * p.c;
-  k[0] = -c2 * (qx * qz + qw * qy);
-  k[1] = -c2 * (qy * qz - qw * qx);
-  k[2] = (T(kG) - p.c) + c2 * (qx * qx + qy * qy);
-  // q' = q (0, W) / 2   (<=> R' = R hat(W))
-  const T h = T(0.5);
-  k[3] = -h * (qx * W1 + qy * W2 + qz * W3);
-  k[4] = h * (qw * W1 + qy * W3 - qz * W2);
-  k[5] = h * (qw * W2 + qz * W1 - qx * W3);
-  k[6] = h * (qw * W3 + qx * W2 - qy * W1);
-  // W' = J^-1 (-W x JW + M), J = diag(J1, J1, J3): the (J1 - J2) W1 W2 term of W3' vanishes
-  k[7] = p.A1 * W2 * W3 + p.U1;
-  k[8] = p.U2 - p.A1 * W3 * W1;
-  k[9] = p.U3;
-}
-
-template <typename T>
-__device__ __forceinline__ void rk4_step(T (&x)[3], T (&y)[10], T h, const Dyn<T>& p) {
-  T k[10], acc[10], yt[10], xs[3];
-  const T h2 = T(0.5) * h, h6 = h * T(1.0 / 6.0);
-  rhs(y, k, p);
-#pragma unroll
-  for (int i = 0; i < 10; ++i) { acc[i] = k[i]; yt[i] = y[i] + h2 * k[i]; }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) xs[i] = y[i];
-  rhs(yt, k, p);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) xs[i] += T(2) * yt[i];
-#pragma unroll
-  for (int i = 0; i < 10; ++i) { acc[i] += T(2) * k[i]; yt[i] = y[i] + h2 * k[i]; }
-  rhs(yt, k, p);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) xs[i] += T(2) * yt[i];
-#pragma unroll
-  for (int i = 0; i < 10; ++i) { acc[i] += T(2) * k[i]; yt[i] = y[i] + h * k[i]; }
-  rhs(yt, k, p);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) x[i] += h6 * (xs[i] + yt[i]);
-#pragma unroll
-  for (int i = 0; i < 10; ++i) y[i] += h6 * (acc[i] + k[i]);
-}
-
-// The flow keeps |q| = 1; RK4 only to truncation order.  Restore it to first order.
-template <typename T>
-__device__ __forceinline__ void renorm_quat(T* q) {
-  const T r = T(1.5) - T(0.5) * (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) q[i] *= r;
-}
-
-// ------------------------------------------------------------------------------------
-// LDS transposes between lane-per-env registers and AoS rows in global memory.
-// The workgroup's rows [first, first+rows) x D floats are contiguous in global memory.
-// ------------------------------------------------------------------------------------
-template <int B, int D>
-__device__ __forceinline__ void store_rows(float* __restrict__ gbase, const float (&vals)[D], float* smem, int tid, int rows) {
-#pragma unroll
-  for (int j = 0; j < D; ++j) smem[tid * D + j] = vals[j];
-  __syncthreads();
-  if (rows == B && (reinterpret_cast<uintptr_t>(gbase) & 15u) == 0) {
-    constexpr int nvec = B * D / 4;  // B is a multiple of 4
-    const float4* s4 = reinterpret_cast<const float4*>(smem);
-    float4* g4 = reinterpret_cast<float4*>(gbase);
-#pragma unroll
-    for (int idx = tid; idx < nvec; idx += B) g4[idx] = s4[idx];
-  } else {
-    const int total = rows * D;
-    for (int idx = tid; idx < total; idx += B) gbase[idx] = smem[idx];
-  }
-  __syncthreads();
-}
-
-template <int B, int D>
-__device__ __forceinline__ void load_rows(const float* __restrict__ gbase, float (&vals)[D], float* smem, int tid, int rows) {
-  if (rows == B && (reinterpret_cast<uintptr_t>(gbase) & 15u) == 0) {
-    constexpr int nvec = B * D / 4;
-    float4* s4 = reinterpret_cast<float4*>(smem);
-    const float4* g4 = reinterpret_cast<const float4*>(gbase);
-#pragma unroll
-    for (int idx = tid; idx < nvec; idx += B) s4[idx] = g4[idx];
-  } else {
-    const int total = rows * D;
-    for (int idx = tid; idx < total; idx += B) smem[idx] = gbase[idx];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < D; ++j) vals[j] = tid < rows ? smem[tid * D + j] : 0.f;
-  __syncthreads();
-}
-
-template <int KIND> struct KindTraits;
-template <> struct KindTraits<QR_KIND_QUAD>      { static constexpr int A = 4, D0 = 18, D1 = 0, NAG = 1; };
-template <> struct KindTraits<QR_KIND_COUPLED>   { static constexpr int A = 4, D0 = 23, D1 = 0, NAG = 1; };
-template <> struct KindTraits<QR_KIND_DECOUPLED> { static constexpr int A = 5, D0 = 15, D1 = 3, NAG = 2; };
-
-// action_wrapper of the three kinds (quad.py:225-242, coupled:44-53, decoupled:49-59 + 68-73)
-template <int KIND, typename T>
-__device__ __forceinline__ void action_map(const float* a, const Work<T>& w, Dyn<T>& p) {
-  const Phys<T> ph(w);
-  T f, M1, M2, M3;
-  if constexpr (KIND == QR_KIND_QUAD) {
-    T t[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) t[j] = clampT(ph.scale_act * T(a[j]) + ph.avrg_act, T(kMinForce), ph.max_force);
-    f = ((t[0] + t[1]) + t[2]) + t[3];
-    M1 = ph.d * (t[3] - t[1]);
-    M2 = ph.d * (t[0] - t[2]);
-    M3 = ph.ctf * ((t[1] - t[0]) + (t[3] - t[2]));
-  } else {
-    f = clampT(T(4) * (ph.scale_act * T(a[0]) + ph.avrg_act), T(4) * T(kMinForce), T(4) * ph.max_force);
-    if constexpr (KIND == QR_KIND_COUPLED) {
-      M1 = T(a[1]); M2 = T(a[2]); M3 = T(a[3]);
-    } else {  // M1 = b1.tau + J3 W3 W2, M2 = b2.tau - J3 W3 W1 from (R, W) at step start
-      const T t1 = T(a[1]), t2 = T(a[2]), t3 = T(a[3]);
-      const T qw = w.y[3], qx = w.y[4], qy = w.y[5], qz = w.y[6];  // b1, b2 = first two columns of R(q)
-      const T b1t = (T(1) - T(2) * (qy * qy + qz * qz)) * t1 + T(2) * (qx * qy + qw * qz) * t2 + T(2) * (qx * qz - qw * qy) * t3;
-      const T b2t = T(2) * (qx * qy - qw * qz) * t1 + (T(1) - T(2) * (qx * qx + qz * qz)) * t2 + T(2) * (qy * qz + qw * qx) * t3;
-      M1 = b1t + ph.J3 * w.y[9] * w.y[8];
-      M2 = b2t - ph.J3 * w.y[9] * w.y[7];
-      M3 = T(a[4]);
-    }
-  }
-  const T iJ1 = recip(ph.J1), iJ3 = recip(ph.J3);
-  p.c = f * recip(ph.m);
-  p.A1 = (ph.J1 - ph.J3) * iJ1;
-  p.U1 = M1 * iJ1; p.U2 = M2 * iJ1; p.U3 = M3 * iJ3;
-}
-
-// get_norm_error_state (quad.py:421-466): fills the float32 observation rows and advances
-// the trapezoid integrators (quad_utils.py:38-63).
-template <int KIND, typename T>
-__device__ __forceinline__ void error_obs(Work<T>& w, const T (&R)[9], const Coeffs& c, float (&o0)[KindTraits<KIND>::D0],
-                                          float (&o1)[KindTraits<KIND>::D1 ? KindTraits<KIND>::D1 : 1]) {
-  const T xl = T(c.x_lim), ixl = T(c.inv_x_lim), ivl = T(c.inv_v_lim), iWl = T(c.inv_W_lim);
-  T ex[3], ev[3], eW[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {  // x/x_lim - xd/x_lim etc. (quad.py:423-434)
-    ex[j] = w.x[j] * ixl - T(w.goal[j]) * ixl;
-    ev[j] = w.y[j] * ivl - T(w.goal[3 + j]) * ivl;
-    eW[j] = w.y[7 + j] * iWl - T(w.goal[9 + j]) * iWl;
-  }
-  const T* b1 = &R[0]; const T* b2 = &R[3]; const T* b3 = &R[6];
-  const T b1d[3] = {T(w.goal[6]), T(w.goal[7]), T(w.goal[8])};
-  const T db3 = b1d[0] * b3[0] + b1d[1] * b3[1] + b1d[2] * b3[2];
-  T b1c[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) b1c[j] = b1d[j] - db3 * b3[j];
-  const T sn = -(b1c[0] * b2[0] + b1c[1] * b2[1] + b1c[2] * b2[2]);
-  const T cs = b1c[0] * b1[0] + b1c[1] * b1[1] + b1c[2] * b1[2];
-  const float eb1 = atan2f((float)sn, (float)cs);  // [rad]
-  const float eb1n = eb1 * (float)(1.0 / kPi);
-  // integrators: I += (g_prev + g) dt/2 ; g uses I before the update.  They are float32 words
-  // (stored and held), advanced in float32.
-  const float hdt = (float)(c.dt * 0.5);
-  float eIxn[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const float g = fmaf(-(float)c.alpha, w.integ[j], (float)(ex[j] * xl));
-    w.integ[j] = fmaf(w.integ[3 + j] + g, hdt, w.integ[j]);
-    w.integ[3 + j] = g;
-    eIxn[j] = clampT(w.integ[j] * (float)c.inv_eIx_lim, -1.0f, 1.0f);
-  }
-  const float gb = fmaf(-(float)c.beta, w.integ[6], eb1);
-  w.integ[6] = fmaf(w.integ[7] + gb, hdt, w.integ[6]);
-  w.integ[7] = gb;
-  const float eIb1n = clampT(w.integ[6] * (float)c.inv_eIb1_lim, -1.0f, 1.0f);
-  if constexpr (KIND == QR_KIND_COUPLED) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { o0[j] = (float)ex[j]; o0[3 + j] = eIxn[j]; o0[6 + j] = (float)ev[j]; o0[20 + j] = (float)eW[j]; }
-#pragma unroll
-    for (int j = 0; j < 9; ++j) o0[9 + j] = (float)R[j];
-    o0[18] = eb1n; o0[19] = eIb1n;
-  } else {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      o0[j] = (float)ex[j]; o0[3 + j] = eIxn[j]; o0[6 + j] = (float)ev[j]; o0[9 + j] = (float)b3[j];
-      o0[12 + j] = (float)(eW[0] * b1[j] + eW[1] * b2[j]);
-    }
-    o1[0] = eb1n; o1[1] = eIb1n; o1[2] = (float)eW[2];
-  }
-}
-
-// ------------------------------------------------------------------------------------
-// Goal generation: utils/trajectory_generator.py modes 0 and 1, per env.
-// tr[8] = {calls, theta_init, b1d_x | w_b1d, b1d_y | smooth_term, x_init[3], -}
-// ------------------------------------------------------------------------------------
-// mark_traj_start(state) (:176-204) + the episode-start branch of calculate_desired:
-//   mode 0 (:141-148): b1d = Rz(theta) b1_proj, theta ~ U(+-25 deg)
-//   mode 1 (:253-266): x_init = x, t_traj ~ U(2,5), smooth = -ln(0.001)/t_traj, w_b1d ~ U(+-0.15 pi)
-template <typename T>
-__device__ __forceinline__ void traj_start(const Work<T>& w, float (&tr)[8], int goal_mode, float theta_b1d, float t_traj, float w_b1d) {
-  const T qw = w.y[3], qx = w.y[4], qy = w.y[5], qz = w.y[6];
-  const float b1x = (float)(T(1) - T(2) * (qy * qy + qz * qz)), b1y = (float)(T(2) * (qx * qy + qw * qz));
-  const float theta_init = atan2f(b1y, b1x);  // update_initial_state (:199-204)
-  tr[0] = 0.0f;
-  tr[1] = theta_init;
-  if (goal_mode == QR_GOAL_MODE0) {
-    float sn, cs;
-    sincos_small(theta_init + theta_b1d, sn, cs);  // Rz(theta) (cos th_i, sin th_i, 0)
-    tr[2] = cs; tr[3] = sn;
-    tr[4] = tr[5] = tr[6] = 0.0f;
-  } else {  // mode 1: x_init + draws; mode 6: eight_shaped_center = x (:430), no draws
-    tr[2] = w_b1d;
-    tr[3] = 6.907755278982137f / t_traj;  // -ln(0.001) / t_traj
-#pragma unroll
-    for (int j = 0; j < 3; ++j) tr[4 + j] = (float)w.x[j];
-  }
-  tr[7] = 0.0f;
-}
-
-// Draws of an episode start that the reset sampler leaves unused (word 19 of the env's Philox
-// stream): mode 0 takes 24 bits for theta; mode 1 splits it 16/16 into t_traj and w_b1d.
-__device__ __forceinline__ void traj_draws(uint32_t r19, float& theta_b1d, float& t_traj, float& w_b1d) {
-  theta_b1d = (float)(25.0 * kPi / 180.0) * fmaf((float)(r19 >> 8), 0x1p-23f, 0x1p-24f - 1.0f);
-  t_traj = 2.0f + 3.0f * fmaf((float)(r19 >> 16), 0x1p-16f, 0x1p-17f);
-  w_b1d = (float)(0.15 * kPi) * fmaf((float)(r19 & 0xFFFFu), 0x1p-15f, 0x1p-16f - 1.0f);
-}
-
-// get_desired(state, mode) (:113-173) for the state in w: advances the call counter, fills
-// w.goal = (xd, vd, b1d, Wd) and returns b1d_dot.
-template <typename T>
-__device__ __forceinline__ void traj_goal(Work<T>& w, float (&tr)[8], int goal_mode, const Coeffs& c, float (&b1d_dot)[3]) {
-  tr[0] += 1.0f;  // update_current_time (:224-229): t = t + dt on every call
-  float b1d[3];
-  if (goal_mode == QR_GOAL_MODE0) {  // set_desired_states_to_zero + the b1d drawn at episode start
-#pragma unroll
-    for (int j = 0; j < 6; ++j) w.goal[j] = 0.0f;
-    b1d[0] = tr[2]; b1d[1] = tr[3]; b1d[2] = 0.0f;
-    b1d_dot[0] = b1d_dot[1] = b1d_dot[2] = 0.0f;
-  } else if (goal_mode == QR_GOAL_MODE6) {  // eight_shaped_curve (:418-505)
-    const float t = fminf(tr[0] * (float)c.dt, c.e8_tmax);
-    const float ek = expf(-c.e8_k * t);
-    const float e = 1.0f - ek, de = c.e8_k * ek;  // exp_term, d/dt exp_term
-    float s1, c1, s2, c2;
-    sincos_small(c.e8_w1 * t, s1, c1);
-    sincos_small(c.e8_w2 * t, s2, c2);
-    const float za = 0.5f * (tr[6] - c.e8_alt);  // synchronised altitude command (:487-492)
-    w.goal[0] = fmaf(c.e8_A2 * s2, e, tr[4]);
-    w.goal[1] = fmaf(c.e8_A1 * (c1 - 1.0f), e, tr[5]);
-    w.goal[2] = fmaf(za, 1.0f - c1, tr[6]);
-    w.goal[3] = c.e8_A2 * (c.e8_w2 * c2 * e + s2 * de);
-    w.goal[4] = c.e8_A1 * (-c.e8_w1 * s1 * e + (c1 - 1.0f) * de);
-    w.goal[5] = za * c.e8_w1 * s1;
-    const float term = fmaf(c.e8_wb * t, e, tr[1]), dterm = c.e8_wb * (e + t * de);  // yaw (:494-498)
-    float sn, cs;
-    sincos_small(term, sn, cs);
-    b1d[0] = cs; b1d[1] = sn; b1d[2] = 0.0f;
-    b1d_dot[0] = -sn * dterm; b1d_dot[1] = cs * dterm; b1d_dot[2] = 0.0f;
-  } else {  // hovering (:268-277), x_goal = 0
-    const float t = tr[0] * (float)c.dt;
-    const float wb = tr[2], sm = tr[3];
-    const float e = expf(-sm * t);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { w.goal[j] = tr[4 + j] * e; w.goal[3 + j] = -tr[4 + j] * sm * e; }
-    float sn, cs;
-    sincos_small(fmaf(wb, t, tr[1]), sn, cs);
-    b1d[0] = cs; b1d[1] = sn; b1d[2] = 0.0f;
-    b1d_dot[0] = -wb * sn; b1d_dot[1] = wb * cs; b1d_dot[2] = 0.0f;
-  }
-#pragma unroll
-  for (int j = 0; j < 3; ++j) w.goal[6 + j] = b1d[j];
-  // Wd = (0, 0, b3 . (b1c x b1c_dot)) with b3' = R hat(W) e3 = W2 b1 - W1 b2 (:165-172)
-  T R[9];
-  quat_to_R(&w.y[3], R);
-  const T W1 = w.y[7], W2 = w.y[8];
-  T b3d[3], b1c[3], b1cd[3];
-  const T d0 = T(b1d[0]), d1 = T(b1d[1]), d2 = T(b1d[2]);
-  const T dd0 = T(b1d_dot[0]), dd1 = T(b1d_dot[1]), dd2 = T(b1d_dot[2]);
-#pragma unroll
-  for (int j = 0; j < 3; ++j) b3d[j] = W2 * R[j] - W1 * R[3 + j];
-  const T b1d_b3 = d0 * R[6] + d1 * R[7] + d2 * R[8];
-  const T b1dd_b3 = dd0 * R[6] + dd1 * R[7] + dd2 * R[8];
-  const T b1d_b3d = d0 * b3d[0] + d1 * b3d[1] + d2 * b3d[2];
-  const T dv[3] = {d0, d1, d2}, ddv[3] = {dd0, dd1, dd2};
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    b1c[j] = dv[j] - b1d_b3 * R[6 + j];
-    b1cd[j] = ddv[j] - (b1dd_b3 * R[6 + j] + b1d_b3d * R[6 + j] + b1d_b3 * b3d[j]);
-  }
-  const T oc0 = b1c[1] * b1cd[2] - b1c[2] * b1cd[1];
-  const T oc1 = b1c[2] * b1cd[0] - b1c[0] * b1cd[2];
-  const T oc2 = b1c[0] * b1cd[1] - b1c[1] * b1cd[0];
-  w.goal[9] = 0.0f; w.goal[10] = 0.0f;
-  w.goal[11] = (float)(R[6] * oc0 + R[7] * oc1 + R[8] * oc2);
-}
-
-__device__ __forceinline__ float sq3(const float* v) { return v[0] * v[0] + v[1] * v[1] + v[2] * v[2]; }
-__device__ __forceinline__ bool out3(const float* v) { return !(fabsf(v[0]) < 1.0f) | !(fabsf(v[1]) < 1.0f) | !(fabsf(v[2]) < 1.0f); }
-__device__ __forceinline__ float interp01(float r, float rmin, float inv_nrmin) { return clampT((r - rmin) * inv_nrmin, 0.0f, 1.0f); }
-
-// ---- SoA access through buffer resources ------------------------------------------------
-// Field f of env (first + lane) of a [F][L] buffer lives at byte (f*L + first + lane)*sizeof(E).
-// `first` and L are wave-uniform, so the access is issued as
-//     buffer_load/store  vdata, voffset = lane*sizeof(E), s[rsrc], soffset = (f*L + first)*sizeof(E)
-// with the 128-bit descriptor and soffset in SGPRs (built once per wave by the SALU).  The
-// equivalent global_load through a pointer makes hipcc chain 64-bit VALU address arithmetic
-// per access (v_mad_u64_u32 / v_lshl_add_u64: ~110 of the ~1100 instructions of the step).
-// soffset is 32-bit: every SoA buffer must be < 4 GiB (checked on the host, QR_E_SIZE).
-typedef int v2i_t __attribute__((ext_vector_type(2)));
-
-template <typename E>
-struct SoA {
-  __amdgpu_buffer_rsrc_t rsrc;
-  unsigned L;  // elements between fields
-  __device__ __forceinline__ SoA(const void* base, int fields, int64_t ld)
-      : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)((int64_t)fields * ld * (int64_t)sizeof(E) > 0x7fffffffLL ? 0x7fffffffLL : (int64_t)fields * ld * (int64_t)sizeof(E)), 0x00020000)),
-        L((unsigned)ld) {}
-  __device__ __forceinline__ unsigned soff(int f, unsigned first) const { return ((unsigned)f * L + first) * (unsigned)sizeof(E); }
-  __device__ __forceinline__ E load(int f, unsigned first, unsigned lane) const {
-    if constexpr (sizeof(E) == 4) {
-      return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4u, soff(f, first), 0));
-    } else {
-      return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane * 8u, soff(f, first), 0));
-    }
-  }
-  __device__ __forceinline__ void store(int f, unsigned first, unsigned lane, E v) const {
-    if constexpr (sizeof(E) == 4) {
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsrc, lane * 4u, soff(f, first), 0);
-    } else {
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_t, v), rsrc, lane * 8u, soff(f, first), 0);
-    }
-  }
-};
-
-template <typename XV, typename QW, typename T>
-__device__ __forceinline__ void load_state(const Args& a, int64_t first64, unsigned lane, Work<T>& w) {
-  const SoA<XV> pv(a.pos_vel, 6, a.ld);
-  const SoA<QW> ar(a.att_rate, 7, a.ld);
-  const unsigned first = (unsigned)first64;
-#pragma unroll
-  for (int f = 0; f < 3; ++f) { w.x[f] = T(pv.load(f, first, lane)); w.y[f] = T(pv.load(3 + f, first, lane)); }
-#pragma unroll
-  for (int f = 0; f < 7; ++f) w.y[3 + f] = T(ar.load(f, first, lane));
-}
-
-template <typename XV, typename QW, typename T>
-__device__ __forceinline__ void store_state(const Args& a, int64_t first64, unsigned lane, const Work<T>& w) {
-  const SoA<XV> pv(a.pos_vel, 6, a.ld);
-  const SoA<QW> ar(a.att_rate, 7, a.ld);
-  const unsigned first = (unsigned)first64;
-#pragma unroll
-  for (int f = 0; f < 3; ++f) { pv.store(f, first, lane, (XV)w.x[f]); pv.store(3 + f, first, lane, (XV)w.y[f]); }
-#pragma unroll
-  for (int f = 0; f < 7; ++f) ar.store(f, first, lane, (QW)w.y[3 + f]);
-}
-
-template <typename T>
-__device__ __forceinline__ void idle_work(Work<T>& w) {  // lanes past the ragged tail
-#pragma unroll
-  for (int f = 0; f < 3; ++f) w.x[f] = T(0);
-#pragma unroll
-  for (int f = 0; f < 10; ++f) w.y[f] = T(f == 3 ? 1 : 0);
-#pragma unroll
-  for (int f = 0; f < 12; ++f) w.goal[f] = f == 6 ? 1.0f : 0.0f;
-#pragma unroll
-  for (int f = 0; f < 8; ++f) w.integ[f] = 0.0f;
-#pragma unroll
-  for (int f = 0; f < 6; ++f) w.prm[f] = 0.0f;
-  w.nominal = true;
-}
-
-// ------------------------------------------------------------------------------------
-// PPO actor in the loop (qr_rollout_actor)
-// ------------------------------------------------------------------------------------
-// tanh for the action mean: (1 - e) / (1 + e), e = exp(-2|x|), sign restored.  Absolute error
-// <= 2e-7 (v_exp_f32 + v_rcp_f32); branch-free, unlike the OCML tanhf (three regimes).
-__device__ __forceinline__ float tanh_fast(float x) {
-  const float e = __expf(-2.0f * fabsf(x));
-  const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
-  return copysignf(t, x);
-}
-
-// MLP_Actor_PPO.forward (ppo_mlp.py:30-43): tanh(mean_linear(relu(fc2(relu(fc1(x)))))).  One lane
-// = one env = one row of the batch.  The weights are wave-uniform: they are copied once per launch
-// into LDS, TRANSPOSED to [in][out] (out padded to a multiple of 4), and every lane reads the
-// same address — broadcast ds_read_b128, no bank conflicts, 4 weights per LDS instruction.
-// A layer is evaluated input-major: for each input k, all `out` accumulators take one FMA, so
-// consecutive FMAs are independent (16 chains in flight).  Output-major — each neuron's 23-term
-// dot product as one dependent FMA chain — measures 3x slower here: with one wave per SIMD
-// nothing hides the ~10-cycle dependent-FMA latency.
-template <int D, int H, int A>
-struct ActorLds {
-  static constexpr int HP = (H + 3) & ~3, AP = (A + 3) & ~3;
-  static constexpr int O_FC1W = 0, O_FC1B = O_FC1W + D * HP, O_FC2W = O_FC1B + HP, O_FC2B = O_FC2W + H * HP,
-                       O_MW = O_FC2B + HP, O_MB = O_MW + H * AP, O_LS = O_MB + AP, SIZE = O_LS + AP;
-
-  __device__ static void fill(float* sm, const ActorW& p, int tid) {  // sm[k][j] = W[j][k]
-    for (int i = tid; i < D * HP; i += 64) { const int k = i / HP, j = i - k * HP; sm[O_FC1W + i] = j < H ? p.fc1_w[j * D + k] : 0.0f; }
-    for (int i = tid; i < H * HP; i += 64) { const int k = i / HP, j = i - k * HP; sm[O_FC2W + i] = j < H ? p.fc2_w[j * H + k] : 0.0f; }
-    for (int i = tid; i < H * AP; i += 64) { const int k = i / AP, j = i - k * AP; sm[O_MW + i] = j < A ? p.mean_w[j * H + k] : 0.0f; }
-    if (tid < HP) { sm[O_FC1B + tid] = tid < H ? p.fc1_b[tid] : 0.0f; sm[O_FC2B + tid] = tid < H ? p.fc2_b[tid] : 0.0f; }
-    if (tid < AP) { sm[O_MB + tid] = tid < A ? p.mean_b[tid] : 0.0f; sm[O_LS + tid] = tid < A ? p.log_std[tid] : 0.0f; }
-  }
-
-  template <int NI, int NO, int NOP>
-  __device__ __forceinline__ static void layer(const float* w, const float* bias, const float (&x)[NI], float (&y)[NO]) {
-#pragma unroll
-    for (int j = 0; j < NO; ++j) y[j] = bias[j];
-#pragma unroll
-    for (int k = 0; k < NI; ++k) {
-#pragma unroll
-      for (int j = 0; j < NO; ++j) y[j] = fmaf(w[k * NOP + j], x[k], y[j]);
-    }
-  }
-
-  __device__ __forceinline__ static void mean(const float* sm, const float (&x)[D], float (&out)[A]) {
-    float h1[H], h2[H];
-    layer<D, H, HP>(sm + O_FC1W, sm + O_FC1B, x, h1);
-#pragma unroll
-    for (int j = 0; j < H; ++j) h1[j] = fmaxf(h1[j], 0.0f);
-    layer<H, H, HP>(sm + O_FC2W, sm + O_FC2B, h1, h2);
-#pragma unroll
-    for (int j = 0; j < H; ++j) h2[j] = fmaxf(h2[j], 0.0f);
-    layer<H, A, AP>(sm + O_MW, sm + O_MB, h2, out);
-#pragma unroll
-    for (int j = 0; j < A; ++j) out[j] = tanh_fast(out[j]);
-  }
-};
-
-// The 16-wide actor on the matrix cores.  Evaluated per-lane on the VALU the three layers are
-// 688 FMAs per env-step whose 744 wave-uniform weights have to be re-delivered every step
-// (LDS broadcast reads or scalar loads): with the step kernel at its VGPR limit only two
-// ds_read_b128 fit in flight and the evaluation measures 3.8 us, LDS-latency-bound.  As a
-// transposed GEMM  H^T[16 x 64 envs] = W[16 x K] . X^T[K x 64]  on v_mfma_f32_16x16x4_f32 (exact f32)
-// the weights are the A operand and stay RESIDENT in 14 registers per lane for the whole
-// rollout; only the observations move (one LDS read per MFMA for the first layer).
-//   lane l: c = l & 15, g = l >> 4.   A: lane supplies A[c][k = g].  B: B[k = g][c].
-//   D: lane holds D[4 g + r][c], r = 0..3.  The 64 envs are 4 column blocks b of 16.
-//   layer 1: A = W1[c][4 s + g] (k-step s), B = X[env 16 b + c][4 s + g] from the LDS obs tile,
-//            D_b = h1[b][r] = H1[4 g + r][env 16 b + c].
-//   layer 2: the lane's h1[b][s] IS a B operand if k-step s is given the hidden units
-//            k(s, g) = 4 g + s, so A = W2[c][4 g + s]: no data movement between layers.
-//   layer 3: block b uses A_b = W3 placed in rows 4 b .. 4 b + 3 (zero elsewhere) and all blocks
-//            accumulate into ONE D: lane (g, c) then holds mean[r] of env 16 g + c — its own env.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-template <int D>  // obs_dim 23 (COUPLED) or 15 (DECOUPLED agent 1); hidden 16, 4 actions
-struct ActorMfma {
-  static constexpr int KS = (D + 3) / 4;
-  float a1[KS], a2[4], w3[4], bias1[4], bias2[4], bias3[4], log_std[4];
-
-  __device__ __forceinline__ void load(const ActorW& p, int lane) {
-    const int c = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) a1[s] = (4 * s + g < D) ? p.fc1_w[c * D + 4 * s + g] : 0.0f;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) { a2[s] = p.fc2_w[c * 16 + 4 * g + s]; w3[s] = p.mean_w[(c & 3) * 16 + 4 * g + s]; }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      bias1[r] = p.fc1_b[4 * g + r]; bias2[r] = p.fc2_b[4 * g + r]; bias3[r] = p.mean_b[r]; log_std[r] = p.log_std[r];
-    }
-  }
-
-  // xs: LDS tile [64 envs][D] of the wave's observations (row = lane)
-  __device__ __forceinline__ void mean(const float* xs, int lane, float (&out)[4]) const {
-    const int c = lane & 15, g = lane >> 4;
-    f32x4 h1[4], h2[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      h1[b] = f32x4{bias1[0], bias1[1], bias1[2], bias1[3]};
-      h2[b] = f32x4{bias2[0], bias2[1], bias2[2], bias2[3]};
-    }
-    // all B operands of the first layer are requested before the first MFMA (the reads are
-    // unconditional: past the last feature the address is clamped and the weight a1 is 0)
-    float x[KS][4];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int k = (4 * s + g < D) ? 4 * s + g : D - 1;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) x[s][b] = xs[(16 * b + c) * D + k];
-    }
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b) h1[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], x[s][b], h1[b], 0, 0, 0);
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b) h2[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[s], fmaxf(h1[b][s], 0.0f), h2[b], 0, 0, 0);
-    }
-    f32x4 m0 = f32x4{bias3[0], bias3[1], bias3[2], bias3[3]}, m1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};  // two chains
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const float w = ((c >> 2) == b) ? w3[s] : 0.0f;
-        f32x4& m = (b & 1) ? m1 : m0;
-        m = __builtin_amdgcn_mfma_f32_16x16x4f32(w, fmaxf(h2[b][s], 0.0f), m, 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) out[r] = tanh_fast(m0[r] + m1[r]);
-  }
-};
-
-// PPO.choose_action (ppo.py:93-101): a = clamp(mean + exp(log_std) eps, +-max_action) and the
-// per-component Normal(mean, std).log_prob of the clamped action (ppo.py:97-98).
-template <int A>
-__device__ __forceinline__ void actor_sample(const float* log_std, const float (&mean)[A], const float* eps, bool deterministic,
-                                             float max_action, float* act, float* logp) {
-#pragma unroll
-  for (int j = 0; j < A; ++j) {
-    const float ls = log_std[j];
-    const float sd = __expf(ls);
-    const float raw = deterministic ? mean[j] : fmaf(sd, eps[j], mean[j]);
-    const float aj = fminf(fmaxf(raw, -max_action), max_action);
-    const float z = (aj - mean[j]) * __expf(-ls);
-    act[j] = aj;
-    logp[j] = fmaf(-0.5f * z, z, -ls - 0.91893853320467274f);
-  }
-}
-
-// 4 standard normals per Philox block (Box-Muller).  Stream: (noise_seed, global env id, global
-// step, 0x80000000 | block) — the top bit keeps it apart from the reset stream (seed, id, episode, b).
-__device__ __forceinline__ void normal4(float (&z)[4], uint64_t seed, uint64_t gid, uint64_t step, uint32_t block) {
-  uint32_t ctr[4] = {(uint32_t)gid, (uint32_t)(gid >> 32) ^ (uint32_t)(step >> 32), (uint32_t)step, 0x80000000u | block};
-  philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const float u1 = fmaf((float)(ctr[2 * h] >> 8), 0x1p-24f, 0x1p-25f);   // (0, 1)
-    const float u2 = fmaf((float)(ctr[2 * h + 1] >> 8), 0x1p-24f, 0x1p-25f);
-    const float r = sqrtf(-2.0f * __logf(u1));
-    float sn, cs;
-    sincos_small(6.283185307179586f * u2, sn, cs);
-    z[2 * h] = r * cs; z[2 * h + 1] = r * sn;
-  }
-}
 
 // ------------------------------------------------------------------------------------
 // The fused step / rollout kernel

@@ -233,6 +233,31 @@ class QuadVecEnv:
             actions = actions.clone()
         return actions
 
+    def _check_out(self, out: dict, lead: tuple, policy: bool = False):
+        """Caller-owned output tensors are written by raw pointer: validate shape, dtype, device and
+        contiguity (a mismatch would silently corrupt memory)."""
+        N, dev = self.num_envs, self.device
+        want = {"reward": (lead + (N, self.n_agents), torch.float32), "terminated": (lead + (N, self.n_agents), torch.bool)}
+        if self.obs_rows or self.kind != "quad":
+            want["obs0"] = (lead + (N, self.obs_dims[0]), torch.float32)
+        if len(self.obs_dims) > 1:
+            want["obs1"] = (lead + (N, self.obs_dims[1]), torch.float32)
+        if policy:
+            want["action"] = (lead + (N, self.action_dim), torch.float32)
+        optional = {"reward_raw": (lead + (N, self.n_agents), torch.float32), "truncated": (lead + (N,), torch.bool),
+                    "logprob": (lead + (N, self.action_dim), torch.float32)}
+        for k, (shape, dtype) in list(want.items()) + [(k, v) for k, v in optional.items() if out.get(k) is not None]:
+            t = out.get(k)
+            if t is None:
+                if k == "obs0" and self.kind == "quad":
+                    continue
+                raise ValueError(f"out[{k!r}] is required")
+            if tuple(t.shape) != shape or t.dtype != dtype or t.device != dev or not t.is_contiguous():
+                raise ValueError(f"out[{k!r}] must be a contiguous {dtype} tensor of shape {shape} on {dev}, got "
+                                 f"{tuple(t.shape)} {t.dtype} on {t.device}")
+        if self._steps is not None and out.get("truncated") is None:
+            raise ValueError("out['truncated'] is required when max_episode_steps is set")
+
     def _obs(self):
         if self._obs0 is None:  # kind='quad' without observation rows: fetch with get_current_state()
             return None
@@ -250,11 +275,8 @@ class QuadVecEnv:
             _lib.check(rc, "qr_step")
             self._last_obs = self._obs()
             return self._last_obs, self._reward, self._done, self._trunc, {}
+        self._check_out(out, ())
         o = _lib.QrStepOut()
-        for k in ("obs0", "obs1", "reward", "terminated", "truncated"):
-            t = out.get(k)
-            if t is not None and (not t.is_contiguous() or t.device != self.device):
-                raise ValueError(f"out[{k!r}] must be a contiguous tensor on {self.device}")
         o.obs0, o.obs1, o.reward = _ptr(out.get("obs0")), _ptr(out.get("obs1")), _ptr(out["reward"])
         o.reward_raw, o.done = _ptr(out.get("reward_raw")), _ptr(out["terminated"])
         o.truncated = _ptr(out.get("truncated")) if self._steps is not None else None
@@ -279,6 +301,8 @@ class QuadVecEnv:
                    "truncated": torch.zeros(T, N, dtype=torch.bool, device=dev)}
             if self._obs1 is not None:
                 out["obs1"] = torch.empty(T, N, self.obs_dims[1], dtype=torch.float32, device=dev)
+        else:
+            self._check_out(out, (T,))
         o = _lib.QrStepOut()
         o.obs0, o.obs1, o.reward = _ptr(out.get("obs0")), _ptr(out.get("obs1")), _ptr(out["reward"])
         o.reward_raw, o.done = _ptr(out.get("reward_raw")), _ptr(out["terminated"])
@@ -337,6 +361,8 @@ class QuadVecEnv:
                    "truncated": torch.zeros(T, N, dtype=torch.bool, device=dev)}
             if len(self.obs_dims) > 1:
                 out["obs1"] = torch.empty(T, N, self.obs_dims[1], dtype=torch.float32, device=dev)
+        else:
+            self._check_out(out, (T,), policy=True)
         arr = _policy.c_actor_array(actors)
         pol = _lib.QrPolicyRollout()
         pol.actors = arr

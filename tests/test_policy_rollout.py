@@ -204,3 +204,12 @@ def test_rollout_actor_api_errors():
         QuadVecEnv("quad", 64, device="cuda", obs_rows=True).rollout_actor(actors, 4)
     out = env.rollout_actor(actors, 4)
     assert out["action"].shape == (4, 64, 4) and out["obs0"].shape == (4, 64, 23)
+    # caller-owned outputs are written by raw pointer: anything but the exact contiguous tensor is refused
+    for key, bad in (("action", torch.empty(4, 64, 8, device="cuda")[..., :4]), ("reward", out["reward"].double()),
+                     ("obs0", out["obs0"][:3]), ("terminated", out["terminated"].cpu())):
+        with pytest.raises(ValueError):
+            env.rollout_actor(actors, 4, out={**{k: v for k, v in out.items() if k != "obs"}, key: bad})
+    with pytest.raises(ValueError):
+        env.rollout(out["action"], out={k: v for k, v in out.items() if k not in ("obs", "reward")})
+    with pytest.raises(ValueError):
+        env.step(out["action"][0], out={"obs0": out["obs0"][0], "reward": out["reward"][0, :, 0], "terminated": out["terminated"][0]})
