@@ -11,30 +11,39 @@ namespace qr {
 
 // ------------------------------------------------------------------------------------
 // Goal generation: utils/trajectory_generator.py modes 0 and 1, per env.
-// tr[8] = {calls, theta_init, b1d_x | w_b1d, b1d_y | smooth_term, x_init[3], -}
+// Generator state per env, stored as traj[8][N] = {calls, theta_init, b1d_x | w_b1d, b1d_y | smooth_term,
+// x_init[3], -}.  Named scalars, not an array: the episode-start branch writes it under divergent
+// control flow, and as an array hipcc kept two of its words in scratch memory.
 // ------------------------------------------------------------------------------------
+struct Traj {
+  float calls = 0.0f, theta_init = 0.0f, p2 = 0.0f, p3 = 0.0f, x0 = 0.0f, x1 = 0.0f, x2 = 0.0f;
+  __device__ __forceinline__ float get(int f) const { return f == 0 ? calls : f == 1 ? theta_init : f == 2 ? p2 : f == 3 ? p3 : f == 4 ? x0 : f == 5 ? x1 : f == 6 ? x2 : 0.0f; }
+  __device__ __forceinline__ void set(int f, float v) {
+    if (f == 0) calls = v; else if (f == 1) theta_init = v; else if (f == 2) p2 = v; else if (f == 3) p3 = v;
+    else if (f == 4) x0 = v; else if (f == 5) x1 = v; else if (f == 6) x2 = v;
+  }
+};
+
 // mark_traj_start(state) (:176-204) + the episode-start branch of calculate_desired:
 //   mode 0 (:141-148): b1d = Rz(theta) b1_proj, theta ~ U(+-25 deg)
 //   mode 1 (:253-266): x_init = x, t_traj ~ U(2,5), smooth = -ln(0.001)/t_traj, w_b1d ~ U(+-0.15 pi)
 template <typename T>
-__device__ __forceinline__ void traj_start(const Work<T>& w, float (&tr)[8], int goal_mode, float theta_b1d, float t_traj, float w_b1d) {
+__device__ __forceinline__ void traj_start(const Work<T>& w, Traj& tr, int goal_mode, float theta_b1d, float t_traj, float w_b1d) {
   const T qw = w.y[3], qx = w.y[4], qy = w.y[5], qz = w.y[6];
   const float b1x = (float)(T(1) - T(2) * (qy * qy + qz * qz)), b1y = (float)(T(2) * (qx * qy + qw * qz));
   const float theta_init = atan2f(b1y, b1x);  // update_initial_state (:199-204)
-  tr[0] = 0.0f;
-  tr[1] = theta_init;
+  tr.calls = 0.0f;
+  tr.theta_init = theta_init;
   if (goal_mode == QR_GOAL_MODE0) {
     float sn, cs;
     sincos_small(theta_init + theta_b1d, sn, cs);  // Rz(theta) (cos th_i, sin th_i, 0)
-    tr[2] = cs; tr[3] = sn;
-    tr[4] = tr[5] = tr[6] = 0.0f;
+    tr.p2 = cs; tr.p3 = sn;
+    tr.x0 = tr.x1 = tr.x2 = 0.0f;
   } else {  // mode 1: x_init + draws; mode 6: eight_shaped_center = x (:430), no draws
-    tr[2] = w_b1d;
-    tr[3] = 6.907755278982137f / t_traj;  // -ln(0.001) / t_traj
-#pragma unroll
-    for (int j = 0; j < 3; ++j) tr[4 + j] = (float)w.x[j];
+    tr.p2 = w_b1d;
+    tr.p3 = 6.907755278982137f / t_traj;  // -ln(0.001) / t_traj
+tr.x0 = (float)w.x[0]; tr.x1 = (float)w.x[1]; tr.x2 = (float)w.x[2];
   }
-  tr[7] = 0.0f;
 }
 
 // Draws of an episode start that the reset sampler leaves unused (word 19 of the env's Philox
@@ -48,41 +57,42 @@ __device__ __forceinline__ void traj_draws(uint32_t r19, float& theta_b1d, float
 // get_desired(state, mode) (:113-173) for the state in w: advances the call counter, fills
 // w.goal = (xd, vd, b1d, Wd) and returns b1d_dot.
 template <typename T>
-__device__ __forceinline__ void traj_goal(Work<T>& w, float (&tr)[8], int goal_mode, const Coeffs& c, float (&b1d_dot)[3]) {
-  tr[0] += 1.0f;  // update_current_time (:224-229): t = t + dt on every call
+__device__ __forceinline__ void traj_goal(Work<T>& w, Traj& tr, int goal_mode, const Coeffs& c, float (&b1d_dot)[3]) {
+  tr.calls += 1.0f;  // update_current_time (:224-229): t = t + dt on every call
   float b1d[3];
   if (goal_mode == QR_GOAL_MODE0) {  // set_desired_states_to_zero + the b1d drawn at episode start
 #pragma unroll
     for (int j = 0; j < 6; ++j) w.goal[j] = 0.0f;
-    b1d[0] = tr[2]; b1d[1] = tr[3]; b1d[2] = 0.0f;
+    b1d[0] = tr.p2; b1d[1] = tr.p3; b1d[2] = 0.0f;
     b1d_dot[0] = b1d_dot[1] = b1d_dot[2] = 0.0f;
   } else if (goal_mode == QR_GOAL_MODE6) {  // eight_shaped_curve (:418-505)
-    const float t = fminf(tr[0] * (float)c.dt, c.e8_tmax);
+    const float t = fminf(tr.calls * (float)c.dt, c.e8_tmax);
     const float ek = expf(-c.e8_k * t);
     const float e = 1.0f - ek, de = c.e8_k * ek;  // exp_term, d/dt exp_term
     float s1, c1, s2, c2;
     sincos_small(c.e8_w1 * t, s1, c1);
     sincos_small(c.e8_w2 * t, s2, c2);
-    const float za = 0.5f * (tr[6] - c.e8_alt);  // synchronised altitude command (:487-492)
-    w.goal[0] = fmaf(c.e8_A2 * s2, e, tr[4]);
-    w.goal[1] = fmaf(c.e8_A1 * (c1 - 1.0f), e, tr[5]);
-    w.goal[2] = fmaf(za, 1.0f - c1, tr[6]);
+    const float za = 0.5f * (tr.x2 - c.e8_alt);  // synchronised altitude command (:487-492)
+    w.goal[0] = fmaf(c.e8_A2 * s2, e, tr.x0);
+    w.goal[1] = fmaf(c.e8_A1 * (c1 - 1.0f), e, tr.x1);
+    w.goal[2] = fmaf(za, 1.0f - c1, tr.x2);
     w.goal[3] = c.e8_A2 * (c.e8_w2 * c2 * e + s2 * de);
     w.goal[4] = c.e8_A1 * (-c.e8_w1 * s1 * e + (c1 - 1.0f) * de);
     w.goal[5] = za * c.e8_w1 * s1;
-    const float term = fmaf(c.e8_wb * t, e, tr[1]), dterm = c.e8_wb * (e + t * de);  // yaw (:494-498)
+    const float term = fmaf(c.e8_wb * t, e, tr.theta_init), dterm = c.e8_wb * (e + t * de);  // yaw (:494-498)
     float sn, cs;
     sincos_small(term, sn, cs);
     b1d[0] = cs; b1d[1] = sn; b1d[2] = 0.0f;
     b1d_dot[0] = -sn * dterm; b1d_dot[1] = cs * dterm; b1d_dot[2] = 0.0f;
   } else {  // hovering (:268-277), x_goal = 0
-    const float t = tr[0] * (float)c.dt;
-    const float wb = tr[2], sm = tr[3];
+    const float t = tr.calls * (float)c.dt;
+    const float wb = tr.p2, sm = tr.p3;
     const float e = expf(-sm * t);
+const float xi[3] = {tr.x0, tr.x1, tr.x2};
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { w.goal[j] = tr[4 + j] * e; w.goal[3 + j] = -tr[4 + j] * sm * e; }
+    for (int j = 0; j < 3; ++j) { w.goal[j] = xi[j] * e; w.goal[3 + j] = -xi[j] * sm * e; }
     float sn, cs;
-    sincos_small(fmaf(wb, t, tr[1]), sn, cs);
+    sincos_small(fmaf(wb, t, tr.theta_init), sn, cs);
     b1d[0] = cs; b1d[1] = sn; b1d[2] = 0.0f;
     b1d_dot[0] = -wb * sn; b1d_dot[1] = wb * cs; b1d_dot[2] = 0.0f;
   }

@@ -116,14 +116,12 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       for (int f = 0; f < 8; ++f) w.integ[f] = integ.load(f, ufirst, lane);
     }
   }
-  float tr[8];
-#pragma unroll
-  for (int f = 0; f < 8; ++f) tr[f] = 0.0f;
+  Traj tr;
   const int goal_mode = TRAJ ? a.goal_mode : QR_GOAL_EXTERNAL;  // wave-uniform
   if (TRAJ && active) {
     const SoA<float> traj(a.traj, 8, L);
 #pragma unroll
-    for (int f = 0; f < 7; ++f) tr[f] = traj.load(f, ufirst, lane);
+    for (int f = 0; f < 7; ++f) tr.set(f, traj.load(f, ufirst, lane));
   }
   int32_t steps = (a.steps && active) ? (a.steps + first)[lane] : 0;
   // The episode counter (RNG stream id) is fetched with the rest of the working set: read
@@ -420,10 +418,10 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     if (a.steps) (a.steps + first)[lane] = steps;
     if constexpr (TRAJ) {
       const SoA<float> traj(a.traj, 8, L);
-      traj.store(0, ufirst, lane, tr[0]);
+      traj.store(0, ufirst, lane, tr.calls);
       if (params_dirty || (a.flags & QR_FLAG_AUTO_RESET)) {  // the rest changes only at a reset
 #pragma unroll
-        for (int f = 1; f < 7; ++f) traj.store(f, ufirst, lane, tr[f]);
+        for (int f = 1; f < 7; ++f) traj.store(f, ufirst, lane, tr.get(f));
       }
     }
     if (params_dirty) {
@@ -551,11 +549,11 @@ __global__ __launch_bounds__(64) void traj_start_kernel(const Args a) {
     draw20(d, a.seed, (uint64_t)(a.env_offset + i), (uint32_t)a.episode[i]);
     traj_draws(d.r[19], th, tt, wb);
   }
-  float tr[8];
+  Traj tr;
   traj_start(w, tr, a.goal_mode, th, tt, wb);
   const SoA<float> traj(a.traj, 8, a.ld);
 #pragma unroll
-  for (int f = 0; f < 8; ++f) traj.store(f, (unsigned)first, lane, tr[f]);
+  for (int f = 0; f < 8; ++f) traj.store(f, (unsigned)first, lane, tr.get(f));
 }
 
 // get_desired for the current state: rows [N][15] = xd, vd, b1d, b1d_dot, Wd
@@ -571,12 +569,12 @@ __global__ __launch_bounds__(64) void get_desired_kernel(const Args a) {
   idle_work(w);
   load_state<XV, QW, T>(a, first, lane, w);
   const SoA<float> traj(a.traj, 8, a.ld);
-  float tr[8];
+  Traj tr;
 #pragma unroll
-  for (int f = 0; f < 8; ++f) tr[f] = traj.load(f, (unsigned)first, lane);
+  for (int f = 0; f < 7; ++f) tr.set(f, traj.load(f, (unsigned)first, lane));
   float b1d_dot[3];
   traj_goal(w, tr, a.goal_mode, a.c, b1d_dot);
-  traj.store(0, (unsigned)first, lane, tr[0]);
+  traj.store(0, (unsigned)first, lane, tr.calls);
   if (a.goal_rows) {
     float* o = a.goal_rows + i * 15;
 #pragma unroll
