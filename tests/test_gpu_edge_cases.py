@@ -148,3 +148,62 @@ def test_torch_custom_ops_match_env_step():
     assert np.abs(_np(adv) - a_ref).max() <= 1e-5
     with pytest.raises(RuntimeError):
         torch.ops.gym_rotor_amd.qr_gae(r.cpu(), dn.cpu(), v.cpu(), 0.99, 0.9, adv.cpu(), tgt.cpu())
+
+
+def test_fuzz_configurations_vs_oracle():
+    """48 random configurations — kind x layout x substeps x batch size (ragged tails, N = 1) x field
+    stride x with/without per-env parameters and goals x step()/rollout() — each run a few steps
+    against the oracle.  Catches interactions the targeted tests do not enumerate."""
+    rng = np.random.default_rng(2024)
+    for trial in range(48):
+        kind = orc.KINDS[rng.integers(3)]
+        layout = ("f64", "mixed")[rng.integers(2)]
+        n = int(rng.choice([1, 2, 63, 64, 65, 127, 200, 333, 640, 701]))
+        S = int(rng.integers(1, 4))
+        T = int(rng.integers(1, 5))
+        use_params, use_goal, use_rollout = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
+        stride = None if rng.integers(2) else 4 * ((n + int(rng.integers(1, 70)) + 3) // 4)
+        A = orc.ACTION_DIM[kind]
+        env = _env(kind, n, layout=layout, substeps=S, use_UDM=use_params, obs_rows=True, field_stride=stride)
+        state = orc.sample_reset_state(rng, n).astype(np.float32).astype(np.float64)
+        params = orc.sample_params(rng, n).astype(np.float32).astype(np.float64) if use_params else None
+        integ = rng.uniform(-0.5, 0.5, (n, 8)).astype(np.float32).astype(np.float64)
+        env.set_state(state, integ=integ, params=params)
+        state = _np(env.get_current_state())
+        goal = None
+        if use_goal:
+            goal = np.tile(orc.DEFAULT_GOAL, (n, 1))
+            goal[:, 0:3] = rng.uniform(-0.3, 0.3, (n, 3)); goal[:, 3:6] = rng.uniform(-0.5, 0.5, (n, 3))
+            psi = rng.uniform(-np.pi, np.pi, n)
+            goal[:, 6:9] = np.stack([np.cos(psi), np.sin(psi), np.zeros(n)], 1)
+            goal[:, 9:12] = rng.uniform(-0.5, 0.5, (n, 3))
+            goal = goal.astype(np.float32).astype(np.float64)
+            g = torch.from_numpy(goal).float().cuda()
+            env.set_goal_state(g[:, 0:3], g[:, 3:6], g[:, 6:9], None, g[:, 9:12])
+        acts = rng.uniform(-1, 1, (T, n, A)).astype(np.float32)
+        tag = f"trial {trial}: {kind}/{layout} N={n} S={S} T={T} params={use_params} goal={use_goal} rollout={use_rollout} stride={stride}"
+        if use_rollout:
+            ro = env.rollout(torch.from_numpy(acts).cuda())
+            rwd_all, done_all, obs_last = _np(ro["reward"]), _np(ro["terminated"]), ro["obs0"][T - 1]
+        else:
+            rw, dn = [], []
+            for t in range(T):
+                obs, r, d, _, _ = env.step(torch.from_numpy(acts[t]).cuda())
+                rw.append(_np(r).copy()); dn.append(_np(d).copy())
+            rwd_all, done_all = np.stack(rw), np.stack(dn)
+            obs_last = obs if isinstance(obs, torch.Tensor) else obs[0]
+        s, it = state, integ
+        for t in range(T):
+            o = orc.step_batch(kind, s, acts[t].astype(np.float64), params, goal, it, n_sub=1)
+            s, it = o["state"], o["integ"]
+            # a done flag may differ only where its deciding quantity sits on the threshold
+            mism = done_all[t] != o["done"]
+            assert mism.sum() == 0, tag
+            assert np.abs(rwd_all[t] - o["reward"]).max() <= 2e-5, tag
+        assert grouped_rel_err(_np(env.get_current_state()), s) <= (2e-7 if layout == "f64" else 1e-6), tag
+        ref_obs = np.asarray(o["obs"][0], np.float64)
+        if kind == "quad":
+            ref_obs = s
+        assert np.abs(_np(obs_last).astype(np.float64) - ref_obs).max() <= 5e-6, tag
+        if kind != "quad":
+            assert np.abs(_np(env._integ[:, :n]).T - it).max() <= 1e-6, tag
