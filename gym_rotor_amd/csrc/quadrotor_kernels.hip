@@ -129,6 +129,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   // critical path of every wave that has a resetting lane.
   int32_t episode = ((a.flags & QR_FLAG_AUTO_RESET) && active) ? (a.episode + first)[lane] : 0;
   bool params_dirty = false;
+  bool traj_dirty = false;  // this lane started a new episode: its generator state changed
 
   // Action rows [N][A] -> lane registers.  A = 4: one 16-byte load per lane.  A = 5: five dword
   // loads per lane (a wave covers 1280 contiguous bytes; L1 merges the sectors).  In a rollout
@@ -362,6 +363,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
           traj_draws(d.r[19], th, tt, wb);
           traj_start(w, tr, goal_mode, th, tt, wb);
           traj_goal(w, tr, goal_mode, c, b1d_dot);
+          traj_dirty = true;
         }
         quat_to_R(&w.y[3], R);
         if constexpr (KIND != QR_KIND_QUAD) {
@@ -419,7 +421,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     if constexpr (TRAJ) {
       const SoA<float> traj(a.traj, 8, L);
       traj.store(0, ufirst, lane, tr.calls);
-      if (params_dirty || (a.flags & QR_FLAG_AUTO_RESET)) {  // the rest changes only at a reset
+      if (traj_dirty) {  // the rest changes only at a reset
 #pragma unroll
         for (int f = 1; f < 7; ++f) traj.store(f, ufirst, lane, tr.get(f));
       }
@@ -711,8 +713,10 @@ static void launch_kind(const Args& a, hipStream_t s) {
       return;
     }
   }
-  if (a.goal_mode != QR_GOAL_EXTERNAL) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-  else if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+  if (a.goal_mode != QR_GOAL_EXTERNAL) {
+    if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+    else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, false>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+  } else if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
   else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false>), grid, dim3(64), 0, s, QR_STEP_ARGS);
 #undef QR_STEP_ARGS
 }
