@@ -23,6 +23,10 @@ launches.  `roofline.achieved` = SURVEY.md §8(d) algorithmic bytes per launch /
 `roofline.traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed under
 profiles/ (tools/profile.sh), when one exists for this configuration.
 
+Secondary figures under `config` (rank 0, --extras 1): the other reset mode, the fused `rollout(T=100)`,
+and `policy_rollout_coupled_T32` — BASELINE configs[2]'s PPO collection loop with the actor inside the
+step kernel (qr_rollout_actor).
+
 `cpu_baseline` (rank 0, N=1 only) times the oracle's reference-style single-env path (NumPy RHS
 + scipy DOP853 + ensure_SO3, reset-on-done; oracle/quad_oracle.py) on one host core for ~12 s.
 """
@@ -245,6 +249,23 @@ def main():
             e0.record(); env.rollout(acts, out=ro); e1.record(); torch.cuda.synchronize(dev)
             out["config"]["rollout_T100"] = {"env_steps_per_s": N * 100 / (e0.elapsed_time(e1) * 1e-3),
                                              "us_per_env_step_batch": e0.elapsed_time(e1) * 10.0}
+            # secondary figure: the PPO collection loop of BASELINE configs[2] with the actor inside the
+            # step kernel (qr_rollout_actor): CoupledWrapper, T = 32 steps per launch, auto-reset, in-kernel noise
+            from gym_rotor_amd import random_actors
+            penv = QuadVecEnv("coupled", N, device=dev, seed=0, substeps=a.substeps, layout=a.layout, auto_reset=True, obs_rows=True)
+            penv.reset("train")
+            penv.get_norm_error_state()
+            actors = random_actors("coupled", dev, generator=torch.Generator(device=dev).manual_seed(7), log_std=-0.5)
+            po = penv.rollout_actor(actors, 32)
+            torch.cuda.synchronize(dev)
+            best = 1e9
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); penv.rollout_actor(actors, 32, out={k: v for k, v in po.items() if k != "obs"}); e1.record()
+                torch.cuda.synchronize(dev)
+                best = min(best, e0.elapsed_time(e1))
+            out["config"]["policy_rollout_coupled_T32"] = {"env_steps_per_s": N * 32 / (best * 1e-3), "us_per_env_step_batch": best * 1e3 / 32,
+                                                           "what": "CoupledWrapper env + 23->16->16->4 PPO actor (MFMA) + sampling in one launch per horizon"}
         if n_gpus == 1 and a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(a.kind, a.cpu_seconds)
         print(json.dumps(out))
