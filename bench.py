@@ -129,6 +129,13 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    if not os.path.exists(os.path.join(ROOT, "gym_rotor_amd", "libquadrotor_hip.so")) and not os.environ.get("QR_LIB"):
+        # a checkout without the (git-ignored) library: build it once (local rank 0), others wait
+        import subprocess
+        if local_rank == 0:
+            subprocess.run(["make", "-C", os.path.join(ROOT, "gym_rotor_amd", "csrc")], check=True, stdout=sys.stderr)
+        if dist is not None:
+            dist.barrier()
     from gym_rotor_amd import ALGO_BYTES, QuadVecEnv
     from gym_rotor_amd.constants import ALGO_BYTES_PARAMS
     N = a.envs
