@@ -105,7 +105,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       for (int f = 0; f < 6; ++f) w.prm[f] = prm.load(f, ufirst, lane);
       w.nominal = false;
     }
-    if (a.goal) {
+    if (!TRAJ && a.goal) {  // (with the fused generator the goal is formed in registers every step)
       const SoA<float> goal(a.goal, 12, L);
 #pragma unroll
       for (int f = 0; f < 12; ++f) w.goal[f] = goal.load(f, ufirst, lane);
