@@ -121,8 +121,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # QR_BENCH_BACKEND=gloo is a test hook: it lets N ranks share the GPUs that exist (rank -> device
+        # local_rank % device_count) so that the multi-rank control flow can be exercised on a 1-GPU box
+        backend = os.environ.get("QR_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % torch.cuda.device_count()
+            dist.init_process_group(backend)
     n_gpus = world
     if a.gpus != world and rank == 0:
         print(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
@@ -200,7 +207,7 @@ def main():
         return wall, dev_ms, finite, done_rate, env.kernel_info()
 
     wall, dev_ms, finite, done_rate, kinfo = run(auto_reset, True)
-    tmax = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev if dist is None or dist.get_backend() == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall, dev_ms = float(tmax[0]), float(tmax[1])

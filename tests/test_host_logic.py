@@ -281,3 +281,23 @@ def test_integration_md_binding_runs():
     assert torch.isfinite(obs).all() and obs.abs().max() <= 1.5
     assert ((rew >= 0) & (rew <= 1) | (rew == -1)).all()
     assert 0 < done.float().mean() < 0.2 or done.sum() == 0
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_control_flow():
+    """bench.py under torch.distributed.run with 2 ranks.  The box has one GPU, so the ranks share it
+    through the QR_BENCH_BACKEND=gloo hook (NCCL/RCCL refuses two ranks on one device); everything
+    else — env sharding by rank, barrier-bracketed timing, MAX over ranks, rank-0 JSON — is the
+    path the 2/4/8-GPU runs take."""
+    import json
+    env = dict(os.environ, QR_BENCH_BACKEND="gloo", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "200", "--warmup", "10",
+                        "--extras", "0"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2 * d["config"]["envs_per_gpu"] and d["scaling"] == "weak"
+    assert d["value"] > 1e9 and abs(d["value"] - d["config"]["global_envs"] * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-3 * d["value"]
+    assert "cpu_baseline" not in d                           # N = 1 only
