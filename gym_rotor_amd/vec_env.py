@@ -501,9 +501,24 @@ class QuadVecEnv:
     def state_dict(self) -> dict:
         """Checkpoint of everything the env owns (18 + 8 words per env + params/goal/counters)."""
         keys = ("_pos_vel", "_att_rate", "_integ", "_params", "_goal", "_traj", "_episode", "_steps")
-        return {k[1:]: (None if getattr(self, k) is None else getattr(self, k).clone()) for k in keys}
+        sd = {k[1:]: (None if getattr(self, k) is None else getattr(self, k).clone()) for k in keys}
+        sd["policy_steps"] = int(self._policy_steps)   # position of the in-kernel action-noise stream (rollout_actor)
+        sd["seed"] = int(self.seed)
+        if self._last_obs is not None:  # the observation the next policy action is computed from
+            last = (self._last_obs,) if isinstance(self._last_obs, torch.Tensor) else tuple(self._last_obs)
+            sd["last_obs"] = tuple(o.clone() for o in last)
+        return sd
 
     def load_state_dict(self, sd: dict):
+        sd = dict(sd)
+        self._policy_steps = int(sd.pop("policy_steps", 0))
+        if "seed" in sd:
+            self.seed = int(sd.pop("seed"))
+            self._cenv.seed = self.seed & (2 ** 64 - 1)
+        last = sd.pop("last_obs", None)
+        if last is not None:
+            last = tuple(o.to(self.device).clone() for o in last)
+            self._last_obs = last[0] if len(last) == 1 else last
         for k, v in sd.items():
             cur = getattr(self, "_" + k)
             if v is None:

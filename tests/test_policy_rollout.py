@@ -213,3 +213,24 @@ def test_rollout_actor_api_errors():
         env.rollout(out["action"], out={k: v for k, v in out.items() if k not in ("obs", "reward")})
     with pytest.raises(ValueError):
         env.step(out["action"][0], out={"obs0": out["obs0"][0], "reward": out["reward"][0, :, 0], "terminated": out["terminated"][0]})
+
+
+def test_checkpoint_resume_reproduces_the_rollout():
+    """state_dict()/load_state_dict() carry the env buffers, episode counters, the position of the
+    action-noise stream and the current observation: a resumed env continues bit-for-bit."""
+    from gym_rotor_amd import random_actors
+    n = 1500
+    actors = random_actors("decoupled", "cuda", generator=torch.Generator("cuda").manual_seed(8), log_std=-0.7)
+    env = _env("decoupled", n, seed=21, auto_reset=True, goal_mode=1)
+    env.reset("train")
+    env.get_desired(store_goal=True)
+    env.get_norm_error_state()
+    env.rollout_actor(actors, 20)
+    sd = env.state_dict()
+    want = env.rollout_actor(actors, 30)
+    twin = _env("decoupled", n, seed=999, auto_reset=True, goal_mode=1)   # different seed: must come from the checkpoint
+    twin.load_state_dict(sd)
+    got = twin.rollout_actor(actors, 30)
+    for k in ("obs0", "obs1", "action", "logprob", "reward", "terminated"):
+        assert torch.equal(got[k], want[k]), k
+    assert torch.equal(twin.get_current_state(), env.get_current_state())
