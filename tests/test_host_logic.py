@@ -301,3 +301,14 @@ def test_bench_multi_rank_control_flow():
     assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2 * d["config"]["envs_per_gpu"] and d["scaling"] == "weak"
     assert d["value"] > 1e9 and abs(d["value"] - d["config"]["global_envs"] * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-3 * d["value"]
     assert "cpu_baseline" not in d                           # N = 1 only
+
+
+@pytest.mark.gpu
+def test_readme_quick_start_runs():
+    text = open(os.path.join(ROOT, "README.md")).read()
+    block = re.search(r"```python\n(import torch\nfrom gym_rotor_amd import.*?)```", text, re.S).group(1)
+    ns = {}
+    exec(block, ns)
+    torch.cuda.synchronize()
+    assert ns["obs"].shape == (65536, 23) and ns["horizon"]["action"].shape == (32, 65536, 4)
+    assert torch.isfinite(ns["horizon"]["obs0"]).all()
