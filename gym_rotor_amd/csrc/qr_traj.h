@@ -137,6 +137,10 @@ __device__ __forceinline__ float interp01(float r, float rmin, float inv_nrmin) 
 // soffset is 32-bit: every SoA buffer must be < 4 GiB (checked on the host, QR_E_SIZE).
 typedef int v2i_t __attribute__((ext_vector_type(2)));
 
+#ifndef QR_STORE_AUX
+#define QR_STORE_AUX 0  // cache policy of the SoA stores (gfx940+ aux bits: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
+
 template <typename E>
 struct SoA {
   __amdgpu_buffer_rsrc_t rsrc;
@@ -154,9 +158,9 @@ struct SoA {
   }
   __device__ __forceinline__ void store(int f, unsigned first, unsigned lane, E v) const {
     if constexpr (sizeof(E) == 4) {
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsrc, lane * 4u, soff(f, first), 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsrc, lane * 4u, soff(f, first), QR_STORE_AUX);
     } else {
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_t, v), rsrc, lane * 8u, soff(f, first), 0);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_t, v), rsrc, lane * 8u, soff(f, first), QR_STORE_AUX);
     }
   }
 };

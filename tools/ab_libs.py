@@ -13,13 +13,13 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
-import json, sys, torch
+import json, os, sys, torch
 sys.path.insert(0, %r)
 from gym_rotor_amd import QuadVecEnv
 dev = torch.device("cuda", 0)
 K, R = 100, 8
 out = {}
-for n in (65536, 1048576):
+for n in [int(x) for x in os.environ.get('QR_AB_SIZES', '65536,1048576').split(',')]:
     for kind in ("quad", "coupled", "decoupled"):
         for ar in (1, 0):
             env = QuadVecEnv(kind, n, device=dev, auto_reset=bool(ar), obs_rows=(kind != "quad"))
