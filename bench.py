@@ -66,10 +66,12 @@ def parse():
     return p.parse_args()
 
 
-def cpu_baseline(kind: str, seconds: float):
-    """Oracle ('port' of the reference's single-env step) on one host core."""
+def _cpu_single_env_loop(args):
+    """`seconds` of the oracle's reference-style single-env step on the calling process' core."""
+    kind, seconds, seed = args
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
     from oracle import quad_oracle as orc
-    rng = np.random.default_rng(0)
+    rng = np.random.default_rng(seed)
     env = orc.RefEnv(kind, orc.sample_params(rng, 1)[0])
     env.state = orc.sample_reset_state(rng, 1)[0]
     n, t0 = 0, time.perf_counter()
@@ -81,18 +83,52 @@ def cpu_baseline(kind: str, seconds: float):
                 env.set_params(orc.sample_params(rng, 1)[0])
                 env.state = orc.sample_reset_state(rng, 1)[0]
                 env.zero_integrators()
-    dt = time.perf_counter() - t0
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline(kind: str, seconds: float):
+    """Oracle ('port' of the reference's single-env step): `value` on one host core for `seconds`;
+    beside it one independent env per host core and the vectorised NumPy oracle."""
+    import multiprocessing as mp
+    import platform
+    import scipy
+    from oracle import quad_oracle as orc
+    n, dt = _cpu_single_env_loop((kind, seconds, 0))
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # a container's CPU quota, when it has one, is the honest core count
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    procs = min(cores, 16)  # bounded so that the default bench run stays short; the figure scales linearly beyond
+    all_cores = None
+    if procs > 1:
+        try:
+            with mp.get_context("spawn").Pool(procs) as pool:
+                res = pool.map(_cpu_single_env_loop, [(kind, min(4.0, seconds), 100 + k) for k in range(procs)])
+            all_cores = sum(r[0] / r[1] for r in res)
+        except Exception as e:  # a locked-down box: report the single-core figure only
+            all_cores = f"unavailable ({type(e).__name__})"
     # best-effort vectorised NumPy line (same maths, all envs at once) for context
+    rng = np.random.default_rng(1)
     nb = 65536
     st, pr = orc.sample_reset_state(rng, nb), orc.sample_params(rng, nb)
     ac = rng.uniform(-1, 1, (nb, orc.ACTION_DIM[kind]))
     t1 = time.perf_counter()
     orc.step_batch(kind, st, ac, pr, None, np.zeros((nb, 8)))
     vec = nb / (time.perf_counter() - t1)
+    cpu = platform.processor() or ""
+    try:
+        cpu = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        pass
     return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
             "sample": f"{n} single-env {kind} steps (NumPy RHS + scipy DOP853 + ensure_SO3, random actions, "
                       f"reset-on-done) in {dt:.1f}s on 1 core; vectorised NumPy oracle at N=65536: {vec:.0f} env-steps/s",
-            "vectorised_numpy_value": vec}
+            "vectorised_numpy_value": vec, "multi_process_value": all_cores, "multi_process_procs": procs, "host_cores": cores,
+            "cpu_model": cpu,
+            "numpy": np.__version__, "scipy": scipy.__version__}
 
 
 def committed_traffic(kind, envs, layout, auto_reset):
