@@ -501,3 +501,33 @@ def test_adaptive_kernel_is_the_plain_kernel_in_regime(kind):
         assert np.abs(out[0][0][:, 15:18]).max() < 16.0
         for x, y in zip(*out):
             assert np.array_equal(x, y)
+
+
+def test_one_million_envs_ten_substeps_and_shard_equivalence():
+    """BASELINE.json configs[4] at full size on one GPU: Quad-v0, 1 048 576 envs, 10 substeps,
+    auto-reset.  Size-independent properties (finite, R in SO(3), crash => -1, rewards in [0, 1]),
+    and the multi-GPU contract: the envs a rank would own (here the 131 072 of rank 5 of 8) stepped
+    as their own shard (env_offset) produce the same bits as inside the global batch — no result
+    depends on how the batch is partitioned."""
+    n, shard, rank, T = 1 << 20, 1 << 17, 5, 12
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    acts = torch.rand(T, n, 4, device="cuda", generator=g) * 2 - 1
+    env = _env("quad", n, seed=9, substeps=10, auto_reset=True, obs_rows=True)
+    env.reset("train")
+    part = _env("quad", shard, seed=9, substeps=10, auto_reset=True, obs_rows=True, env_offset=rank * shard)
+    part.reset("train")
+    lo, hi = rank * shard, (rank + 1) * shard
+    dones = 0
+    for t in range(T):
+        obs, rwd, done, _, _ = env.step(acts[t])
+        o2, r2, d2, _, _ = part.step(acts[t, lo:hi].contiguous())
+        assert torch.equal(obs[lo:hi], o2) and torch.equal(rwd[lo:hi], r2) and torch.equal(done[lo:hi], d2)
+        dones += int(done.sum())
+    assert dones > 0                                    # resets happened inside the launches
+    s = env.get_current_state()
+    assert torch.isfinite(s).all() and torch.equal(s[lo:hi], part.get_current_state())
+    idx = torch.randint(0, n, (8192,), device="cuda", generator=g)
+    R = s[idx, 6:15].reshape(-1, 3, 3).transpose(1, 2)
+    assert (R.transpose(1, 2) @ R - torch.eye(3, device="cuda", dtype=R.dtype)).abs().max() < 1e-12
+    r, d = rwd[:, 0], done[:, 0]
+    assert (r[d] == -1.0).all() and ((r[~d] >= 0) & (r[~d] <= 1)).all()
