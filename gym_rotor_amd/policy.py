@@ -43,6 +43,18 @@ class ActorParams:
                    actor.mean_linear.weight.data, actor.mean_linear.bias.data, actor.log_std.data.reshape(-1))
 
     @classmethod
+    def from_td3_module(cls, actor, explor_noise_std: float) -> "ActorParams":
+        """From the reference's TD3 actor (algos/td3/td3_mlp.py:5-34: fc1, fc2, fc3, tanh).  TD3.choose_action
+        (td3.py:82-96) is clip(actor(obs) + N(0, explor_noise_std)) — the PPO path with mean_linear = fc3
+        and log_std = log(explor_noise_std); for explor_noise_std = 0 call rollout_actor(deterministic=True)."""
+        import math
+        A = actor.fc3.weight.shape[0]
+        ls = math.log(explor_noise_std) if explor_noise_std > 0 else -30.0
+        return cls(actor.fc1.weight.data, actor.fc1.bias.data, actor.fc2.weight.data, actor.fc2.bias.data,
+                   actor.fc3.weight.data, actor.fc3.bias.data,
+                   torch.full((A,), ls, dtype=torch.float32, device=actor.fc3.weight.device))
+
+    @classmethod
     def random(cls, obs_dim: int, hidden: int, action_dim: int, device, generator=None, log_std: float = 0.0) -> "ActorParams":
         """Same initial distribution as the reference module: torch.nn.Linear's default
         U(+-1/sqrt(fan_in)), mean_linear weight x0.1 and bias 0 (ppo_mlp.py:26-28)."""

@@ -234,3 +234,26 @@ def test_checkpoint_resume_reproduces_the_rollout():
     for k in ("obs0", "obs1", "action", "logprob", "reward", "terminated"):
         assert torch.equal(got[k], want[k]), k
     assert torch.equal(twin.get_current_state(), env.get_current_state())
+
+
+@pytest.mark.parametrize("kind", ["coupled", "decoupled"])
+def test_td3_actor_in_kernel_vs_reference_module(golden, kind):
+    """TD3.choose_action (td3.py:93-96): clip(MLP_Actor_TD3(obs) + sigma eps) is the same kernel path
+    with mean_linear = fc3 and log_std = log sigma (ActorParams.from_td3_module)."""
+    import types
+    from gym_rotor_amd import ActorParams
+    d = golden("actor_td3")
+    tags = [f"{kind}0"] if kind == "coupled" else [f"{kind}0", f"{kind}1"]
+    n = d[f"{tags[0]}_obs"].shape[0]
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    mods = [types.SimpleNamespace(**{f"fc{i}": types.SimpleNamespace(weight=types.SimpleNamespace(data=cu(d[f"{t}_fc{i}_w"]), shape=d[f"{t}_fc{i}_w"].shape, device=torch.device("cuda", 0)),
+                                                                   bias=types.SimpleNamespace(data=cu(d[f"{t}_fc{i}_b"]))) for i in (1, 2, 3)}) for t in tags]
+    env = _env(kind, n)
+    env.reset("train")
+    obs = [cu(d[f"{t}_obs"]) for t in tags]
+    eps = cu(np.concatenate([d[f"{t}_eps"] for t in tags], 1)[None])
+    noisy = env.rollout_actor([ActorParams.from_td3_module(m, float(d["sigma"])) for m in mods], 1, obs=obs, noise=eps)
+    want = np.concatenate([d[f"{t}_action"] for t in tags], 1)
+    assert np.abs(_np(noisy["action"][0]) - want).max() <= 1e-6
+    greedy = env.rollout_actor([ActorParams.from_td3_module(m, 0.0) for m in mods], 1, obs=obs, deterministic=True)
+    assert np.abs(_np(greedy["action"][0]) - np.concatenate([d[f"{t}_mean"] for t in tags], 1)).max() <= 1e-6

@@ -20,6 +20,7 @@ Files written (see tests/golden/README.md for the field lists):
   gae.npz                  the reference's own GAE + normalisation lines (ppo.py:134-147) on synthetic data
   trajgoal_m{0,1,6}_{kind}.npz  closed loop env + TrajectoryGenerator (modes 0/1/6) as main.py drives them
   actor_ppo.npz            the reference's MLP_Actor_PPO (torch): weights, obs -> mean, injected-noise action, log_prob
+  actor_td3.npz            the reference's MLP_Actor_TD3 + explicit-noise choose_action
   actorloop_{kind}.npz     closed loop: reference wrapper env stepped by the reference's actor(s), 4 envs x 200 steps
 """
 import os
@@ -497,6 +498,34 @@ def gen_actor(seed=0, n=256):
     np.savez_compressed(os.path.join(OUT, "actor_ppo.npz"), **out)
 
 
+def gen_actor_td3(seed=0, n=256, sigma=0.1):
+    """The reference's TD3 actor (algos/td3/td3_mlp.py) and TD3.choose_action (td3.py:93-96) with the
+    exploration noise made explicit: clip(actor(obs) + sigma * eps)."""
+    import types
+    import torch
+    from algos.td3.td3_mlp import MLP_Actor_TD3
+    rng = np.random.default_rng(6500 + seed)
+    out = {"sigma": np.float32(sigma)}
+    for kind in ("coupled", "decoupled"):
+        dims = ACTOR_DIMS[kind]
+        args = types.SimpleNamespace(obs_dim_n=[d[0] for d in dims], actor_hidden_dim=[d[1] for d in dims], action_dim_n=[d[2] for d in dims])
+        torch.manual_seed(300 + seed)
+        for k, (D, H, A) in enumerate(dims):
+            a = MLP_Actor_TD3(args, k)
+            obs = rng.uniform(-1.5, 1.5, (n, D)).astype(np.float32)
+            eps = rng.standard_normal((n, A)).astype(np.float32)
+            with torch.no_grad():
+                mean = a(torch.from_numpy(obs)).numpy()
+            action = np.clip(mean + np.float32(sigma) * eps, -1.0, 1.0).astype(np.float32)  # td3.py:95-96 with explicit noise
+            tag = f"{kind}{k}"
+            out.update({f"{tag}_fc1_w": a.fc1.weight.detach().numpy().copy(), f"{tag}_fc1_b": a.fc1.bias.detach().numpy().copy(),
+                        f"{tag}_fc2_w": a.fc2.weight.detach().numpy().copy(), f"{tag}_fc2_b": a.fc2.bias.detach().numpy().copy(),
+                        f"{tag}_fc3_w": a.fc3.weight.detach().numpy().copy(), f"{tag}_fc3_b": a.fc3.bias.detach().numpy().copy(),
+                        f"{tag}_obs": obs, f"{tag}_eps": eps, f"{tag}_mean": mean, f"{tag}_action": action})
+    np.savez_compressed(os.path.join(OUT, "actor_td3.npz"), **out)
+    print("actor_td3 golden written")
+
+
 def gen_actorloop(kind, n_env=4, T=200, seed=0):
     """The collection loop of main.py:141-166 with the reference's env AND the reference's actor(s):
     obs_t -> choose_action (injected noise) -> concatenate -> env.step -> obs_{t+1}.  Free run."""
@@ -553,6 +582,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if ARGV[:1] == ["actor"]:  # only the actor files
         gen_actor()
+        gen_actor_td3()
         for kind in ("coupled", "decoupled"):
             gen_actorloop(kind)
         sys.exit(0)
@@ -570,5 +600,6 @@ if __name__ == "__main__":
         for mode in (0, 1, 6):
             gen_trajgoal(kind, mode)
     gen_actor()
+    gen_actor_td3()
     for kind in ("coupled", "decoupled"):
         gen_actorloop(kind)
