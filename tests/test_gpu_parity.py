@@ -531,3 +531,34 @@ def test_one_million_envs_ten_substeps_and_shard_equivalence():
     assert (R.transpose(1, 2) @ R - torch.eye(3, device="cuda", dtype=R.dtype)).abs().max() < 1e-12
     r, d = rwd[:, 0], done[:, 0]
     assert (r[d] == -1.0).all() and ((r[~d] >= 0) & (r[~d] <= 1)).all()
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_in_launch_reset_draws_equal_the_reset_kernel(kind):
+    """The wave-cooperative Philox path of the in-launch reset (one pass serves up to 12 resetting
+    lanes; several passes when more reset) produces exactly the state, parameters and counters that
+    qr_reset's per-lane draws give for the same (seed, env id, episode) — checked with 1, a few,
+    13..63 and all 64 lanes of a wave resetting in the same step."""
+    n = 64 * 40 + 17
+    env = _env(kind, n, seed=77, auto_reset=True, obs_rows=True)
+    env.reset("train")
+    # make a chosen set of lanes terminate in this step: x far outside the arena
+    kill = torch.zeros(n, dtype=torch.bool, device="cuda")
+    for w_, cnt in enumerate([1, 2, 3, 11, 12, 13, 24, 25, 37, 63, 64, 5]):
+        idx = torch.randperm(64, device="cuda")[:cnt] + 64 * w_
+        kill[idx] = True
+    kill[n - 3:] = True                                             # ragged tail wave
+    st = _np(env.get_current_state())
+    st[_np(kill), 0] = 5.0
+    env.set_state(st, mask=kill)
+    ep_before = env._episode.clone()
+    obs, rwd, done, _, _ = env.step(torch.zeros(n, env.action_dim, device="cuda"))
+    assert bool(done[kill].any(1).all()) and bool((env._episode == ep_before + kill.int()).all())
+    twin = _env(kind, n, seed=77, auto_reset=False, obs_rows=True)
+    twin.load_state_dict({k: v for k, v in env.state_dict().items() if k not in ("last_obs",)})
+    twin._episode.copy_(ep_before)
+    twin.reset("train", mask=kill)
+    assert torch.equal(twin._episode, env._episode)
+    a, b = _np(env.get_current_state()), _np(twin.get_current_state())
+    assert np.array_equal(a[_np(kill)], b[_np(kill)])
+    assert torch.equal(env.params[kill], twin.params[kill])
