@@ -562,3 +562,48 @@ def test_in_launch_reset_draws_equal_the_reset_kernel(kind):
     a, b = _np(env.get_current_state()), _np(twin.get_current_state())
     assert np.array_equal(a[_np(kill)], b[_np(kill)])
     assert torch.equal(env.params[kill], twin.params[kill])
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_production_mode_1000_steps_every_episode_vs_oracle(kind):
+    """The mode a training loop runs (default layout, 1 substep, in-launch auto-reset, random
+    actions): 512 envs x 1000 steps, ~5000 complete episodes.  The oracle steps every env from its
+    own state and only adopts the GPU's freshly sampled state when an episode ends, so the error of
+    every env is followed through every whole episode; rewards and done flags are compared at
+    every step including the terminal one."""
+    n, T = 512, 1000
+    rng = np.random.default_rng(4242 + KINDS.index(kind))
+    A = orc.ACTION_DIM[kind]
+    env = _env(kind, n, seed=31, auto_reset=True, obs_rows=True)
+    assert env.layout == "mixed" and env.substeps == 1
+    env.reset("train")
+    if kind != "quad":
+        env.get_norm_error_state()
+    s = _np(env.get_current_state())
+    params = _np(env.params).astype(np.float64)
+    integ = _np(env.integ).astype(np.float64) if kind != "quad" else np.zeros((n, 8))
+    worst_state = worst_rwd = 0.0
+    episodes = ties = 0
+    for t in range(T):
+        act = rng.uniform(-1, 1, (n, A)).astype(np.float32)
+        obs, rwd, done, _, _ = env.step(torch.from_numpy(act).cuda())
+        o = orc.step_batch(kind, s, act.astype(np.float64), params, None, integ)
+        g_state, g_done, g_rwd = _np(env.get_current_state()), _np(done), _np(rwd)
+        mism = (g_done != o["done"]).any(1)
+        ties += int(mism.sum())                      # deciding quantity within round-off of its threshold
+        ended = g_done.any(1)
+        keep = ~ended & ~mism
+        worst_state = max(worst_state, grouped_rel_err(g_state[keep], o["state"][keep]))
+        worst_rwd = max(worst_rwd, np.abs(g_rwd[~mism] - o["reward"][~mism]).max())
+        # continue from the oracle's own state; adopt the GPU's new episode where one ended
+        s, integ = o["state"], o["integ"]
+        adopt = ended | mism
+        if adopt.any():
+            s[adopt] = g_state[adopt]
+            params[adopt] = _np(env.params)[adopt]
+            if kind != "quad":
+                integ[adopt] = _np(env.integ)[adopt]
+            episodes += int(ended.sum())
+    print(f"production mode {kind}: {episodes} episodes, worst in-episode state error {worst_state:.2e}, reward {worst_rwd:.2e}, threshold ties {ties}")
+    assert episodes > 2000 and ties <= 3
+    assert worst_state <= 2e-6 and worst_rwd <= 2e-5
