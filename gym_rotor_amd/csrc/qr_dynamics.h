@@ -229,7 +229,7 @@ __device__ __forceinline__ void error_obs(Work<T>& w, const T (&R)[9], const Coe
   for (int j = 0; j < 3; ++j) b1c[j] = b1d[j] - db3 * b3[j];
   const T sn = -(b1c[0] * b2[0] + b1c[1] * b2[1] + b1c[2] * b2[2]);
   const T cs = b1c[0] * b1[0] + b1c[1] * b1[1] + b1c[2] * b1[2];
-  const float eb1 = atan2f((float)sn, (float)cs);  // [rad]
+  const float eb1 = atan2_fast((float)sn, (float)cs);  // [rad]
   const float eb1n = eb1 * (float)(1.0 / kPi);
   // integrators: I += (g_prev + g) dt/2 ; g uses I before the update.  They are float32 words
   // (stored and held), advanced in float32.

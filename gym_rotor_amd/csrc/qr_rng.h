@@ -109,6 +109,28 @@ __device__ __forceinline__ void sincos_small(float x, float& sn, float& cs) {
 
 // sin/cos of a random angle re-normalised in f64, so every factor, hence q, has unit norm to
 // f64 round-off.
+// atan2 for float arguments, ~1.5e-7 rad: octant reduction (cephes atanf: [0, tan(pi/8)] by
+// (a - 1)/(a + 1)), quotients by v_rcp_f32 + one Newton step, degree-4 polynomial in a^2.
+// Branch-free and ~30 instructions (the OCML atan2f carries an IEEE float division and special-case
+// branches; with one wave per SIMD every instruction of the slowest wave is exposed).
+__device__ __forceinline__ float rcp_nr(float x) {
+  float r = __builtin_amdgcn_rcpf(x);
+  return r * (2.0f - x * r);
+}
+__device__ __forceinline__ float atan2_fast(float y, float x) {
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  float a = (mx > 0.0f) ? mn * rcp_nr(mx) : 0.0f;           // in [0, 1]
+  const bool hi = a > 0.41421356237f;                        // tan(pi/8)
+  const float z = hi ? (a - 1.0f) * rcp_nr(a + 1.0f) : a;    // |z| <= tan(pi/8)
+  const float z2 = z * z;
+  float p = fmaf(fmaf(fmaf(fmaf(8.05374449538e-2f, z2, -1.38776856032e-1f), z2, 1.99777106478e-1f), z2, -3.33329491539e-1f) * z2, z, z);
+  p = hi ? p + 0.78539816339744831f : p;                     // atan(mn / mx)
+  p = (ay > ax) ? 1.57079632679489662f - p : p;              // first quadrant
+  p = (x < 0.0f) ? 3.14159265358979324f - p : p;
+  return copysignf(p, y);
+}
+
 __device__ __forceinline__ void unit_sincos(float ang, double& s, double& c) {
   float sf, cf;
   sincos_small(ang, sf, cf);

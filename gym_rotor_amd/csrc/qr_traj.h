@@ -31,7 +31,7 @@ template <typename T>
 __device__ __forceinline__ void traj_start(const Work<T>& w, Traj& tr, int goal_mode, float theta_b1d, float t_traj, float w_b1d) {
   const T qw = w.y[3], qx = w.y[4], qy = w.y[5], qz = w.y[6];
   const float b1x = (float)(T(1) - T(2) * (qy * qy + qz * qz)), b1y = (float)(T(2) * (qx * qy + qw * qz));
-  const float theta_init = atan2f(b1y, b1x);  // update_initial_state (:199-204)
+  const float theta_init = atan2_fast(b1y, b1x);  // update_initial_state (:199-204)
   tr.calls = 0.0f;
   tr.theta_init = theta_init;
   if (goal_mode == QR_GOAL_MODE0) {

@@ -288,7 +288,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       const T cz = g6 * R[1] - g7 * R[0];
       const T hy2 = R[0] * R[0] + R[1] * R[1];
       const float sabs = sqrtf((float)(g8 * g8 * hy2 + cz * cz));
-      float ang = atan2f(sabs, (float)dot);
+      float ang = atan2_fast(sabs, (float)dot);
       if (cz < T(0)) ang = -ang;
       const T eb1 = T(ang) * T(1.0 / kPi);
       const T r = -T(c.Cx) * eX2 - T(c.Cb1) * fabs(eb1) - T(c.Cv) * eV2 - T(c.CW) * W2;
@@ -361,8 +361,12 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         if constexpr (TRAJ) {  // mark_traj_start + first get_desired of the episode (main.py:227-229)
           float th, tt, wb, b1d_dot[3];
           traj_draws(d.r[19], th, tt, wb);
+#if QR_ABLATE != 5 && QR_ABLATE != 7
           traj_start(w, tr, goal_mode, th, tt, wb);
+#endif
+#if QR_ABLATE != 6 && QR_ABLATE != 7
           traj_goal(w, tr, goal_mode, c, b1d_dot);
+#endif
           traj_dirty = true;
         }
         quat_to_R(&w.y[3], R);
