@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("QR_LIB", os.path.join(_HERE, "libquadrotor_hip.so"))
 KIND_QUAD, KIND_COUPLED, KIND_DECOUPLED = 0, 1, 2
 KIND_ID = {"quad": KIND_QUAD, "coupled": KIND_COUPLED, "decoupled": KIND_DECOUPLED}
 FLAG_AUTO_RESET, FLAG_EVAL_RESET, FLAG_NO_UDM = 1, 2, 4
-ABI_VERSION = 8
+ABI_VERSION = 9
 GOAL_EXTERNAL, GOAL_MODE0, GOAL_MODE1, GOAL_MODE6 = 0, 1, 2, 3
 GOAL_ID = {None: 0, 0: 1, 1: 2, 6: 3}  # TrajectoryGenerator mode -> QR_GOAL_*
 LAYOUT_ID = {"mixed": 0, "f64": 1, "f32": 2}
@@ -55,7 +55,11 @@ class QrStepOut(C.Structure):
 class QrActor(C.Structure):
     _fields_ = [("fc1_w", C.c_void_p), ("fc1_b", C.c_void_p), ("fc2_w", C.c_void_p), ("fc2_b", C.c_void_p),
                 ("mean_w", C.c_void_p), ("mean_b", C.c_void_p), ("log_std", C.c_void_p),
-                ("obs_dim", C.c_int32), ("hidden_dim", C.c_int32), ("action_dim", C.c_int32), ("reserved0", C.c_int32)]
+                ("log_std_w", C.c_void_p), ("log_std_b", C.c_void_p),
+                ("obs_dim", C.c_int32), ("hidden_dim", C.c_int32), ("action_dim", C.c_int32), ("squash", C.c_int32)]
+
+
+ACTOR_TANH_MEAN, ACTOR_TANH_SAMPLE = 0, 1
 
 
 class QrPolicyRollout(C.Structure):

@@ -1,5 +1,5 @@
 // qr_actor.h — part of the gfx950 quadrotor step library (included by quadrotor_kernels.hip, in this order).
-// PPO actor in the loop (qr_rollout_actor): MFMA actor, VALU/LDS actor, sampling, normals.
+// The reference's MLP actors (PPO, TD3, SAC) in the loop (qr_rollout_actor): MFMA actor, VALU/LDS actor, sampling, normals.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,14 +32,19 @@ template <int D, int H, int A>
 struct ActorLds {
   static constexpr int HP = (H + 3) & ~3, AP = (A + 3) & ~3;
   static constexpr int O_FC1W = 0, O_FC1B = O_FC1W + D * HP, O_FC2W = O_FC1B + HP, O_FC2B = O_FC2W + H * HP,
-                       O_MW = O_FC2B + HP, O_MB = O_MW + H * AP, O_LS = O_MB + AP, SIZE = O_LS + AP;
+                       O_MW = O_FC2B + HP, O_MB = O_MW + H * AP, O_LS = O_MB + AP, O_LW = O_LS + AP, O_LB = O_LW + H * AP,
+                       SIZE = O_LB + AP;
 
   __device__ static void fill(float* sm, const ActorW& p, int tid) {  // sm[k][j] = W[j][k]
     for (int i = tid; i < D * HP; i += 64) { const int k = i / HP, j = i - k * HP; sm[O_FC1W + i] = j < H ? p.fc1_w[j * D + k] : 0.0f; }
     for (int i = tid; i < H * HP; i += 64) { const int k = i / HP, j = i - k * HP; sm[O_FC2W + i] = j < H ? p.fc2_w[j * H + k] : 0.0f; }
     for (int i = tid; i < H * AP; i += 64) { const int k = i / AP, j = i - k * AP; sm[O_MW + i] = j < A ? p.mean_w[j * H + k] : 0.0f; }
     if (tid < HP) { sm[O_FC1B + tid] = tid < H ? p.fc1_b[tid] : 0.0f; sm[O_FC2B + tid] = tid < H ? p.fc2_b[tid] : 0.0f; }
-    if (tid < AP) { sm[O_MB + tid] = tid < A ? p.mean_b[tid] : 0.0f; sm[O_LS + tid] = tid < A ? p.log_std[tid] : 0.0f; }
+    if (tid < AP) { sm[O_MB + tid] = tid < A ? p.mean_b[tid] : 0.0f; sm[O_LS + tid] = (tid < A && p.log_std) ? p.log_std[tid] : 0.0f; }
+    if (p.ls_w) {
+      for (int i = tid; i < H * AP; i += 64) { const int k = i / AP, j = i - k * AP; sm[O_LW + i] = j < A ? p.ls_w[j * H + k] : 0.0f; }
+      if (tid < AP) sm[O_LB + tid] = tid < A ? p.ls_b[tid] : 0.0f;
+    }
   }
 
   template <int NI, int NO, int NOP>
@@ -53,7 +58,8 @@ struct ActorLds {
     }
   }
 
-  __device__ __forceinline__ static void mean(const float* sm, const float (&x)[D], float (&out)[A]) {
+  // pre[] = mean head before any squashing; ls[] = log_std (parameter, or the head's output)
+  __device__ __forceinline__ static void heads(const float* sm, bool ls_head, const float (&x)[D], float (&pre)[A], float (&ls)[A]) {
     float h1[H], h2[H];
     layer<D, H, HP>(sm + O_FC1W, sm + O_FC1B, x, h1);
 #pragma unroll
@@ -61,9 +67,13 @@ struct ActorLds {
     layer<H, H, HP>(sm + O_FC2W, sm + O_FC2B, h1, h2);
 #pragma unroll
     for (int j = 0; j < H; ++j) h2[j] = fmaxf(h2[j], 0.0f);
-    layer<H, A, AP>(sm + O_MW, sm + O_MB, h2, out);
+    layer<H, A, AP>(sm + O_MW, sm + O_MB, h2, pre);
+    if (ls_head) {
+      layer<H, A, AP>(sm + O_LW, sm + O_LB, h2, ls);
+    } else {
 #pragma unroll
-    for (int j = 0; j < A; ++j) out[j] = tanh_fast(out[j]);
+      for (int j = 0; j < A; ++j) ls[j] = sm[O_LS + j];
+    }
   }
 };
 
@@ -87,7 +97,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int D>  // obs_dim 23 (COUPLED) or 15 (DECOUPLED agent 1); hidden 16, 4 actions
 struct ActorMfma {
   static constexpr int KS = (D + 3) / 4;
-  float a1[KS], a2[4], w3[4], bias1[4], bias2[4], bias3[4], log_std[4];
+  float a1[KS], a2[4], w3[4], w3s[4], bias1[4], bias2[4], bias3[4], bias3s[4], log_std[4];
+  bool ls_head;
 
   __device__ __forceinline__ void load(const ActorW& p, int lane) {
     const int c = lane & 15, g = lane >> 4;
@@ -95,14 +106,20 @@ struct ActorMfma {
     for (int s = 0; s < KS; ++s) a1[s] = (4 * s + g < D) ? p.fc1_w[c * D + 4 * s + g] : 0.0f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) { a2[s] = p.fc2_w[c * 16 + 4 * g + s]; w3[s] = p.mean_w[(c & 3) * 16 + 4 * g + s]; }
+    ls_head = p.ls_w != nullptr;  // wave-uniform
+#pragma unroll
+    for (int s = 0; s < 4; ++s) w3s[s] = ls_head ? p.ls_w[(c & 3) * 16 + 4 * g + s] : 0.0f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      bias1[r] = p.fc1_b[4 * g + r]; bias2[r] = p.fc2_b[4 * g + r]; bias3[r] = p.mean_b[r]; log_std[r] = p.log_std[r];
+      bias1[r] = p.fc1_b[4 * g + r]; bias2[r] = p.fc2_b[4 * g + r]; bias3[r] = p.mean_b[r];
+      bias3s[r] = ls_head ? p.ls_b[r] : 0.0f;
+      log_std[r] = p.log_std ? p.log_std[r] : 0.0f;
     }
   }
 
   // xs: LDS tile [64 envs][D] of the wave's observations (row = lane)
-  __device__ __forceinline__ void mean(const float* xs, int lane, float (&out)[4]) const {
+  // pre[] = mean head before any squashing; ls[] = log_std (parameter, or the second head's output)
+  __device__ __forceinline__ void heads(const float* xs, int lane, float (&pre)[4], float (&ls)[4]) const {
     const int c = lane & 15, g = lane >> 4;
     f32x4 h1[4], h2[4];
 #pragma unroll
@@ -140,24 +157,55 @@ struct ActorMfma {
       }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) out[r] = tanh_fast(m0[r] + m1[r]);
+    for (int r = 0; r < 4; ++r) pre[r] = m0[r] + m1[r];
+    if (ls_head) {  // same placement as the mean head: lane (g, c) receives log_std[r] of env 16 g + c
+      f32x4 l0 = f32x4{bias3s[0], bias3s[1], bias3s[2], bias3s[3]}, l1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const float w = ((c >> 2) == b) ? w3s[s] : 0.0f;
+          f32x4& l = (b & 1) ? l1 : l0;
+          l = __builtin_amdgcn_mfma_f32_16x16x4f32(w, fmaxf(h2[b][s], 0.0f), l, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ls[r] = l0[r] + l1[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ls[r] = log_std[r];
+    }
   }
 };
 
-// PPO.choose_action (ppo.py:93-101): a = clamp(mean + exp(log_std) eps, +-max_action) and the
-// per-component Normal(mean, std).log_prob of the clamped action (ppo.py:97-98).
+// Action selection from the heads' outputs.
+//   QR_ACTOR_TANH_MEAN   PPO.choose_action (ppo.py:93-101), TD3.choose_action (td3.py:93-96):
+//     mean = tanh(pre); a = clamp(mean + exp(log_std) eps, +-max_action); logp = per-component
+//     Normal(mean, std).log_prob of the CLAMPED action (ppo.py:97-98).
+//   QR_ACTOR_TANH_SAMPLE MLP_Actor_SAC.sample (sac_mlp.py:60-82): log_std clamped to [-20, 2];
+//     u = pre + exp(log_std) eps; a = tanh(u); logp = Normal(pre, std).log_prob(u) - log(1 - a^2 + 1e-6).
 template <int A>
-__device__ __forceinline__ void actor_sample(const float* log_std, const float (&mean)[A], const float* eps, bool deterministic,
-                                             float max_action, float* act, float* logp) {
+__device__ __forceinline__ void actor_sample(int squash, bool ls_head, const float* pre, const float* log_std, const float* eps,
+                                             bool deterministic, float max_action, float* act, float* logp) {
 #pragma unroll
   for (int j = 0; j < A; ++j) {
-    const float ls = log_std[j];
-    const float sd = __expf(ls);
-    const float raw = deterministic ? mean[j] : fmaf(sd, eps[j], mean[j]);
-    const float aj = fminf(fmaxf(raw, -max_action), max_action);
-    const float z = (aj - mean[j]) * __expf(-ls);
-    act[j] = aj;
-    logp[j] = fmaf(-0.5f * z, z, -ls - 0.91893853320467274f);
+    if (squash == QR_ACTOR_TANH_SAMPLE) {
+      const float ls = fminf(fmaxf(log_std[j], -20.0f), 2.0f);
+      const float sd = __expf(ls);
+      const float z = deterministic ? 0.0f : eps[j];
+      const float aj = tanh_fast(fmaf(sd, z, pre[j]));
+      act[j] = aj;
+      logp[j] = fmaf(-0.5f * z, z, -ls - 0.91893853320467274f) - __logf(fmaf(-aj, aj, 1.0f) + 1e-6f);
+    } else {
+      const float ls = ls_head ? fminf(fmaxf(log_std[j], -20.0f), 2.0f) : log_std[j];
+      const float sd = __expf(ls);
+      const float mean = tanh_fast(pre[j]);
+      const float raw = deterministic ? mean : fmaf(sd, eps[j], mean);
+      const float aj = fminf(fmaxf(raw, -max_action), max_action);
+      const float z = (aj - mean) * __expf(-ls);
+      act[j] = aj;
+      logp[j] = fmaf(-0.5f * z, z, -ls - 0.91893853320467274f);
+    }
   }
 }
 

@@ -25,6 +25,8 @@ struct Coeffs {  // double-precision copy of QrCoeffs + derived reward floors
 
 struct ActorW {  // QrActor's tensors (torch.nn.Linear layout: weight [out][in])
   const float *fc1_w, *fc1_b, *fc2_w, *fc2_b, *mean_w, *mean_b, *log_std;
+  const float *ls_w, *ls_b;  // optional state-dependent log_std head (SAC); log_std is then unused
+  int32_t squash;            // QR_ACTOR_TANH_MEAN | QR_ACTOR_TANH_SAMPLE
 };
 
 struct Args {

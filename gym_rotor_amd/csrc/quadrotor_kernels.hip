@@ -169,20 +169,21 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   for (int t = 0; t < a.n_steps; ++t) {
     float act[A];
     if constexpr (POLICY) {
-      float mean[A], eps[A], logp[A];
+      float pre[A], ls[A], eps[A], logp[A];
       // the wave's observation rows -> LDS tile [lane][D0] (B operands of the first layer)
 #pragma unroll
       for (int j = 0; j < D0; ++j) smem[tid * D0 + j] = po0[j];
       __syncthreads();
-      if constexpr (KIND == QR_KIND_COUPLED) {
-        actor0.mean(smem, tid, mean);
-      } else {
-        float m0[4], m1[1];
-        actor0.mean(smem, tid, m0);
-        Actor1::mean(wsm, po1, m1);
+      {
+        float p0[4], l0[4];
+        actor0.heads(smem, tid, p0, l0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) mean[j] = m0[j];
-        mean[A - 1] = m1[0];
+        for (int j = 0; j < 4; ++j) { pre[j] = p0[j]; ls[j] = l0[j]; }
+      }
+      if constexpr (KIND == QR_KIND_DECOUPLED) {
+        float p1[1], l1[1];
+        Actor1::heads(wsm, a.actor[1].ls_w != nullptr, po1, p1, l1);
+        pre[A - 1] = p1[0]; ls[A - 1] = l1[0];
       }
 #pragma unroll
       for (int j = 0; j < A; ++j) eps[j] = 0.0f;
@@ -205,10 +206,10 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         }
       }
       __syncthreads();  // the tile is reused by the row stores below
-      actor_sample<4>(actor0.log_std, *reinterpret_cast<const float(*)[4]>(&mean[0]), &eps[0], a.deterministic != 0, a.max_action, &act[0], &logp[0]);
+      actor_sample<4>(a.actor[0].squash, actor0.ls_head, &pre[0], &ls[0], &eps[0], a.deterministic != 0, a.max_action, &act[0], &logp[0]);
       if constexpr (A > 4)
-        actor_sample<1>(wsm + Actor1::O_LS, *reinterpret_cast<const float(*)[1]>(&mean[A - 1]), &eps[A - 1], a.deterministic != 0, a.max_action,
-                        &act[A - 1], &logp[A - 1]);
+        actor_sample<1>(a.actor[1].squash, a.actor[1].ls_w != nullptr, &pre[A - 1], &ls[A - 1], &eps[A - 1], a.deterministic != 0,
+                        a.max_action, &act[A - 1], &logp[A - 1]);
       if (active) {
         const int64_t arow = ((int64_t)t * N + first) * A;
         if constexpr (A == 4) {
@@ -771,9 +772,13 @@ static void launch_get_desired(const Args& a, unsigned grid, hipStream_t s) {
 
 static int fill_actor(ActorW& w, const QrActor& q, int obs_dim, int hidden, int action_dim) {
   if (q.obs_dim != obs_dim || q.hidden_dim != hidden || q.action_dim != action_dim) return QR_E_SIZE;
-  if (!q.fc1_w || !q.fc1_b || !q.fc2_w || !q.fc2_b || !q.mean_w || !q.mean_b || !q.log_std) return QR_E_NULL;
+  if (!q.fc1_w || !q.fc1_b || !q.fc2_w || !q.fc2_b || !q.mean_w || !q.mean_b) return QR_E_NULL;
+  if (!q.log_std && !(q.log_std_w && q.log_std_b)) return QR_E_NULL;  // one of the two log_std sources
+  if ((q.log_std_w == nullptr) != (q.log_std_b == nullptr)) return QR_E_NULL;
+  if (q.squash != QR_ACTOR_TANH_MEAN && q.squash != QR_ACTOR_TANH_SAMPLE) return QR_E_KIND;
   w.fc1_w = q.fc1_w; w.fc1_b = q.fc1_b; w.fc2_w = q.fc2_w; w.fc2_b = q.fc2_b;
   w.mean_w = q.mean_w; w.mean_b = q.mean_b; w.log_std = q.log_std;
+  w.ls_w = q.log_std_w; w.ls_b = q.log_std_b; w.squash = q.squash;
   return 0;
 }
 

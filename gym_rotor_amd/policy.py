@@ -1,7 +1,10 @@
-"""PPO actor parameters for the policy-in-the-loop rollout (`QuadVecEnv.rollout_actor`).
+"""Actor parameters for the policy-in-the-loop rollout (`QuadVecEnv.rollout_actor`).
 
-The network is the reference's `MLP_Actor_PPO` (algos/ppo/ppo_mlp.py:6-58): fc1 -> relu -> fc2 ->
-relu -> mean_linear -> tanh, plus a state-independent `log_std`; sizes are the reference's
+The networks are the reference's MLP actors: `MLP_Actor_PPO` (algos/ppo/ppo_mlp.py:6-58: fc1 -> relu
+-> fc2 -> relu -> mean_linear -> tanh, plus a state-independent `log_std`), `MLP_Actor_TD3`
+(algos/td3/td3_mlp.py:5-34: the same with fc3 as the mean head and the exploration std) and
+`MLP_Actor_SAC` (algos/sac/sac_mlp.py:16-82: mean and log_std heads, tanh applied to the sample);
+sizes are the reference's
 defaults (args_parse.py:40 `actor_hidden_dim=[16, 4]`, obs/action dims of the wrappers).  The
 tensors are used by the kernel in place, in torch.nn.Linear layout — `ActorParams.from_module`
 takes a live module, so an optimiser step is seen by the next rollout without any copy.
@@ -10,7 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass
-from typing import List, Sequence
+from typing import List, Optional, Sequence
 
 import torch
 
@@ -28,9 +31,12 @@ class ActorParams:
     fc2_b: torch.Tensor
     mean_w: torch.Tensor
     mean_b: torch.Tensor
-    log_std: torch.Tensor
+    log_std: Optional[torch.Tensor]               # [A] state-independent log std (PPO; TD3: log exploration std)
+    log_std_w: Optional[torch.Tensor] = None      # [A, H] \ state-dependent log_std head (SAC); log_std is then None
+    log_std_b: Optional[torch.Tensor] = None      # [A]    /
+    squash: int = _lib.ACTOR_TANH_MEAN            # TANH_MEAN: tanh(mean) + noise, clamp; TANH_SAMPLE: tanh(mean + noise)
 
-    NAMES = ("fc1_w", "fc1_b", "fc2_w", "fc2_b", "mean_w", "mean_b", "log_std")
+    NAMES = ("fc1_w", "fc1_b", "fc2_w", "fc2_b", "mean_w", "mean_b", "log_std", "log_std_w", "log_std_b")
 
     @property
     def dims(self):
@@ -41,6 +47,14 @@ class ActorParams:
         """From a reference-style actor module (attributes fc1, fc2, mean_linear, log_std)."""
         return cls(actor.fc1.weight.data, actor.fc1.bias.data, actor.fc2.weight.data, actor.fc2.bias.data,
                    actor.mean_linear.weight.data, actor.mean_linear.bias.data, actor.log_std.data.reshape(-1))
+
+    @classmethod
+    def from_sac_module(cls, actor) -> "ActorParams":
+        """From the reference's SAC actor (algos/sac/sac_mlp.py:16-82: fc1, fc2, mean_linear, log_std_linear);
+        rollout_actor then does MLP_Actor_SAC.sample: action = tanh(mean + exp(clamp(log_std, -20, 2)) eps)."""
+        return cls(actor.fc1.weight.data, actor.fc1.bias.data, actor.fc2.weight.data, actor.fc2.bias.data,
+                   actor.mean_linear.weight.data, actor.mean_linear.bias.data, None,
+                   actor.log_std_linear.weight.data, actor.log_std_linear.bias.data, _lib.ACTOR_TANH_SAMPLE)
 
     @classmethod
     def from_td3_module(cls, actor, explor_noise_std: float) -> "ActorParams":
@@ -72,17 +86,26 @@ class ActorParams:
         if self.dims != tuple(dims):
             raise ValueError(f"actor sizes {self.dims} do not match {tuple(dims)} (obs, hidden, action)")
         shapes = {"fc1_w": (dims[1], dims[0]), "fc1_b": (dims[1],), "fc2_w": (dims[1], dims[1]), "fc2_b": (dims[1],),
-                  "mean_w": (dims[2], dims[1]), "mean_b": (dims[2],), "log_std": (dims[2],)}
+                  "mean_w": (dims[2], dims[1]), "mean_b": (dims[2],), "log_std": (dims[2],),
+                  "log_std_w": (dims[2], dims[1]), "log_std_b": (dims[2],)}
+        if (self.log_std_w is None) != (self.log_std_b is None) or (self.log_std is None and self.log_std_w is None):
+            raise ValueError("actor needs either log_std or the (log_std_w, log_std_b) head")
+        if self.squash not in (_lib.ACTOR_TANH_MEAN, _lib.ACTOR_TANH_SAMPLE):
+            raise ValueError("actor.squash must be ACTOR_TANH_MEAN or ACTOR_TANH_SAMPLE")
         for n in self.NAMES:
             t = getattr(self, n)
+            if t is None:
+                continue
             if tuple(t.shape) != shapes[n] or t.dtype != torch.float32 or t.device != device or not t.is_contiguous():
                 raise ValueError(f"actor tensor {n} must be a contiguous float32 {shapes[n]} tensor on {device}")
 
     def as_c(self) -> _lib.QrActor:
         q = _lib.QrActor()
         for n in self.NAMES:
-            setattr(q, n, getattr(self, n).data_ptr())
+            t = getattr(self, n)
+            setattr(q, n, None if t is None else t.data_ptr())
         q.obs_dim, q.hidden_dim, q.action_dim = self.dims
+        q.squash = int(self.squash)
         return q
 
 

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define QR_ABI_VERSION 8
+#define QR_ABI_VERSION 9
 
 /* env kinds */
 #define QR_KIND_QUAD      0 /* QuadEnv            gym_rotor/envs/quad.py:19            */
@@ -154,15 +154,26 @@ int qr_step(const QrEnv* env, const float* action, int32_t substeps, const QrSte
 int qr_rollout(const QrEnv* env, const float* action, int32_t n_steps, int32_t substeps,
                const QrStepOut* out, void* stream);
 
-/* One PPO actor, MLP_Actor_PPO (algos/ppo/ppo_mlp.py:6-58): mean = tanh(mean_linear(relu(fc2(
- * relu(fc1(obs)))))), std = exp(log_std).  Device pointers to float32 tensors in torch.nn.Linear
- * layout (weight [out][in] row-major), i.e. `actor.fc1.weight.data_ptr()` etc. as they are. */
+/* One MLP actor of the reference: fc1 -> relu -> fc2 -> relu -> heads.  Device pointers to float32
+ * tensors in torch.nn.Linear layout (weight [out][in] row-major), i.e. `actor.fc1.weight.data_ptr()`
+ * etc. as they are.
+ *   QR_ACTOR_TANH_MEAN   PPO  MLP_Actor_PPO (algos/ppo/ppo_mlp.py:6-58) and TD3 MLP_Actor_TD3
+ *                        (algos/td3/td3_mlp.py:5-34, mean head = fc3): mean = tanh(head(h));
+ *                        action = clamp(mean + exp(log_std) eps, +-max_action)  (ppo.py:93-99, td3.py:93-96)
+ *   QR_ACTOR_TANH_SAMPLE SAC  MLP_Actor_SAC (algos/sac/sac_mlp.py:16-82): mean = mean_linear(h),
+ *                        log_std = clamp(log_std_linear(h), -20, 2); action = tanh(mean + exp(log_std) eps)
+ * log_std: the state-independent parameter [action_dim] (PPO; TD3: log of the exploration std) —
+ * or, when log_std_w is set, the second head log_std_w [action_dim][hidden], log_std_b [action_dim]. */
+#define QR_ACTOR_TANH_MEAN   0
+#define QR_ACTOR_TANH_SAMPLE 1
 typedef struct QrActor {
   const float* fc1_w;   const float* fc1_b;   /* [hidden][obs_dim], [hidden]        */
   const float* fc2_w;   const float* fc2_b;   /* [hidden][hidden],  [hidden]        */
   const float* mean_w;  const float* mean_b;  /* [action_dim][hidden], [action_dim] */
-  const float* log_std;                        /* [action_dim]                       */
-  int32_t obs_dim, hidden_dim, action_dim, reserved0;
+  const float* log_std;                        /* [action_dim], or NULL with a log_std head */
+  const float* log_std_w; const float* log_std_b; /* optional state-dependent log_std head  */
+  int32_t obs_dim, hidden_dim, action_dim;
+  int32_t squash;                              /* QR_ACTOR_TANH_MEAN | QR_ACTOR_TANH_SAMPLE */
 } QrActor;
 
 /* Caller side of a PPO collection loop (main.py:141-166 with PPO.choose_action, ppo.py:82-101)
@@ -181,10 +192,11 @@ typedef struct QrPolicyRollout {
   uint64_t noise_seed;
   uint64_t step_base;     /* global step index of t = 0 (advance by K per call)               */
   float max_action;       /* clamp (args_parse.py:45: 1.0)                                    */
-  int32_t deterministic;  /* != 0: action = clamp(mean) (is_eval, ppo.py:100-101)             */
+  int32_t deterministic;  /* != 0: action = clamp(mean) resp. tanh(mean) (is_eval: ppo.py:100-101, sac.py:104-105) */
   float* action_out;      /* [K][N][A] actions taken (agents concatenated, main.py:161)       */
-  float* logprob_out;     /* [K][N][A] Normal(mean, std).log_prob(action) per component of the
-                             CLAMPED action (ppo.py:97-98); NULL allowed                      */
+  float* logprob_out;     /* [K][N][A] per component: TANH_MEAN Normal(mean, std).log_prob(action) of the
+                             CLAMPED action (ppo.py:97-98); TANH_SAMPLE Normal.log_prob(u) - log(1 -
+                             action^2 + 1e-6), u the pre-tanh sample (sac_mlp.py:74-77).  NULL allowed */
 } QrPolicyRollout;
 
 /* K env-steps in ONE launch with the policy inside the loop: per step, each env's actor(s) are

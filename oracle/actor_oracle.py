@@ -35,3 +35,21 @@ def choose_action(p, obs, eps=None, max_action=1.0):
     action = np.clip(mean + std * np.asarray(eps, np.float64), -max_action, max_action)  # ppo.py:96-97
     logprob = -((action - mean) ** 2) / (2.0 * std ** 2) - log_std - LOG_SQRT_2PI       # torch Normal.log_prob
     return action, logprob, mean
+
+
+def sac_sample(p, obs, eps=None):
+    """MLP_Actor_SAC.forward + sample (algos/sac/sac_mlp.py:36-82).  p additionally holds log_std_w [A,H],
+    log_std_b [A].  eps: standard normals (rsample = mean + std * eps); None = the deterministic
+    action tanh(mean) (sac.py:104-105).  Returns (action, per-component log_prob, mean, log_std)."""
+    x = np.asarray(obs, dtype=np.float64)
+    h = np.maximum(x @ np.asarray(p["fc1_w"], np.float64).T + np.asarray(p["fc1_b"], np.float64), 0.0)
+    h = np.maximum(h @ np.asarray(p["fc2_w"], np.float64).T + np.asarray(p["fc2_b"], np.float64), 0.0)
+    mean = h @ np.asarray(p["mean_w"], np.float64).T + np.asarray(p["mean_b"], np.float64)
+    log_std = np.clip(h @ np.asarray(p["log_std_w"], np.float64).T + np.asarray(p["log_std_b"], np.float64), -20.0, 2.0)
+    if eps is None:
+        return np.tanh(mean), None, mean, log_std
+    std = np.exp(log_std)
+    u = mean + std * np.asarray(eps, np.float64)
+    action = np.tanh(u)
+    logprob = -((u - mean) ** 2) / (2.0 * std ** 2) - log_std - LOG_SQRT_2PI - np.log(1.0 - action ** 2 + 1e-6)
+    return action, logprob, mean, log_std

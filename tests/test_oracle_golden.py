@@ -226,3 +226,21 @@ def test_actor_loop_oracle_vs_reference(golden, kind):
         assert np.array_equal(o["done"], d["dones"][t])
     assert worst["state"] <= 1e-9 and worst["obs"] <= 1e-6 and worst["rwd"] <= 1e-6, worst
     assert worst["act"] <= 2e-6 and worst["logp"] <= 5e-5, worst
+
+
+@pytest.mark.parametrize("tag", ["coupled0", "decoupled0", "decoupled1"])
+def test_sac_actor_oracle_vs_reference_module(golden, tag):
+    """oracle sac_sample against the reference's MLP_Actor_SAC forward / sample (torch float32)."""
+    from oracle import actor_oracle as ao
+    d = golden("actor_sac")
+    p = {n: d[f"{tag}_{n}"] for n in ("fc1_w", "fc1_b", "fc2_w", "fc2_b", "mean_w", "mean_b", "log_std_w", "log_std_b")}
+    action, logprob, mean, log_std = ao.sac_sample(p, d[f"{tag}_obs"], d[f"{tag}_eps"])
+    scale = np.maximum(np.abs(d[f"{tag}_mean"]), 1.0)
+    assert (np.abs(mean - d[f"{tag}_mean"]) / scale).max() <= 1e-5   # float32 torch sums over inputs up to 60 in magnitude
+    assert np.abs(log_std - d[f"{tag}_log_std"]).max() <= 2e-5 and log_std.min() == -20.0
+    ok = np.abs(d[f"{tag}_log_std"]) < 1.99        # away from the clamp edges a 1e-6 shift of the head moves nothing else
+    assert np.abs(action - d[f"{tag}_action"])[ok].max() <= 5e-5
+    inner = ok & (np.abs(d[f"{tag}_action"]) < 0.99)   # 1 - a^2 cancels in float32 near saturation
+    assert np.abs(logprob - d[f"{tag}_logprob"])[inner].max() <= 5e-4
+    det, none, _, _ = ao.sac_sample(p, d[f"{tag}_obs"], None)
+    assert none is None and np.abs(det - np.tanh(d[f"{tag}_mean"].astype(np.float64))).max() <= 2e-6

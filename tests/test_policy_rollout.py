@@ -257,3 +257,31 @@ def test_td3_actor_in_kernel_vs_reference_module(golden, kind):
     assert np.abs(_np(noisy["action"][0]) - want).max() <= 1e-6
     greedy = env.rollout_actor([ActorParams.from_td3_module(m, 0.0) for m in mods], 1, obs=obs, deterministic=True)
     assert np.abs(_np(greedy["action"][0]) - np.concatenate([d[f"{t}_mean"] for t in tags], 1)).max() <= 1e-6
+
+
+@pytest.mark.parametrize("kind", ["coupled", "decoupled"])
+def test_sac_actor_in_kernel_vs_reference_module(golden, kind):
+    """MLP_Actor_SAC.sample (sac_mlp.py:60-82) in the kernel: state-dependent log_std head (second MFMA
+    head), clamp to [-20, 2], action = tanh(mean + std eps), squashed log-prob; eval = tanh(mean)."""
+    from gym_rotor_amd import ActorParams, _lib
+    d = golden("actor_sac")
+    tags = [f"{kind}0"] if kind == "coupled" else [f"{kind}0", f"{kind}1"]
+    n = d[f"{tags[0]}_obs"].shape[0]
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    actors = [ActorParams(cu(d[f"{t}_fc1_w"]), cu(d[f"{t}_fc1_b"]), cu(d[f"{t}_fc2_w"]), cu(d[f"{t}_fc2_b"]), cu(d[f"{t}_mean_w"]),
+                          cu(d[f"{t}_mean_b"]), None, cu(d[f"{t}_log_std_w"]), cu(d[f"{t}_log_std_b"]), _lib.ACTOR_TANH_SAMPLE) for t in tags]
+    env = _env(kind, n)
+    env.reset("train")
+    obs = [cu(d[f"{t}_obs"]) for t in tags]
+    eps = cu(np.concatenate([d[f"{t}_eps"] for t in tags], 1)[None])
+    out = env.rollout_actor(actors, 1, obs=obs, noise=eps)
+    want_a = np.concatenate([d[f"{t}_action"] for t in tags], 1)
+    want_l = np.concatenate([d[f"{t}_logprob"] for t in tags], 1)
+    ls = np.concatenate([d[f"{t}_log_std"] for t in tags], 1)
+    ok = np.abs(ls) < 1.99
+    assert np.abs(_np(out["action"][0]) - want_a)[ok].max() <= 3e-5
+    inner = ok & (np.abs(want_a) < 0.99)
+    assert np.abs(_np(out["logprob"][0]) - want_l)[inner].max() <= 1e-3
+    det = env.rollout_actor(actors, 1, obs=obs, deterministic=True)
+    want_m = np.tanh(np.concatenate([d[f"{t}_mean"] for t in tags], 1).astype(np.float64))
+    assert np.abs(_np(det["action"][0]) - want_m).max() <= 3e-6

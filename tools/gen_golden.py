@@ -21,6 +21,7 @@ Files written (see tests/golden/README.md for the field lists):
   trajgoal_m{0,1,6}_{kind}.npz  closed loop env + TrajectoryGenerator (modes 0/1/6) as main.py drives them
   actor_ppo.npz            the reference's MLP_Actor_PPO (torch): weights, obs -> mean, injected-noise action, log_prob
   actor_td3.npz            the reference's MLP_Actor_TD3 + explicit-noise choose_action
+  actor_sac.npz            the reference's MLP_Actor_SAC forward + explicit-noise sample
   actorloop_{kind}.npz     closed loop: reference wrapper env stepped by the reference's actor(s), 4 envs x 200 steps
 """
 import os
@@ -526,6 +527,45 @@ def gen_actor_td3(seed=0, n=256, sigma=0.1):
     print("actor_td3 golden written")
 
 
+def gen_actor_sac(seed=0, n=256):
+    """The reference's SAC actor (algos/sac/sac_mlp.py): forward() for mean / log_std, and sample() with the
+    reparameterisation noise made explicit (x_t = mean + std * eps), per-component log-probs before the sum."""
+    import types
+    import torch
+    from torch.distributions import Normal
+    from algos.sac.sac_mlp import MLP_Actor_SAC, epsilon
+    rng = np.random.default_rng(6800 + seed)
+    out = {}
+    for kind in ("coupled", "decoupled"):
+        dims = ACTOR_DIMS[kind]
+        args = types.SimpleNamespace(obs_dim_n=[d[0] for d in dims], actor_hidden_dim=[d[1] for d in dims], action_dim_n=[d[2] for d in dims])
+        torch.manual_seed(400 + seed)
+        for k, (D, H, A) in enumerate(dims):
+            a = MLP_Actor_SAC(args, k)
+            with torch.no_grad():   # xavier init with zero bias: move the biases so that every term is exercised
+                a.mean_linear.bias.uniform_(-0.2, 0.2); a.log_std_linear.bias.uniform_(-2.0, -0.5)
+                a.fc1.bias.uniform_(-0.2, 0.2); a.fc2.bias.uniform_(-0.2, 0.2)
+            obs = rng.uniform(-1.5, 1.5, (n, D)).astype(np.float32)
+            obs[: n // 16] *= 40.0   # a few rows far out: log_std hits its clamp
+            eps = rng.standard_normal((n, A)).astype(np.float32)
+            with torch.no_grad():
+                mean, log_std = a(torch.from_numpy(obs))
+                normal = Normal(mean, log_std.exp())
+                x_t = mean + log_std.exp() * torch.from_numpy(eps)
+                action = torch.tanh(x_t)
+                logp = normal.log_prob(x_t) - torch.log((1 - action.pow(2)) + epsilon)
+            tag = f"{kind}{k}"
+            out.update({f"{tag}_fc1_w": a.fc1.weight.detach().numpy().copy(), f"{tag}_fc1_b": a.fc1.bias.detach().numpy().copy(),
+                        f"{tag}_fc2_w": a.fc2.weight.detach().numpy().copy(), f"{tag}_fc2_b": a.fc2.bias.detach().numpy().copy(),
+                        f"{tag}_mean_w": a.mean_linear.weight.detach().numpy().copy(), f"{tag}_mean_b": a.mean_linear.bias.detach().numpy().copy(),
+                        f"{tag}_log_std_w": a.log_std_linear.weight.detach().numpy().copy(),
+                        f"{tag}_log_std_b": a.log_std_linear.bias.detach().numpy().copy(),
+                        f"{tag}_obs": obs, f"{tag}_eps": eps, f"{tag}_mean": mean.numpy(), f"{tag}_log_std": log_std.numpy(),
+                        f"{tag}_action": action.numpy(), f"{tag}_logprob": logp.numpy()})
+            print(f"actor_sac {tag}: log_std range {float(log_std.min()):.2f}..{float(log_std.max()):.2f}, |action| max {float(action.abs().max()):.4f}")
+    np.savez_compressed(os.path.join(OUT, "actor_sac.npz"), **out)
+
+
 def gen_actorloop(kind, n_env=4, T=200, seed=0):
     """The collection loop of main.py:141-166 with the reference's env AND the reference's actor(s):
     obs_t -> choose_action (injected noise) -> concatenate -> env.step -> obs_{t+1}.  Free run."""
@@ -583,6 +623,7 @@ if __name__ == "__main__":
     if ARGV[:1] == ["actor"]:  # only the actor files
         gen_actor()
         gen_actor_td3()
+        gen_actor_sac()
         for kind in ("coupled", "decoupled"):
             gen_actorloop(kind)
         sys.exit(0)
@@ -601,5 +642,6 @@ if __name__ == "__main__":
             gen_trajgoal(kind, mode)
     gen_actor()
     gen_actor_td3()
+    gen_actor_sac()
     for kind in ("coupled", "decoupled"):
         gen_actorloop(kind)
