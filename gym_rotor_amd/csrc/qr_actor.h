@@ -94,7 +94,10 @@ struct ActorLds {
 //            accumulate into ONE D: lane (g, c) then holds mean[r] of env 16 g + c — its own env.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int D>  // obs_dim 23 (COUPLED) or 15 (DECOUPLED agent 1); hidden 16, 4 actions
+// GENERAL = false: the PPO / TD3 form only (no log_std head, tanh-of-mean rule) — what the launcher
+// picks when no actor needs more, so that the common path carries neither the second head's registers
+// nor the rule's branches.
+template <int D, bool GENERAL>  // obs_dim 23 (COUPLED) or 15 (DECOUPLED agent 1); hidden 16, 4 actions
 struct ActorMfma {
   static constexpr int KS = (D + 3) / 4;
   float a1[KS], a2[4], w3[4], w3s[4], bias1[4], bias2[4], bias3[4], bias3s[4], log_std[4];
@@ -106,7 +109,7 @@ struct ActorMfma {
     for (int s = 0; s < KS; ++s) a1[s] = (4 * s + g < D) ? p.fc1_w[c * D + 4 * s + g] : 0.0f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) { a2[s] = p.fc2_w[c * 16 + 4 * g + s]; w3[s] = p.mean_w[(c & 3) * 16 + 4 * g + s]; }
-    ls_head = p.ls_w != nullptr;  // wave-uniform
+    ls_head = GENERAL && p.ls_w != nullptr;  // wave-uniform
 #pragma unroll
     for (int s = 0; s < 4; ++s) w3s[s] = ls_head ? p.ls_w[(c & 3) * 16 + 4 * g + s] : 0.0f;
 #pragma unroll
@@ -184,12 +187,12 @@ struct ActorMfma {
 //     Normal(mean, std).log_prob of the CLAMPED action (ppo.py:97-98).
 //   QR_ACTOR_TANH_SAMPLE MLP_Actor_SAC.sample (sac_mlp.py:60-82): log_std clamped to [-20, 2];
 //     u = pre + exp(log_std) eps; a = tanh(u); logp = Normal(pre, std).log_prob(u) - log(1 - a^2 + 1e-6).
-template <int A>
+template <int A, bool GENERAL>
 __device__ __forceinline__ void actor_sample(int squash, bool ls_head, const float* pre, const float* log_std, const float* eps,
                                              bool deterministic, float max_action, float* act, float* logp) {
 #pragma unroll
   for (int j = 0; j < A; ++j) {
-    if (squash == QR_ACTOR_TANH_SAMPLE) {
+    if (GENERAL && squash == QR_ACTOR_TANH_SAMPLE) {
       const float ls = fminf(fmaxf(log_std[j], -20.0f), 2.0f);
       const float sd = __expf(ls);
       const float z = deterministic ? 0.0f : eps[j];
@@ -197,7 +200,7 @@ __device__ __forceinline__ void actor_sample(int squash, bool ls_head, const flo
       act[j] = aj;
       logp[j] = fmaf(-0.5f * z, z, -ls - 0.91893853320467274f) - __logf(fmaf(-aj, aj, 1.0f) + 1e-6f);
     } else {
-      const float ls = ls_head ? fminf(fmaxf(log_std[j], -20.0f), 2.0f) : log_std[j];
+      const float ls = (GENERAL && ls_head) ? fminf(fmaxf(log_std[j], -20.0f), 2.0f) : log_std[j];
       const float sd = __expf(ls);
       const float mean = tanh_fast(pre[j]);
       const float raw = deterministic ? mean : fmaf(sd, eps[j], mean);

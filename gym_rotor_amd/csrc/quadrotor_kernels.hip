@@ -64,9 +64,10 @@ namespace qr {
 // separate instantiation so that the default path carries none of its registers.  ADAPT = the
 // rate-adaptive substep count (QrCoeffs::w_adapt); launch_kind() picks the plain instantiation
 // whenever adaptivity provably cannot trigger.
-// POLICY = qr_rollout_actor: the action of every step comes from the PPO actor(s) evaluated on the
-// env's current observation, which stays in registers from one step to the next.
-template <int KIND, typename XV, typename QW, int B, bool TRAJ, bool ADAPT, bool POLICY = false>
+// POLICY != 0 = qr_rollout_actor: the action of every step comes from the actor(s) evaluated on the
+// env's current observation, which stays in registers from one step to the next.  1: PPO / TD3 actors
+// (parameter log_std, tanh-of-mean rule); 2: any reference MLP actor (adds SAC's log_std head and rule).
+template <int KIND, typename XV, typename QW, int B, bool TRAJ, bool ADAPT, int POLICY = 0>
 __global__ __launch_bounds__(B, ((TRAJ || POLICY) ? 1 : QR_WAVES_PER_SIMD))
 void step_kernel(void* pos_vel, void* att_rate, const float* action, float* params, float* integ, int64_t n_envs,
                  int64_t ld_envs, const Args a_in) {
@@ -155,7 +156,8 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   float po0[D0], po1[D1];
   // agent 0 (23 / 15 -> 16 -> 16 -> 4, args_parse.py:40, main.py:68-73) on the matrix cores, weights
   // resident in registers; agent 1 of DECOUPLED (3 -> 4 -> 4 -> 1: 32 FMAs) per lane from LDS
-  ActorMfma<D0> actor0;
+  constexpr bool GENERAL = POLICY == 2;
+  ActorMfma<D0, GENERAL> actor0;
   using Actor1 = ActorLds<3, 4, 1>;
   __shared__ __attribute__((aligned(16))) float wsm[POLICY ? Actor1::SIZE : 4];
   if constexpr (POLICY) {
@@ -182,7 +184,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       }
       if constexpr (KIND == QR_KIND_DECOUPLED) {
         float p1[1], l1[1];
-        Actor1::heads(wsm, a.actor[1].ls_w != nullptr, po1, p1, l1);
+        Actor1::heads(wsm, GENERAL && a.actor[1].ls_w != nullptr, po1, p1, l1);
         pre[A - 1] = p1[0]; ls[A - 1] = l1[0];
       }
 #pragma unroll
@@ -206,9 +208,9 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         }
       }
       __syncthreads();  // the tile is reused by the row stores below
-      actor_sample<4>(a.actor[0].squash, actor0.ls_head, &pre[0], &ls[0], &eps[0], a.deterministic != 0, a.max_action, &act[0], &logp[0]);
+      actor_sample<4, GENERAL>(a.actor[0].squash, actor0.ls_head, &pre[0], &ls[0], &eps[0], a.deterministic != 0, a.max_action, &act[0], &logp[0]);
       if constexpr (A > 4)
-        actor_sample<1>(a.actor[1].squash, a.actor[1].ls_w != nullptr, &pre[A - 1], &ls[A - 1], &eps[A - 1], a.deterministic != 0,
+        actor_sample<1, GENERAL>(a.actor[1].squash, a.actor[1].ls_w != nullptr, &pre[A - 1], &ls[A - 1], &eps[A - 1], a.deterministic != 0,
                         a.max_action, &act[A - 1], &logp[A - 1]);
       if (active) {
         const int64_t arow = ((int64_t)t * N + first) * A;
@@ -713,8 +715,13 @@ static void launch_kind(const Args& a, hipStream_t s) {
 #define QR_STEP_ARGS a.pos_vel, a.att_rate, a.action, a.params, a.integ, a.n, a.ld, a
   if constexpr (KIND != QR_KIND_QUAD) {
     if (a.act_out != nullptr) {  // qr_rollout_actor
-      if (a.goal_mode != QR_GOAL_EXTERNAL) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-      else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+      const bool general = a.actor[0].ls_w || a.actor[0].squash != QR_ACTOR_TANH_MEAN ||
+                           (KIND == QR_KIND_DECOUPLED && (a.actor[1].ls_w || a.actor[1].squash != QR_ACTOR_TANH_MEAN));
+      const bool traj = a.goal_mode != QR_GOAL_EXTERNAL;
+      if (traj && general) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true, 2>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+      else if (traj) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true, 1>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+      else if (general) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 2>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+      else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 1>), grid, dim3(64), 0, s, QR_STEP_ARGS);
       return;
     }
   }
