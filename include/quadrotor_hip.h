@@ -55,7 +55,7 @@ extern "C" {
 
 /* argument errors */
 #define QR_E_NULL   (-1) /* a required pointer is NULL             */
-#define QR_E_KIND   (-2) /* kind / layout out of range             */
+#define QR_E_KIND   (-2) /* kind / layout / actor.squash out of range, or an entry point undefined for the kind */
 #define QR_E_SIZE   (-3) /* num_envs < 0 or > 22 369 621 (32-bit SoA offsets), bad field_stride, substeps < 1, n_steps < 1 */
 #define QR_E_ALIGN  (-4) /* a buffer is not 16-byte aligned        */
 
