@@ -16,13 +16,13 @@ LIB_PATH = os.environ.get("QR_LIB", os.path.join(_HERE, "libquadrotor_hip.so"))
 KIND_QUAD, KIND_COUPLED, KIND_DECOUPLED = 0, 1, 2
 KIND_ID = {"quad": KIND_QUAD, "coupled": KIND_COUPLED, "decoupled": KIND_DECOUPLED}
 FLAG_AUTO_RESET, FLAG_EVAL_RESET, FLAG_NO_UDM = 1, 2, 4
-ABI_VERSION = 9
+ABI_VERSION = 10
 GOAL_EXTERNAL, GOAL_MODE0, GOAL_MODE1, GOAL_MODE6 = 0, 1, 2, 3
 GOAL_ID = {None: 0, 0: 1, 1: 2, 6: 3}  # TrajectoryGenerator mode -> QR_GOAL_*
 LAYOUT_ID = {"mixed": 0, "f64": 1, "f32": 2}
 
 ERRORS = {-1: "QR_E_NULL: a required pointer is NULL", -2: "QR_E_KIND: bad env kind",
-          -3: "QR_E_SIZE: bad num_envs / substeps / n_steps", -4: "QR_E_ALIGN: buffer not 16-byte aligned"}
+          -3: "QR_E_SIZE: bad num_envs / substeps / n_steps / coefficients", -4: "QR_E_ALIGN: buffer not 16-byte aligned"}
 
 # every symbol include/quadrotor_hip.h declares
 SYMBOLS = ("qr_step", "qr_rollout", "qr_rollout_actor", "qr_error_obs", "qr_reset", "qr_get_state", "qr_set_state",
@@ -34,7 +34,8 @@ class QrCoeffs(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "Cx", "CIx", "Cv", "Cb1", "CIb1", "CW", "Cw12", "CW3", "alpha", "beta", "dt",
         "x_lim", "v_lim", "W_lim", "eIx_lim", "eIb1_lim", "euler_lim_deg", "udm_fraction",
-        "eight_T", "eight_A1", "eight_A2", "eight_w_b1d", "eight_alt_d", "eight_eps", "eight_count", "w_adapt")]
+        "eight_T", "eight_A1", "eight_A2", "eight_w_b1d", "eight_alt_d", "eight_eps", "eight_count", "w_adapt",
+        "m_nominal", "d_nominal", "J1_nominal", "J3_nominal", "c_tf_nominal", "c_tw_nominal", "g", "min_force")]
 
 
 class QrEnv(C.Structure):
@@ -43,13 +44,14 @@ class QrEnv(C.Structure):
                 ("pos_vel", C.c_void_p), ("att_rate", C.c_void_p),
                 ("integ", C.c_void_p), ("params", C.c_void_p), ("goal", C.c_void_p),
                 ("traj", C.c_void_p), ("goal_mode", C.c_int32), ("reserved0", C.c_int32),
-                ("episode", C.c_void_p), ("steps", C.c_void_p),
+                ("episode", C.c_void_p), ("steps", C.c_void_p), ("reset_count", C.c_void_p),
                 ("max_episode_steps", C.c_int32), ("flags", C.c_uint32), ("coeffs", QrCoeffs)]
 
 
 class QrStepOut(C.Structure):
     _fields_ = [("obs0", C.c_void_p), ("obs1", C.c_void_p), ("reward", C.c_void_p),
-                ("reward_raw", C.c_void_p), ("done", C.c_void_p), ("truncated", C.c_void_p)]
+                ("reward_raw", C.c_void_p), ("done", C.c_void_p), ("truncated", C.c_void_p),
+                ("final_obs0", C.c_void_p), ("final_obs1", C.c_void_p)]
 
 
 class QrActor(C.Structure):
@@ -106,7 +108,7 @@ def load():
     lib.qr_get_state.restype = C.c_int
     lib.qr_get_state.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p]
     lib.qr_set_state.restype = C.c_int
-    lib.qr_set_state.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.qr_set_state.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.qr_traj_start.restype = C.c_int
     lib.qr_traj_start.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p, C.c_void_p]
     lib.qr_get_desired.restype = C.c_int

@@ -11,16 +11,24 @@ namespace qr {
 // ------------------------------------------------------------------------------------
 // Kernel argument block (passed by value in kernarg memory)
 // ------------------------------------------------------------------------------------
-struct Coeffs {  // double-precision copy of QrCoeffs + derived reward floors
-  double Cx, CIx, Cv, Cb1, CIb1, CW, Cw12, CW3, alpha, beta, dt;
-  double x_lim, v_lim, W_lim, eIx_lim, eIb1_lim;
-  double sin_euler_lim, tan_euler_lim, udm;
-  double rmin_mono, rmin_1, rmin_2;
-  // reciprocals formed once on the host (an f64 division costs ~35 VALU slots on the device)
-  double inv_x_lim, inv_v_lim, inv_W_lim, inv_eIx_lim, inv_eIb1_lim, inv_nrmin_mono, inv_nrmin_1, inv_nrmin_2;
+// Coefficients as the kernels consume them.  Only what enters float64 arithmetic is a double:
+// every field that is used sits in SGPRs for the whole kernel, and with ~50 doubles the round-1
+// kernel spilled SGPRs into VGPR lanes (42 v_writelane + 12 v_readlane on the step's critical
+// path).  Reciprocals are formed once on the host (an f64 division is ~35 VALU slots).
+struct Coeffs {
+  // float64: step length, the limits observations / terminations are formed with, nominal parameters
+  double dt, inv_x_lim, inv_v_lim, inv_W_lim, W_lim, sin_euler_lim, tan_euler_lim, inv_w_adapt;
+  double x_lim, v_lim;                       // (float64 layout only: x, v held as doubles)
+  double nom[6], g, min_force;               // quad.py:28-36 (a QuadConstants may override them)
+  // float32: rewards (formed in float32 on float32 observations, like NumPy >= 2), integrators, reset ranges
+  float Cx, CIx, Cv, Cb1, CIb1, CW, Cw12, CW3, alpha, beta, hdt;
+  float x_lim_f, x_lim_up, v_lim_up;         // *_up = smallest float >= the limit: |x_f32| < up  <=>  |x_f32| < limit
+  float inv_eIx_lim, inv_eIb1_lim;
+  float rmin_mono, rmin_1, rmin_2, inv_nrmin_mono, inv_nrmin_1, inv_nrmin_2;
+  float udm, reset_v, reset_W;               // reset sampling: UDM fraction, v_lim / 2, W_lim / 2 (quad.py:348-351)
+  float nom_f[6], g_f;
   // eight-shaped curve (trajectory_generator.py:98-110, 418-505)
   float e8_w1, e8_w2, e8_k, e8_A1, e8_A2, e8_wb, e8_alt, e8_tmax;
-  double inv_w_adapt;  // 1 / w_adapt, 0 = fixed substep count
 };
 
 struct ActorW {  // QrActor's tensors (torch.nn.Linear layout: weight [out][in])
@@ -39,10 +47,13 @@ struct Args {
   float* traj;
   int32_t* episode;
   int32_t* steps;
+  int32_t* reset_count;   // [ceil(N/64)] per-tile counter of the in-launch reset stream
   // per-call
   const float* action;
   float* obs0;
   float* obs1;
+  float* final_obs0;      // optional: pre-reset observation rows of envs that are re-sampled in the launch
+  float* final_obs1;
   float* reward;
   float* reward_raw;
   uint8_t* done;
@@ -50,6 +61,7 @@ struct Args {
   const uint8_t* mask;
   double* rows_out;       // qr_get_state
   const double* rows_in;  // qr_set_state
+  int32_t* status;        // qr_set_state: count of rejected rows (det R <= 0 / non-finite)
   const float* draws;     // qr_traj_start: injected [3][N] theta_b1d, t_traj, w_b1d
   float* goal_rows;       // qr_get_desired: [N][15]
   int32_t goal_mode;
@@ -76,9 +88,6 @@ struct Args {
   Coeffs c;
 };
 
-// Nominal parameters (quad.py:28-33)
-constexpr double kMnom = 2.15, kDnom = 0.23, kJ1nom = 0.022, kJ3nom = 0.035, kCtfNom = 0.0135,
-                 kCtwNom = 2.2, kG = 9.81, kMinForce = 0.5;
 constexpr double kPi = 3.14159265358979323846;
 
 template <typename T> __device__ __forceinline__ T clampT(T v, T lo, T hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -96,15 +105,17 @@ __device__ __forceinline__ float recip(float a) {
   return fmaf(fmaf(-a, x, 1.0f), x, x);
 }
 
-// Per-env working set held in VGPRs.  y = (v[0..2], q[3..6] = w,x,y,z, W[7..9]) is the RK4
-// vector; x' = v is integrated from the stage velocities.  Everything that is STORED as
-// float32 is also HELD as float32 (converted at use): the step kernel is register-bound —
-// two waves per SIMD need <= 256 VGPRs — and a float64 copy of 26 words costs 26 registers.
-template <typename T>
+// Per-env working set held in VGPRs: the 13-word state (x, v, unit quaternion q = (w,x,y,z), W) plus
+// parameters, goal and integrator words.  T is the type q and W are held and accumulated in, X the
+// type of x and v (mixed layout: T = double, X = float — what is STORED as float32 is also HELD as
+// float32: the kernel's occupancy is set by its VGPR count).
+template <typename T, typename X>
 struct Work {
-  T x[3];
-  T y[10];
-  float prm[6];    // m, d, J1(=J2), J3, c_tf, c_tw (quad.py:359-387); kNominal[] when not randomised
+  X x[3];
+  X v[3];
+  T q[4];
+  T W[3];
+  float prm[6];    // m, d, J1(=J2), J3, c_tf, c_tw (quad.py:359-387); the nominal values when not randomised
   float goal[12];  // xd, vd, b1d, Wd
   float integ[8];  // eIx, g_x prev, eIb1, g_b prev
   bool nominal;    // parameters are the exact float64 nominal values, not prm[]
@@ -113,17 +124,18 @@ struct Work {
 template <typename T>
 struct Phys {  // what set_random_parameters derives (quad.py:389-404), formed when needed
   T m, d, J1, J3, ctf, ctw;
-  T max_force, avrg_act, scale_act;
+  T min_force, max_force, avrg_act, scale_act;
   template <typename W>
-  __device__ __forceinline__ explicit Phys(const W& w) {
+  __device__ __forceinline__ Phys(const W& w, const Coeffs& c) {
     if (w.nominal) {
-      m = T(kMnom); d = T(kDnom); J1 = T(kJ1nom); J3 = T(kJ3nom); ctf = T(kCtfNom); ctw = T(kCtwNom);
+      m = T(c.nom[0]); d = T(c.nom[1]); J1 = T(c.nom[2]); J3 = T(c.nom[3]); ctf = T(c.nom[4]); ctw = T(c.nom[5]);
     } else {
       m = T(w.prm[0]); d = T(w.prm[1]); J1 = T(w.prm[2]); J3 = T(w.prm[3]); ctf = T(w.prm[4]); ctw = T(w.prm[5]);
     }
-    const T hover = m * T(kG * 0.25);
+    const T hover = m * T(c.g * 0.25);
+    min_force = T(c.min_force);
     max_force = ctw * hover;
-    avrg_act = (T(kMinForce) + max_force) * T(0.5);
+    avrg_act = (min_force + max_force) * T(0.5);
     scale_act = max_force - avrg_act;
   }
 };

@@ -27,10 +27,19 @@ __device__ __forceinline__ void quat_to_R(const T* q, T (&R)[9]) {
 // internal attitude is a unit quaternion, the nearest rotation is taken always (for an R
 // that is orthonormal to round-off this changes nothing).  The polar factor is computed by
 // the Newton iteration X <- (X + X^-T)/2, which converges quadratically to U V^T (det R > 0).
-__device__ void R_to_quat(const double* Rin, double (&q)[4]) {
+// Returns false — q untouched — when R has no nearest rotation: det R <= 0 (the closest orthogonal
+// matrix is a reflection) or a non-finite entry.
+__device__ bool R_to_quat(const double* Rin, double (&q)[4]) {
   double X[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) X[i] = Rin[i];
+  {
+    const double det = X[0] * (X[4] * X[8] - X[5] * X[7]) + X[1] * (X[5] * X[6] - X[3] * X[8]) + X[2] * (X[3] * X[7] - X[4] * X[6]);
+    double amax = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) amax = fmax(amax, fabs(X[i]));
+    if (!(det > 1e-300) || !(amax < 1e150)) return false;  // also catches NaN / Inf
+  }
   for (int it = 0; it < 40; ++it) {
     double C[9];  // C = cof(X), column-major like X; X^-T = C / det X
     C[0] = X[4] * X[8] - X[5] * X[7]; C[1] = X[5] * X[6] - X[3] * X[8]; C[2] = X[3] * X[7] - X[4] * X[6];
@@ -63,6 +72,7 @@ __device__ void R_to_quat(const double* Rin, double (&q)[4]) {
   }
   const double inv = 1.0 / sqrt(w * w + x * x + y * y + z * z);
   q[0] = w * inv; q[1] = x * inv; q[2] = y * inv; q[3] = z * inv;
+  return true;
 }
 
 // ------------------------------------------------------------------------------------
@@ -73,8 +83,10 @@ struct Dyn {
   T c;           // f/m
   T A1;          // (J2-J3)/J1 with J2 = J1; the W2' coefficient (J3-J1)/J2 is -A1
   T U1, U2, U3;  // M_i / J_i
+  T g;
 };
 
+// y = (v[0..2], q[3..6] = w,x,y,z, W[7..9])
 template <typename T>
 __device__ __forceinline__ void rhs(const T* __restrict__ y, T* __restrict__ k, const Dyn<T>& p) {
   const T qw = y[3], qx = y[4], qy = y[5], qz = y[6];
@@ -83,7 +95,7 @@ __device__ __forceinline__ void rhs(const T* __restrict__ y, T* __restrict__ k, 
   const T c2 = T(2) * p.c;
   k[0] = -c2 * (qx * qz + qw * qy);
   k[1] = -c2 * (qy * qz - qw * qx);
-  k[2] = (T(kG) - p.c) + c2 * (qx * qx + qy * qy);
+  k[2] = (p.g - p.c) + c2 * (qx * qx + qy * qy);
   // q' = q (0, W) / 2   (<=> R' = R hat(W))
   const T h = T(0.5);
   k[3] = -h * (qx * W1 + qy * W2 + qz * W3);
@@ -128,6 +140,141 @@ __device__ __forceinline__ void renorm_quat(T* q) {
   const T r = T(1.5) - T(0.5) * (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
 #pragma unroll
   for (int i = 0; i < 4; ++i) q[i] *= r;
+}
+
+// Uniform-precision layouts (f64: the reference-grade mode, 4th-order convergence to the
+// reference's DOP853 down to 1e-10; f32: the approximate mode): plain RK4 in T.
+template <typename T>
+__device__ __forceinline__ void integrate(T (&x)[3], T (&v)[3], T (&q)[4], T (&W)[3], const Dyn<T>& p, int nsub, T h) {
+  T y[10];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { y[j] = v[j]; y[7 + j] = W[j]; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) y[3 + j] = q[j];
+  for (int s = 0; s < nsub; ++s) rk4_step(x, y, h, p);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { v[j] = y[j]; W[j] = y[7 + j]; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) q[j] = y[3 + j];
+}
+
+// ------------------------------------------------------------------------------------
+// The default (`mixed`) layout: x, v float32; q, W float64.  Which arithmetic needs float64?
+//   * W: its increments are large (|W'| up to ~120 rad/s^2 from the torques, ~500 from the
+//     gyroscopic term in a tumbling free run) and every error in W is integrated once more into
+//     q.  W1, W2 are therefore integrated by RK4 in float64 — cheap, because W3' = M3/J3 is
+//     constant over the step (zero-order-hold torque, J1 = J2), so W3(t) is linear in time,
+//     drops out of the RK4 vector and turns the W1-W2 system into a linear one with a known
+//     time-varying coefficient a(t) = A1 W3(t).
+//   * q: only its ACCUMULATION.  The increment dq = h/6 (k1 + 2 k2 + 2 k3 + k4) is ~|W| h / 2 <= 0.1,
+//     so forming the stage quaternions and derivatives in float32 (from the float32-rounded
+//     substep-start q and float32 copies of the stage rates) perturbs q by ~1e-9 per step,
+//     pseudo-randomly; the float64 state absorbs the increments exactly.
+//   * x, v are float32 in memory already; their increments are quadratures of the thrust
+//     direction R(q) e3 over the stages, linear in it, so the stage sums are simply accumulated
+//     over all substeps (float32) and applied once.
+// Measured against the float64 DOP853 oracle (tools/numerics_f32stage.py: 1000 free-run steps,
+// |W| up to 26 rad/s): R 1.3e-6 (all-float64 RK4: 1.0e-6, truncation), x, v 4e-7; with 10
+// substeps R 9e-7 — the bar is 1e-5.  On gfx950 an f32 VALU instruction issues at up to twice
+// the f64 rate once two waves share a SIMD, and the float32 stage code needs half the registers.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void integrate(float (&x)[3], float (&v)[3], double (&q)[4], double (&W)[3], const Dyn<double>& p, int nsub,
+                                          double h) {
+  const float hf = (float)h, h2f = 0.5f * hf, h6f = hf * (1.0f / 6.0f);
+  const double h2 = 0.5 * h, h6 = h * (1.0 / 6.0);
+  float qs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) qs[j] = (float)q[j];
+  // half body rates (q' = q (0, W/2)); a(t) = A1 W3(t) and W3(t)/2 advance by a constant per half substep
+  float w1 = 0.5f * (float)W[0], w2 = 0.5f * (float)W[1], w3 = 0.5f * (float)W[2];
+  double a3 = p.A1 * W[2];
+  const double da = p.A1 * p.U3 * h2;
+  float a3f = (float)a3;
+  const float daf = (float)da, dw3 = (float)(0.5 * p.U3 * h2);
+  const float u1 = (float)(0.5 * p.U1), u2 = (float)(0.5 * p.U2);
+  double W1 = W[0], W2 = W[1];
+  float g1[3] = {0.f, 0.f, 0.f}, g23[3] = {0.f, 0.f, 0.f}, g4[3] = {0.f, 0.f, 0.f}, xx[3] = {0.f, 0.f, 0.f};
+  // thrust direction, un-normalised: R e3 = (2 u0, 2 u1, 1 - 2 u2)
+#define QR_THRUST(G, Q)                                         \
+  G[0] = fmaf(Q[1], Q[3], fmaf(Q[0], Q[2], G[0]));              \
+  G[1] = fmaf(Q[2], Q[3], fmaf(-Q[0], Q[1], G[1]));             \
+  G[2] = fmaf(Q[1], Q[1], fmaf(Q[2], Q[2], G[2]));
+#define QR_QDOT(K, Q, A, B, C)                                  \
+  K[0] = -fmaf(Q[1], A, fmaf(Q[2], B, Q[3] * C));               \
+  K[1] = fmaf(Q[0], A, fmaf(Q[2], C, -Q[3] * B));               \
+  K[2] = fmaf(Q[0], B, fmaf(Q[3], A, -Q[1] * C));               \
+  K[3] = fmaf(Q[0], C, fmaf(Q[1], B, -Q[2] * A));
+  for (int s = 0; s < nsub; ++s) {
+    if (s > 0) {  // prefix sums of the substeps' thrust sums: the double integral for x
+#pragma unroll
+      for (int j = 0; j < 3; ++j) xx[j] += fmaf(2.0f, g23[j], g1[j] + g4[j]);
+    }
+    // ---- W1, W2 in float64: W1' = a(t) W2 + U1, W2' = -a(t) W1 + U2 ----
+    const double a0 = a3, am = a3 + da, a1 = am + da;
+    const double k1a = fma(a0, W2, p.U1), k1b = fma(-a0, W1, p.U2);
+    double s1 = fma(h2, k1a, W1), s2 = fma(h2, k1b, W2);
+    const double k2a = fma(am, s2, p.U1), k2b = fma(-am, s1, p.U2);
+    s1 = fma(h2, k2a, W1); s2 = fma(h2, k2b, W2);
+    const double k3a = fma(am, s2, p.U1), k3b = fma(-am, s1, p.U2);
+    s1 = fma(h, k3a, W1); s2 = fma(h, k3b, W2);
+    const double k4a = fma(a1, s2, p.U1), k4b = fma(-a1, s1, p.U2);
+    // ---- stage rates in float32 (half units) for the quaternion ----
+    const float b0 = a3f, bm = a3f + daf, b1 = bm + daf;
+    const float z0 = w3, zm = w3 + dw3, z1 = zm + dw3;
+    float kq[4], acc[4], qt[4];
+    // stage 1
+    QR_QDOT(kq, qs, w1, w2, z0)
+    QR_THRUST(g1, qs)
+    float ka = fmaf(b0, w2, u1), kb = fmaf(-b0, w1, u2);
+    float t1 = fmaf(h2f, ka, w1), t2 = fmaf(h2f, kb, w2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[j] = kq[j]; qt[j] = fmaf(h2f, kq[j], qs[j]); }
+    // stage 2
+    QR_QDOT(kq, qt, t1, t2, zm)
+    QR_THRUST(g23, qt)
+    ka = fmaf(bm, t2, u1); kb = fmaf(-bm, t1, u2);
+    t1 = fmaf(h2f, ka, w1); t2 = fmaf(h2f, kb, w2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[j] = fmaf(2.0f, kq[j], acc[j]); qt[j] = fmaf(h2f, kq[j], qs[j]); }
+    // stage 3
+    QR_QDOT(kq, qt, t1, t2, zm)
+    QR_THRUST(g23, qt)
+    ka = fmaf(bm, t2, u1); kb = fmaf(-bm, t1, u2);
+    t1 = fmaf(hf, ka, w1); t2 = fmaf(hf, kb, w2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[j] = fmaf(2.0f, kq[j], acc[j]); qt[j] = fmaf(hf, kq[j], qs[j]); }
+    // stage 4
+    QR_QDOT(kq, qt, t1, t2, z1)
+    QR_THRUST(g4, qt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float dq = h6f * (acc[j] + kq[j]);
+      q[j] += (double)dq;   // the float64 state takes the increment exactly
+      qs[j] += dq;          // float32 track for the next substep's stages (re-synchronised every env-step)
+    }
+    W1 = fma(h6, fma(2.0, k2a + k3a, k1a + k4a), W1);
+    W2 = fma(h6, fma(2.0, k2b + k3b, k1b + k4b), W2);
+    a3 = a1; a3f = b1; w3 = z1;
+    w1 = 0.5f * (float)W1; w2 = 0.5f * (float)W2;
+  }
+#undef QR_THRUST
+#undef QR_QDOT
+  // v' = g e3 - c R e3 integrated over all substeps: sum_n h/6 (k1 + 2 k2 + 2 k3 + k4)_n, and x' = v:
+  //   v_end = v0 + dt (0, 0, g - c) + (h c / 3) s (G1 + 2 G23 + G4),        s = (-1, -1, +1)
+  //   x_end = x0 + dt v0 + dt^2/2 (0, 0, g - c) + (h^2 c / 3) s (XX + G1 + G23)
+  const float cf = (float)p.c, dtf = hf * (float)nsub, gc = (float)p.g - cf;
+  const float hc3 = hf * cf * (1.0f / 3.0f), hhc3 = hf * hc3;
+  float G[3], X2[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { G[j] = fmaf(2.0f, g23[j], g1[j] + g4[j]); X2[j] = xx[j] + (g1[j] + g23[j]); }
+  x[0] = fmaf(-hhc3, X2[0], fmaf(dtf, v[0], x[0]));
+  x[1] = fmaf(-hhc3, X2[1], fmaf(dtf, v[1], x[1]));
+  x[2] = fmaf(hhc3, X2[2], fmaf(0.5f * dtf * dtf, gc, fmaf(dtf, v[2], x[2])));
+  v[0] = fmaf(-hc3, G[0], v[0]);
+  v[1] = fmaf(-hc3, G[1], v[1]);
+  v[2] = fmaf(hc3, G[2], fmaf(dtf, gc, v[2]));
+  W[0] = W1; W[1] = W2;
+  W[2] = fma(p.U3, h * (double)nsub, W[2]);
 }
 
 // ------------------------------------------------------------------------------------
@@ -176,29 +323,29 @@ template <> struct KindTraits<QR_KIND_COUPLED>   { static constexpr int A = 4, D
 template <> struct KindTraits<QR_KIND_DECOUPLED> { static constexpr int A = 5, D0 = 15, D1 = 3, NAG = 2; };
 
 // action_wrapper of the three kinds (quad.py:225-242, coupled:44-53, decoupled:49-59 + 68-73)
-template <int KIND, typename T>
-__device__ __forceinline__ void action_map(const float* a, const Work<T>& w, Dyn<T>& p) {
-  const Phys<T> ph(w);
+template <int KIND, typename T, typename X>
+__device__ __forceinline__ void action_map(const float* a, const Work<T, X>& w, const Coeffs& c, Dyn<T>& p) {
+  const Phys<T> ph(w, c);
   T f, M1, M2, M3;
   if constexpr (KIND == QR_KIND_QUAD) {
     T t[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) t[j] = clampT(ph.scale_act * T(a[j]) + ph.avrg_act, T(kMinForce), ph.max_force);
+    for (int j = 0; j < 4; ++j) t[j] = clampT(ph.scale_act * T(a[j]) + ph.avrg_act, ph.min_force, ph.max_force);
     f = ((t[0] + t[1]) + t[2]) + t[3];
     M1 = ph.d * (t[3] - t[1]);
     M2 = ph.d * (t[0] - t[2]);
     M3 = ph.ctf * ((t[1] - t[0]) + (t[3] - t[2]));
   } else {
-    f = clampT(T(4) * (ph.scale_act * T(a[0]) + ph.avrg_act), T(4) * T(kMinForce), T(4) * ph.max_force);
+    f = clampT(T(4) * (ph.scale_act * T(a[0]) + ph.avrg_act), T(4) * ph.min_force, T(4) * ph.max_force);
     if constexpr (KIND == QR_KIND_COUPLED) {
       M1 = T(a[1]); M2 = T(a[2]); M3 = T(a[3]);
     } else {  // M1 = b1.tau + J3 W3 W2, M2 = b2.tau - J3 W3 W1 from (R, W) at step start
       const T t1 = T(a[1]), t2 = T(a[2]), t3 = T(a[3]);
-      const T qw = w.y[3], qx = w.y[4], qy = w.y[5], qz = w.y[6];  // b1, b2 = first two columns of R(q)
+      const T qw = w.q[0], qx = w.q[1], qy = w.q[2], qz = w.q[3];  // b1, b2 = first two columns of R(q)
       const T b1t = (T(1) - T(2) * (qy * qy + qz * qz)) * t1 + T(2) * (qx * qy + qw * qz) * t2 + T(2) * (qx * qz - qw * qy) * t3;
       const T b2t = T(2) * (qx * qy - qw * qz) * t1 + (T(1) - T(2) * (qx * qx + qz * qz)) * t2 + T(2) * (qy * qz + qw * qx) * t3;
-      M1 = b1t + ph.J3 * w.y[9] * w.y[8];
-      M2 = b2t - ph.J3 * w.y[9] * w.y[7];
+      M1 = b1t + ph.J3 * w.W[2] * w.W[1];
+      M2 = b2t - ph.J3 * w.W[2] * w.W[0];
       M3 = T(a[4]);
     }
   }
@@ -206,20 +353,23 @@ __device__ __forceinline__ void action_map(const float* a, const Work<T>& w, Dyn
   p.c = f * recip(ph.m);
   p.A1 = (ph.J1 - ph.J3) * iJ1;
   p.U1 = M1 * iJ1; p.U2 = M2 * iJ1; p.U3 = M3 * iJ3;
+  p.g = T(c.g);
 }
 
 // get_norm_error_state (quad.py:421-466): fills the float32 observation rows and advances
-// the trapezoid integrators (quad_utils.py:38-63).
-template <int KIND, typename T>
-__device__ __forceinline__ void error_obs(Work<T>& w, const T (&R)[9], const Coeffs& c, float (&o0)[KindTraits<KIND>::D0],
+// the trapezoid integrators (quad_utils.py:38-63).  The normalised errors are formed in T
+// (float64 in the default layout) and rounded once, like the reference's `.astype(float32)`: the
+// wrappers' terminations compare these float32 numbers with 1.
+template <int KIND, typename T, typename X>
+__device__ __forceinline__ void error_obs(Work<T, X>& w, const T (&R)[9], const Coeffs& c, float (&o0)[KindTraits<KIND>::D0],
                                           float (&o1)[KindTraits<KIND>::D1 ? KindTraits<KIND>::D1 : 1]) {
-  const T xl = T(c.x_lim), ixl = T(c.inv_x_lim), ivl = T(c.inv_v_lim), iWl = T(c.inv_W_lim);
+  const T ixl = T(c.inv_x_lim), ivl = T(c.inv_v_lim), iWl = T(c.inv_W_lim);
   T ex[3], ev[3], eW[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {  // x/x_lim - xd/x_lim etc. (quad.py:423-434)
-    ex[j] = w.x[j] * ixl - T(w.goal[j]) * ixl;
-    ev[j] = w.y[j] * ivl - T(w.goal[3 + j]) * ivl;
-    eW[j] = w.y[7 + j] * iWl - T(w.goal[9 + j]) * iWl;
+    ex[j] = T(w.x[j]) * ixl - T(w.goal[j]) * ixl;
+    ev[j] = T(w.v[j]) * ivl - T(w.goal[3 + j]) * ivl;
+    eW[j] = w.W[j] * iWl - T(w.goal[9 + j]) * iWl;
   }
   const T* b1 = &R[0]; const T* b2 = &R[3]; const T* b3 = &R[6];
   const T b1d[3] = {T(w.goal[6]), T(w.goal[7]), T(w.goal[8])};
@@ -233,29 +383,31 @@ __device__ __forceinline__ void error_obs(Work<T>& w, const T (&R)[9], const Coe
   const float eb1n = eb1 * (float)(1.0 / kPi);
   // integrators: I += (g_prev + g) dt/2 ; g uses I before the update.  They are float32 words
   // (stored and held), advanced in float32.
-  const float hdt = (float)(c.dt * 0.5);
+  const float hdt = c.hdt;
   float eIxn[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    const float g = fmaf(-(float)c.alpha, w.integ[j], (float)(ex[j] * xl));
+    const float exf = (float)ex[j];
+    o0[j] = exf;
+    const float g = fmaf(-c.alpha, w.integ[j], exf * c.x_lim_f);
     w.integ[j] = fmaf(w.integ[3 + j] + g, hdt, w.integ[j]);
     w.integ[3 + j] = g;
-    eIxn[j] = clampT(w.integ[j] * (float)c.inv_eIx_lim, -1.0f, 1.0f);
+    eIxn[j] = clampT(w.integ[j] * c.inv_eIx_lim, -1.0f, 1.0f);
   }
-  const float gb = fmaf(-(float)c.beta, w.integ[6], eb1);
+  const float gb = fmaf(-c.beta, w.integ[6], eb1);
   w.integ[6] = fmaf(w.integ[7] + gb, hdt, w.integ[6]);
   w.integ[7] = gb;
-  const float eIb1n = clampT(w.integ[6] * (float)c.inv_eIb1_lim, -1.0f, 1.0f);
+  const float eIb1n = clampT(w.integ[6] * c.inv_eIb1_lim, -1.0f, 1.0f);
   if constexpr (KIND == QR_KIND_COUPLED) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { o0[j] = (float)ex[j]; o0[3 + j] = eIxn[j]; o0[6 + j] = (float)ev[j]; o0[20 + j] = (float)eW[j]; }
+    for (int j = 0; j < 3; ++j) { o0[3 + j] = eIxn[j]; o0[6 + j] = (float)ev[j]; o0[20 + j] = (float)eW[j]; }
 #pragma unroll
     for (int j = 0; j < 9; ++j) o0[9 + j] = (float)R[j];
     o0[18] = eb1n; o0[19] = eIb1n;
   } else {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      o0[j] = (float)ex[j]; o0[3 + j] = eIxn[j]; o0[6 + j] = (float)ev[j]; o0[9 + j] = (float)b3[j];
+      o0[3 + j] = eIxn[j]; o0[6 + j] = (float)ev[j]; o0[9 + j] = (float)b3[j];
       o0[12 + j] = (float)(eW[0] * b1[j] + eW[1] * b2[j]);
     }
     o1[0] = eb1n; o1[1] = eIb1n; o1[2] = (float)eW[2];

@@ -45,51 +45,6 @@ __device__ __forceinline__ void draw20(Draws& d, uint64_t seed, uint64_t gid, ui
   }
 }
 
-// Wave-cooperative form for the in-step auto-reset.  Only ~1 % of the envs reset in a given
-// step, but a wave runs the reset path if ANY of its 64 lanes needs it and the kernel ends with
-// its slowest wave, so what counts is the instruction count of the path — and Philox is the
-// bulk of it (v_mul_hi/lo_u32 are quarter-rate).  Instead of each resetting lane grinding
-// through 5 Philox blocks with the rest of the wave idle, ONE Philox pass serves up to 12
-// resetting envs: lane 5k+b computes block b of the k-th resetting env, then each owner pulls
-// its 20 words with ds_bpermute.  Same draws as draw20.
-__device__ __forceinline__ void coop_draw20(Draws& d, bool need, uint64_t seed, uint64_t gid, uint32_t episode) {
-  const int lane = (int)__lane_id();
-  const int glo = (int)(uint32_t)gid, ghi = (int)(uint32_t)(gid >> 32), ep = (int)episode;
-#pragma unroll
-  for (int j = 0; j < 20; ++j) d.r[j] = 0u;
-  unsigned long long m = __ballot(need);
-  const int my_rank = __popcll(m & ((1ull << lane) - 1ull));  // rank among the resetting lanes
-  const int k = lane / 5, b = lane - 5 * k;                   // slot / block of this lane (k = 12: idle)
-  int base = 0;
-  while (m) {  // wave-uniform; one pass unless > 12 lanes of this wave reset
-    int src = lane, cnt = 0;
-    for (int s = 0; s < 12 && m; ++s) {  // lane index of the s-th resetting env -> lanes of slot s
-      const int l = __builtin_ctzll(m);
-      m &= m - 1;
-      if (k == s) src = l;
-      ++cnt;
-    }
-    uint32_t ctr[4] = {(uint32_t)__shfl(glo, src), (uint32_t)__shfl(ghi, src), (uint32_t)__shfl(ep, src), (uint32_t)b};
-    philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
-    const int r = my_rank - base;
-    const bool mine = need && r >= 0 && r < cnt;
-    const int from4 = (mine ? 5 * r : 0) << 2;  // ds_bpermute takes a byte address (lane * 4)
-    // All 20 cross-lane reads are issued back to back and waited for once: written as
-    // "read, select, read, select, ..." hipcc puts an s_waitcnt lgkmcnt(0) behind every
-    // ds_bpermute and the ~100-cycle LDS-crossbar latency is paid 20 times in series.
-    int got[20];
-#pragma unroll
-    for (int bb = 0; bb < 5; ++bb) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) got[4 * bb + j] = __builtin_amdgcn_ds_bpermute(from4 + 4 * bb, (int)ctr[j]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int w = 0; w < 20; ++w) d.r[w] = mine ? (uint32_t)got[w] : d.r[w];
-    base += cnt;
-  }
-}
-
 // sin and cos of a float angle of moderate size (|x| < ~1e3): Cody-Waite reduction by pi/2 and
 // the cephes minimax polynomials on [-pi/4, pi/4]; ~1e-7 absolute.  Branch-free and small: the
 // OCML sincosf drags its Payne-Hanek slow path (and its registers) into every kernel using it.
@@ -145,22 +100,19 @@ __device__ __forceinline__ void unit_sincos(float ang, double& s, double& c) {
 // QuadEnv.reset + sample_init_error + set_random_parameters (quad.py:171-222, 338-404).
 // Draw order: 0..5 m,d,J1,J3,c_tf,c_tw; 6 yaw; 7 zero-error branch; 8..10 x; 11..13 v;
 // 14..16 W; 17,18 roll,pitch.  R = Rz(yaw) Ry(pitch) Rx(roll) (scipy 'xyz' extrinsic,
-// quad.py:199)  <=>  q = qz(yaw) qy(pitch) qx(roll).
-template <typename T>
-__device__ void sample_reset(Work<T>& w, const Draws& d, bool randomise, bool eval, const Coeffs& c) {
+// quad.py:199)  <=>  q = qz(yaw) qy(pitch) qx(roll).  Every sampled value is a float32 number
+// (W is returned as such); q has unit norm to float64 round-off.
+template <typename T, typename X>
+__device__ __forceinline__ void sample_start(const Draws& d, bool randomise, bool eval, const Coeffs& c, X (&x)[3], X (&v)[3],
+                                             T (&q)[4], float (&Wf)[3], float (&prm)[6]) {
   if (randomise) {  // float32 values: that is how the params buffer stores them
-    const float p = (float)c.udm;
-    w.prm[0] = (float)kMnom * fmaf(p, d.sym(0), 1.0f);
-    w.prm[1] = (float)kDnom * fmaf(p, d.sym(1), 1.0f);
-    w.prm[2] = (float)kJ1nom * fmaf(p, d.sym(2), 1.0f);
-    w.prm[3] = (float)kJ3nom * fmaf(p, d.sym(3), 1.0f);
-    w.prm[4] = (float)kCtfNom * fmaf(p, d.sym(4), 1.0f);
-    w.prm[5] = (float)kCtwNom * fmaf(0.5f * p, d.sym(5), 1.0f);
-    w.nominal = false;
+    const float p = c.udm;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) prm[j] = c.nom_f[j] * fmaf(p, d.sym(j), 1.0f);
+    prm[5] = c.nom_f[5] * fmaf(0.5f * p, d.sym(5), 1.0f);
   } else {
-    w.prm[0] = (float)kMnom; w.prm[1] = (float)kDnom; w.prm[2] = (float)kJ1nom;
-    w.prm[3] = (float)kJ3nom; w.prm[4] = (float)kCtfNom; w.prm[5] = (float)kCtwNom;
-    w.nominal = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) prm[j] = c.nom_f[j];
   }
   const float yaw = (float)kPi * d.sym(6);
   float ix, iv, iR, iW;
@@ -169,22 +121,115 @@ __device__ void sample_reset(Work<T>& w, const Draws& d, bool randomise, bool ev
   } else if (d.u01(7) < 0.2f) {  // quad.py:342-346
     ix = 0.0f; iv = 0.0f; iR = 0.0f; iW = 0.0f;
   } else {  // quad.py:348-351
-    ix = 0.6f; iv = (float)(c.v_lim * 0.5); iR = (float)(50.0 * kPi / 180.0); iW = (float)(c.W_lim * 0.5);
+    ix = 0.6f; iv = c.reset_v; iR = (float)(50.0 * kPi / 180.0); iW = c.reset_W;
   }
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    w.x[j] = T(ix * d.sym(8 + j));
-    w.y[j] = T(iv * d.sym(11 + j));
-    w.y[7 + j] = T(iW * d.sym(14 + j));
+    x[j] = X(ix * d.sym(8 + j));
+    v[j] = X(iv * d.sym(11 + j));
+    Wf[j] = iW * d.sym(14 + j);
   }
   double sr, cr, sp, cp, sy, cy;
   unit_sincos(0.5f * iR * d.sym(17), sr, cr);
   unit_sincos(0.5f * iR * d.sym(18), sp, cp);
   unit_sincos(0.5f * yaw, sy, cy);
-  w.y[3] = T(cr * cp * cy + sr * sp * sy);
-  w.y[4] = T(sr * cp * cy - cr * sp * sy);
-  w.y[5] = T(cr * sp * cy + sr * cp * sy);
-  w.y[6] = T(cr * cp * sy - sr * sp * cy);
+  q[0] = T(cr * cp * cy + sr * sp * sy);
+  q[1] = T(sr * cp * cy - cr * sp * sy);
+  q[2] = T(cr * sp * cy + sr * cp * sy);
+  q[3] = T(cr * cp * sy - sr * sp * cy);
+}
+
+template <typename T, typename X>
+__device__ __forceinline__ void sample_reset(Work<T, X>& w, const Draws& d, bool randomise, bool eval, const Coeffs& c) {
+  float Wf[3];
+  sample_start<T, X>(d, randomise, eval, c, w.x, w.v, w.q, Wf, w.prm);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) w.W[j] = T(Wf[j]);
+  w.nominal = !randomise;
+}
+
+// ------------------------------------------------------------------------------------
+// In-launch auto-reset: a POOL of freshly sampled episode starts per wavefront.
+//
+// Only ~1 % of the envs reset in a given step, but ~50 % of the waves contain one and a launch
+// ends with its slowest wave, so the reset's instructions sit on the critical path of the whole
+// launch.  Nothing about WHICH lane resets is known before the step has been integrated — but
+// what a resetting lane needs (Philox draws + the sampling arithmetic) does not depend on the
+// lane at all if the stream is keyed by the wave instead of by the env:
+//     draws(slot s) = Philox4x32-10(key = seed; ctr = (global id of the wave's first env [64 bit],
+//                                   reset counter of this wave's tile, 0x40000000 | s << 8 | block))
+// One cooperative Philox pass (lane 5k+b computes block b of slot k; 12 slots) plus the sampling
+// of the 12 starts (lane 5k) is therefore issued right after the wave's state loads and runs
+// while they are in flight, when the SIMD has nothing else to do.  A lane that resets takes the
+// slot given by its rank among the wave's resetting lanes (ds_bpermute from lane 5 * rank);
+// ranks >= 12 (e.g. a time limit ending all 64 episodes at once) draw further pools on demand
+// (slots 12 p + k).  The tile's counter advances by one per env-step, so no (tile, counter, slot)
+// is ever used twice — also under hipGraph replay, because the counter lives in device memory.
+// Results are independent of how the batch is sharded as long as shards start at multiples of 64.
+// ------------------------------------------------------------------------------------
+template <typename T, typename X>
+struct ResetPool {  // meaningful in lanes 5k, k = 0..11
+  X x[3], v[3];
+  T q[4];
+  float W[3];
+  float prm[6];
+  uint32_t r19;  // the word the goal generator's episode-start draws are taken from
+};
+
+template <typename T, typename X>
+__device__ __forceinline__ void make_pool(ResetPool<T, X>& p, uint64_t seed, uint64_t gfirst, uint32_t count, int pass, bool randomise,
+                                          bool eval, const Coeffs& c) {
+  const int lane = (int)__lane_id();
+  const int k = lane / 5, b = lane - 5 * k;  // slot / block of this lane (k = 12: lanes 60..63 idle)
+  uint32_t ctr[4] = {(uint32_t)gfirst, (uint32_t)(gfirst >> 32), count, 0x40000000u | ((uint32_t)(12 * pass + k) << 8) | (uint32_t)b};
+  philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+  // lane 5k gathers blocks 1..4 of its slot from lanes 5k+1 .. 5k+4 (all reads issued, one wait)
+  Draws d;
+  int got[16];
+#pragma unroll
+  for (int bb = 1; bb < 5; ++bb) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) got[4 * (bb - 1) + j] = __builtin_amdgcn_ds_bpermute((lane + bb) << 2, (int)ctr[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) d.r[j] = ctr[j];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) d.r[4 + j] = (uint32_t)got[j];
+  sample_start<T, X>(d, randomise, eval, c, p.x, p.v, p.q, p.W, p.prm);
+  p.r19 = d.r[19];
+}
+
+__device__ __forceinline__ float bperm(int addr4, float v) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr4, __builtin_bit_cast(int, v))); }
+__device__ __forceinline__ double bperm(int addr4, double v) {
+  const uint64_t u = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr4, (int)(uint32_t)u);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr4, (int)(uint32_t)(u >> 32));
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
+// Lanes with take == true copy slot `slot` of the pool into their working set.  Executed by the whole wave.
+template <typename T, typename X, bool TRAJ>
+__device__ __forceinline__ void take_from_pool(const ResetPool<T, X>& p, bool take, int slot, Work<T, X>& w, uint32_t& r19) {
+  const int addr = (take ? 5 * slot : 0) << 2;
+  X x[3], v[3]; T q[4]; float W[3], prm[6];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { x[j] = bperm(addr, p.x[j]); v[j] = bperm(addr, p.v[j]); W[j] = bperm(addr, p.W[j]); }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) q[j] = bperm(addr, p.q[j]);
+#pragma unroll
+  for (int j = 0; j < 6; ++j) prm[j] = bperm(addr, p.prm[j]);
+  uint32_t r = 0;
+  if constexpr (TRAJ) r = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)p.r19);
+  __builtin_amdgcn_sched_barrier(0);  // all cross-lane reads are in flight before the first select waits for one
+  if (take) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { w.x[j] = x[j]; w.v[j] = v[j]; w.W[j] = T(W[j]); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w.q[j] = q[j];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) w.prm[j] = prm[j];
+    if constexpr (TRAJ) r19 = r;
+  }
 }
 
 }  // namespace qr

@@ -27,9 +27,9 @@ struct Traj {
 // mark_traj_start(state) (:176-204) + the episode-start branch of calculate_desired:
 //   mode 0 (:141-148): b1d = Rz(theta) b1_proj, theta ~ U(+-25 deg)
 //   mode 1 (:253-266): x_init = x, t_traj ~ U(2,5), smooth = -ln(0.001)/t_traj, w_b1d ~ U(+-0.15 pi)
-template <typename T>
-__device__ __forceinline__ void traj_start(const Work<T>& w, Traj& tr, int goal_mode, float theta_b1d, float t_traj, float w_b1d) {
-  const T qw = w.y[3], qx = w.y[4], qy = w.y[5], qz = w.y[6];
+template <typename T, typename X>
+__device__ __forceinline__ void traj_start(const Work<T, X>& w, Traj& tr, int goal_mode, float theta_b1d, float t_traj, float w_b1d) {
+  const T qw = w.q[0], qx = w.q[1], qy = w.q[2], qz = w.q[3];
   const float b1x = (float)(T(1) - T(2) * (qy * qy + qz * qz)), b1y = (float)(T(2) * (qx * qy + qw * qz));
   const float theta_init = atan2_fast(b1y, b1x);  // update_initial_state (:199-204)
   tr.calls = 0.0f;
@@ -56,8 +56,8 @@ __device__ __forceinline__ void traj_draws(uint32_t r19, float& theta_b1d, float
 
 // get_desired(state, mode) (:113-173) for the state in w: advances the call counter, fills
 // w.goal = (xd, vd, b1d, Wd) and returns b1d_dot.
-template <typename T>
-__device__ __forceinline__ void traj_goal(Work<T>& w, Traj& tr, int goal_mode, const Coeffs& c, float (&b1d_dot)[3]) {
+template <typename T, typename X>
+__device__ __forceinline__ void traj_goal(Work<T, X>& w, Traj& tr, int goal_mode, const Coeffs& c, float (&b1d_dot)[3]) {
   tr.calls += 1.0f;  // update_current_time (:224-229): t = t + dt on every call
   float b1d[3];
   if (goal_mode == QR_GOAL_MODE0) {  // set_desired_states_to_zero + the b1d drawn at episode start
@@ -66,7 +66,7 @@ __device__ __forceinline__ void traj_goal(Work<T>& w, Traj& tr, int goal_mode, c
     b1d[0] = tr.p2; b1d[1] = tr.p3; b1d[2] = 0.0f;
     b1d_dot[0] = b1d_dot[1] = b1d_dot[2] = 0.0f;
   } else if (goal_mode == QR_GOAL_MODE6) {  // eight_shaped_curve (:418-505)
-    const float t = fminf(tr.calls * (float)c.dt, c.e8_tmax);
+    const float t = fminf(tr.calls * (2.0f * c.hdt), c.e8_tmax);
     const float ek = expf(-c.e8_k * t);
     const float e = 1.0f - ek, de = c.e8_k * ek;  // exp_term, d/dt exp_term
     float s1, c1, s2, c2;
@@ -85,7 +85,7 @@ __device__ __forceinline__ void traj_goal(Work<T>& w, Traj& tr, int goal_mode, c
     b1d[0] = cs; b1d[1] = sn; b1d[2] = 0.0f;
     b1d_dot[0] = -sn * dterm; b1d_dot[1] = cs * dterm; b1d_dot[2] = 0.0f;
   } else {  // hovering (:268-277), x_goal = 0
-    const float t = tr.calls * (float)c.dt;
+    const float t = tr.calls * (2.0f * c.hdt);
     const float wb = tr.p2, sm = tr.p3;
     const float e = expf(-sm * t);
 const float xi[3] = {tr.x0, tr.x1, tr.x2};
@@ -100,8 +100,8 @@ const float xi[3] = {tr.x0, tr.x1, tr.x2};
   for (int j = 0; j < 3; ++j) w.goal[6 + j] = b1d[j];
   // Wd = (0, 0, b3 . (b1c x b1c_dot)) with b3' = R hat(W) e3 = W2 b1 - W1 b2 (:165-172)
   T R[9];
-  quat_to_R(&w.y[3], R);
-  const T W1 = w.y[7], W2 = w.y[8];
+  quat_to_R(w.q, R);
+  const T W1 = w.W[0], W2 = w.W[1];
   T b3d[3], b1c[3], b1cd[3];
   const T d0 = T(b1d[0]), d1 = T(b1d[1]), d2 = T(b1d[2]);
   const T dd0 = T(b1d_dot[0]), dd1 = T(b1d_dot[1]), dd2 = T(b1d_dot[2]);
@@ -165,40 +165,44 @@ struct SoA {
   }
 };
 
-template <typename XV, typename QW, typename T>
-__device__ __forceinline__ void load_state(const Args& a, int64_t first64, unsigned lane, Work<T>& w) {
+template <typename XV, typename QW>
+__device__ __forceinline__ void load_state(const Args& a, int64_t first64, unsigned lane, Work<QW, XV>& w) {
   const SoA<XV> pv(a.pos_vel, 6, a.ld);
   const SoA<QW> ar(a.att_rate, 7, a.ld);
   const unsigned first = (unsigned)first64;
 #pragma unroll
-  for (int f = 0; f < 3; ++f) { w.x[f] = T(pv.load(f, first, lane)); w.y[f] = T(pv.load(3 + f, first, lane)); }
+  for (int f = 0; f < 4; ++f) w.q[f] = ar.load(f, first, lane);
 #pragma unroll
-  for (int f = 0; f < 7; ++f) w.y[3 + f] = T(ar.load(f, first, lane));
+  for (int f = 0; f < 3; ++f) w.W[f] = ar.load(4 + f, first, lane);
+#pragma unroll
+  for (int f = 0; f < 3; ++f) { w.x[f] = pv.load(f, first, lane); w.v[f] = pv.load(3 + f, first, lane); }
 }
 
-template <typename XV, typename QW, typename T>
-__device__ __forceinline__ void store_state(const Args& a, int64_t first64, unsigned lane, const Work<T>& w) {
+template <typename XV, typename QW>
+__device__ __forceinline__ void store_state(const Args& a, int64_t first64, unsigned lane, const Work<QW, XV>& w) {
   const SoA<XV> pv(a.pos_vel, 6, a.ld);
   const SoA<QW> ar(a.att_rate, 7, a.ld);
   const unsigned first = (unsigned)first64;
 #pragma unroll
-  for (int f = 0; f < 3; ++f) { pv.store(f, first, lane, (XV)w.x[f]); pv.store(3 + f, first, lane, (XV)w.y[f]); }
+  for (int f = 0; f < 4; ++f) ar.store(f, first, lane, w.q[f]);
 #pragma unroll
-  for (int f = 0; f < 7; ++f) ar.store(f, first, lane, (QW)w.y[3 + f]);
+  for (int f = 0; f < 3; ++f) ar.store(4 + f, first, lane, w.W[f]);
+#pragma unroll
+  for (int f = 0; f < 3; ++f) { pv.store(f, first, lane, w.x[f]); pv.store(3 + f, first, lane, w.v[f]); }
 }
 
-template <typename T>
-__device__ __forceinline__ void idle_work(Work<T>& w) {  // lanes past the ragged tail
+template <typename T, typename X>
+__device__ __forceinline__ void idle_work(Work<T, X>& w, const Coeffs& c) {  // lanes past the ragged tail
 #pragma unroll
-  for (int f = 0; f < 3; ++f) w.x[f] = T(0);
+  for (int f = 0; f < 3; ++f) { w.x[f] = X(0); w.v[f] = X(0); w.W[f] = T(0); }
 #pragma unroll
-  for (int f = 0; f < 10; ++f) w.y[f] = T(f == 3 ? 1 : 0);
+  for (int f = 0; f < 4; ++f) w.q[f] = T(f == 0 ? 1 : 0);
 #pragma unroll
   for (int f = 0; f < 12; ++f) w.goal[f] = f == 6 ? 1.0f : 0.0f;
 #pragma unroll
   for (int f = 0; f < 8; ++f) w.integ[f] = 0.0f;
 #pragma unroll
-  for (int f = 0; f < 6; ++f) w.prm[f] = 0.0f;
+  for (int f = 0; f < 6; ++f) w.prm[f] = c.nom_f[f];
   w.nominal = true;
 }
 

@@ -57,6 +57,28 @@
 
 namespace qr {
 
+// byte offset of the Args block in the step kernel's kernarg segment: 5 pointers + 2 x int64 precede it
+constexpr int kArgsOffset = 5 * 8 + 2 * 8;
+static_assert(alignof(Args) == 8, "Args follows the leading scalar arguments without padding");
+
+// QR_STAMPS: diagnostic build (tools/stamp_timeline.py).  Every wave records the 100 MHz real-time clock at
+// seven points of the step; the values go to a buffer of their own that nothing else reads.
+#ifdef QR_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;
+#define QR_STAMP(k, dep)                                                                          \
+  do {                                                                                            \
+    unsigned long long t_;                                                                        \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory");    \
+    if (g_stamps != nullptr && lane == 0) g_stamps[(size_t)blockIdx.x * 8 + (k)] = t_;            \
+  } while (0)
+#else
+#define QR_STAMP(k, dep) do { } while (0)
+#endif
+
+#ifndef QR_SPEC_GRID
+#define QR_SPEC_GRID 4096  // grids up to this many waves sample their reset pool speculatively (under the load latency)
+#endif
+
 // ------------------------------------------------------------------------------------
 // The fused step / rollout kernel
 // ------------------------------------------------------------------------------------
@@ -75,10 +97,24 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   // plain kernel arguments they are preloaded into SGPRs by the dispatcher (gfx950 kernarg
   // preload, -mllvm -amdgpu-kernarg-preload-count), so the state loads are issued without first
   // waiting for a scalar-load round trip to the kernarg segment.
-  Args a = a_in;
+  // Everything else is read from the kernarg segment WHERE IT IS USED: referenced as a by-value
+  // struct, every used field of Args would be loaded in the kernel's entry block (that is how the
+  // AMDGPU backend lowers kernel arguments) and stay live in SGPRs from there on — far more than the
+  // 102 a wave has, so the round-1 kernel spilled them into VGPR lanes (v_writelane / v_readlane, a
+  // VALU slot each, ~220 on the step's path).  Through the segment pointer they are ordinary
+  // scalar loads from constant memory with short live ranges.
+#if defined(__HIP_DEVICE_COMPILE__)
+  const Args& ka = *reinterpret_cast<const Args*>(reinterpret_cast<const char*>(__builtin_amdgcn_kernarg_segment_ptr()) + kArgsOffset);
+  (void)a_in;
+#else
+  const Args& ka = a_in;  // (host pass of the single-source compile: never executed)
+#endif
+  Args a;  // the fields the hot path touches, assembled from the preloaded scalars
   a.pos_vel = pos_vel; a.att_rate = att_rate; a.action = action; a.params = params; a.integ = integ;
   a.n = n_envs; a.ld = ld_envs;
-  using T = QW;  // arithmetic type
+  a.goal = ka.goal; a.traj = ka.traj; a.steps = ka.steps; a.reset_count = ka.reset_count;
+  using T = QW;  // q, W are held and accumulated in their storage type
+  using X = XV;  // and so are x, v
   using KT = KindTraits<KIND>;
   constexpr int A = KT::A, D0 = KT::D0, D1 = KT::D1 ? KT::D1 : 1, NAG = KT::NAG;
   __shared__ __attribute__((aligned(16))) float smem[B * (D0 > A ? D0 : A)];
@@ -90,16 +126,17 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   const int64_t N = a.n, L = a.ld;
   const int rows = (int)((N - first) < B ? (N - first) : B);
   const bool active = tid < rows;
-  const Coeffs& c = a.c;
+  const Coeffs& c = ka.c;
 #if QR_ABLATE == 1  // measurement build: launch floor only
   return;
 #endif
 
-  Work<T> w;
+  QR_STAMP(0, tid);
+  Work<T, X> w;
   // ---- load the env's working set (SoA, lane-contiguous) ----
-  idle_work(w);
+  idle_work(w, c);
   if (active) {
-    load_state<XV, QW, T>(a, first, lane, w);
+    load_state<XV, QW>(a, first, lane, w);
     if (a.params) {
       const SoA<float> prm(a.params, 6, L);
 #pragma unroll
@@ -118,17 +155,13 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     }
   }
   Traj tr;
-  const int goal_mode = TRAJ ? a.goal_mode : QR_GOAL_EXTERNAL;  // wave-uniform
+  const int goal_mode = TRAJ ? ka.goal_mode : QR_GOAL_EXTERNAL;  // wave-uniform
   if (TRAJ && active) {
     const SoA<float> traj(a.traj, 8, L);
 #pragma unroll
     for (int f = 0; f < 7; ++f) tr.set(f, traj.load(f, ufirst, lane));
   }
   int32_t steps = (a.steps && active) ? (a.steps + first)[lane] : 0;
-  // The episode counter (RNG stream id) is fetched with the rest of the working set: read
-  // lazily inside the reset path it would put a full memory round-trip (~1.5 us) on the
-  // critical path of every wave that has a resetting lane.
-  int32_t episode = ((a.flags & QR_FLAG_AUTO_RESET) && active) ? (a.episode + first)[lane] : 0;
   bool params_dirty = false;
   bool traj_dirty = false;  // this lane started a new episode: its generator state changed
 
@@ -151,6 +184,26 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   if constexpr (!POLICY) {
     if (active) load_action(0, act_next);
   }
+
+  // ---- in-launch reset: this wave's pool of episode starts (qr_rng.h), sampled while the loads are in flight ----
+  const bool auto_reset = (ka.flags & QR_FLAG_AUTO_RESET) != 0;
+  const bool eval_reset = (ka.flags & QR_FLAG_EVAL_RESET) != 0;
+  const bool randomise = !eval_reset && !(ka.flags & QR_FLAG_NO_UDM) && a.params != nullptr;
+  const uint64_t gfirst = (uint64_t)(ka.env_offset + first);
+  uint32_t rcount = 0;
+  ResetPool<T, X> pool;
+  bool have_pool = false;
+  if (auto_reset) {
+    rcount = (uint32_t)a.reset_count[blockIdx.x];  // wave-uniform: a scalar load
+#if QR_ABLATE != 3
+    if (gridDim.x <= QR_SPEC_GRID) {
+      make_pool<T, X>(pool, ka.seed, gfirst, rcount, 0, randomise, eval_reset, c);
+      have_pool = true;
+    }
+#endif
+  }
+
+  QR_STAMP(1, have_pool ? (float)pool.q[0] + pool.x[0] + pool.prm[5] : 0.0f);
   // POLICY: the observation the next action is computed from (rows -> lane registers once, then
   // carried from step to step)
   float po0[D0], po1[D1];
@@ -161,14 +214,14 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   using Actor1 = ActorLds<3, 4, 1>;
   __shared__ __attribute__((aligned(16))) float wsm[POLICY ? Actor1::SIZE : 4];
   if constexpr (POLICY) {
-    load_rows<B, D0>(a.obs0_in + first * D0, po0, smem, tid, rows);
-    if constexpr (KT::D1 > 0) load_rows<B, D1>(a.obs1_in + first * D1, po1, smem, tid, rows);
-    actor0.load(a.actor[0], tid);
-    if constexpr (KT::D1 > 0) Actor1::fill(wsm, a.actor[1], tid);
+    load_rows<B, D0>(ka.obs0_in + first * D0, po0, smem, tid, rows);
+    if constexpr (KT::D1 > 0) load_rows<B, D1>(ka.obs1_in + first * D1, po1, smem, tid, rows);
+    actor0.load(ka.actor[0], tid);
+    if constexpr (KT::D1 > 0) Actor1::fill(wsm, ka.actor[1], tid);
     __syncthreads();
   }
 
-  for (int t = 0; t < a.n_steps; ++t) {
+  for (int t = 0; t < ka.n_steps; ++t) {
     float act[A];
     if constexpr (POLICY) {
       float pre[A], ls[A], eps[A], logp[A];
@@ -184,64 +237,65 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       }
       if constexpr (KIND == QR_KIND_DECOUPLED) {
         float p1[1], l1[1];
-        Actor1::heads(wsm, GENERAL && a.actor[1].ls_w != nullptr, po1, p1, l1);
+        Actor1::heads(wsm, GENERAL && ka.actor[1].ls_w != nullptr, po1, p1, l1);
         pre[A - 1] = p1[0]; ls[A - 1] = l1[0];
       }
 #pragma unroll
       for (int j = 0; j < A; ++j) eps[j] = 0.0f;
-      if (!a.deterministic) {
-        if (a.noise != nullptr) {  // injected draws [T][N][A]
+      if (!ka.deterministic) {
+        if (ka.noise != nullptr) {  // injected draws [T][N][A]
           if (active) {
-            const float* nbase = a.noise + ((int64_t)t * N + first) * A;
+            const float* nbase = ka.noise + ((int64_t)t * N + first) * A;
 #pragma unroll
             for (int j = 0; j < A; ++j) eps[j] = nbase[lane * A + j];
           }
         } else {
           float z[4];
-          normal4(z, a.noise_seed, (uint64_t)(a.env_offset + i), a.step_base + (uint64_t)t, 0u);
+          normal4(z, ka.noise_seed, (uint64_t)(ka.env_offset + i), ka.step_base + (uint64_t)t, 0u);
 #pragma unroll
           for (int j = 0; j < 4; ++j) eps[j] = z[j];
           if constexpr (A > 4) {
-            normal4(z, a.noise_seed, (uint64_t)(a.env_offset + i), a.step_base + (uint64_t)t, 1u);
+            normal4(z, ka.noise_seed, (uint64_t)(ka.env_offset + i), ka.step_base + (uint64_t)t, 1u);
             eps[A - 1] = z[0];
           }
         }
       }
       __syncthreads();  // the tile is reused by the row stores below
-      actor_sample<4, GENERAL>(a.actor[0].squash, actor0.ls_head, &pre[0], &ls[0], &eps[0], a.deterministic != 0, a.max_action, &act[0], &logp[0]);
+      actor_sample<4, GENERAL>(ka.actor[0].squash, actor0.ls_head, &pre[0], &ls[0], &eps[0], ka.deterministic != 0, ka.max_action, &act[0], &logp[0]);
       if constexpr (A > 4)
-        actor_sample<1, GENERAL>(a.actor[1].squash, a.actor[1].ls_w != nullptr, &pre[A - 1], &ls[A - 1], &eps[A - 1], a.deterministic != 0,
-                        a.max_action, &act[A - 1], &logp[A - 1]);
+        actor_sample<1, GENERAL>(ka.actor[1].squash, ka.actor[1].ls_w != nullptr, &pre[A - 1], &ls[A - 1], &eps[A - 1], ka.deterministic != 0,
+                        ka.max_action, &act[A - 1], &logp[A - 1]);
       if (active) {
         const int64_t arow = ((int64_t)t * N + first) * A;
         if constexpr (A == 4) {
-          reinterpret_cast<float4*>(a.act_out + arow)[lane] = make_float4(act[0], act[1], act[2], act[3]);
-          if (a.logp_out) reinterpret_cast<float4*>(a.logp_out + arow)[lane] = make_float4(logp[0], logp[1], logp[2], logp[3]);
+          reinterpret_cast<float4*>(ka.act_out + arow)[lane] = make_float4(act[0], act[1], act[2], act[3]);
+          if (ka.logp_out) reinterpret_cast<float4*>(ka.logp_out + arow)[lane] = make_float4(logp[0], logp[1], logp[2], logp[3]);
         } else {
 #pragma unroll
           for (int j = 0; j < A; ++j) {
-            (a.act_out + arow)[lane * A + j] = act[j];
-            if (a.logp_out) (a.logp_out + arow)[lane * A + j] = logp[j];
+            (ka.act_out + arow)[lane * A + j] = act[j];
+            if (ka.logp_out) (ka.logp_out + arow)[lane * A + j] = logp[j];
           }
         }
       }
     } else {
 #pragma unroll
       for (int j = 0; j < A; ++j) act[j] = act_next[j];
-      if (active && t + 1 < a.n_steps) load_action(t + 1, act_next);
+      if (active && t + 1 < ka.n_steps) load_action(t + 1, act_next);
     }
 
 #if QR_ABLATE == 2  // measurement build: memory traffic only (no integration)
-    w.x[0] += T(act[0]);
+    w.x[0] += X(act[0]);
 #else
     // ---- goal for this step from the pre-step state (main.py:145-147) ----
     if constexpr (TRAJ) {
       float b1d_dot[3];
       traj_goal(w, tr, goal_mode, c, b1d_dot);
     }
+    QR_STAMP(2, (float)w.q[0] + (float)w.x[0] + act[0] + w.prm[0] + (float)w.W[2]);
     // ---- action_wrapper ----
     Dyn<T> dyn;
-    action_map<KIND, T>(act, w, dyn);
+    action_map<KIND, T, X>(act, w, c, dyn);
     // ---- observation_wrapper: integrate over dt with zero-order-hold (f, M) ----
     // The reference's DOP853 is adaptive (6 % of its steps subdivide); the fixed-step stand-in
     // is made rate-adaptive: RK4's local error grows like (|W| h)^5, so a wave that contains an
@@ -249,77 +303,78 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     // multiplier is the wave's maximum (found with ballots, so the substep loop stays wave-uniform
     // and in regime — |W| < 2 pi < w_adapt — this costs one ballot): every lane takes at least
     // the count its own rate asks for.
-    int nsub = a.substeps;
+    int nsub = ka.substeps;
     if constexpr (ADAPT) {
-      const T wmax = fmax(fmax(fabs(w.y[7]), fabs(w.y[8])), fabs(w.y[9]));
+      const T wmax = fmax(fmax(fabs(w.W[0]), fabs(w.W[1])), fabs(w.W[2]));
       const T need = wmax * T(c.inv_w_adapt);
       int mul = 1;
       while (mul < 16 && __ballot(need > T(mul))) ++mul;
       nsub *= mul;
     }
     const T h = T(c.dt) * recip(T(nsub));
-    for (int s = 0; s < nsub; ++s) rk4_step(w.x, w.y, h, dyn);
-    renorm_quat(&w.y[3]);
-    // x, v take their storage precision at every env-step boundary, so that a K-step rollout
-    // (state kept in registers) is bit-identical to K single-step launches
-    if constexpr (!std::is_same<XV, T>::value) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) { w.x[j] = T((XV)w.x[j]); w.y[j] = T((XV)w.y[j]); }
-    }
+    integrate(w.x, w.v, w.q, w.W, dyn, nsub, h);
+    renorm_quat(w.q);
+    QR_STAMP(3, (float)w.q[0] + (float)w.x[0] + (float)w.v[2] + (float)w.W[0]);
 #endif
 
     // ---- obs / reward / done ----
     T R[9];
-    quat_to_R(&w.y[3], R);
     float o0[D0];
     float o1[D1];
     float rraw[NAG], rwd[NAG];
     bool dn[NAG];
     if constexpr (KIND == QR_KIND_QUAD) {
-      // reward_wrapper (quad.py:274-298)
-      T eX2 = 0, eV2 = 0, W2 = 0;
+      const T qw = w.q[0], qx = w.q[1], qy = w.q[2], qz = w.q[3];
+      const T R00 = T(1) - T(2) * (qy * qy + qz * qz), R10 = T(2) * (qx * qy + qw * qz);  // b1 = first column of R(q)
+      const T R20 = T(2) * (qx * qz - qw * qy), R21 = T(2) * (qy * qz + qw * qx), R22 = T(1) - T(2) * (qx * qx + qy * qy);
+      // reward_wrapper (quad.py:274-298), formed in float32 (its result is a float32 word)
+      float eX2 = 0.f, eV2 = 0.f, W2 = 0.f;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const T dx = w.x[j] - T(w.goal[j]), dv = w.y[j] - T(w.goal[3 + j]);
-        eX2 += dx * dx; eV2 += dv * dv; W2 += w.y[7 + j] * w.y[7 + j];
+        const float dx = (float)w.x[j] - w.goal[j], dv = (float)w.v[j] - w.goal[3 + j], wj = (float)w.W[j];
+        eX2 = fmaf(dx, dx, eX2); eV2 = fmaf(dv, dv, eV2); W2 = fmaf(wj, wj, W2);
       }
       // eb1 = signed angle from b1d to b1_proj ~ (R00, R10, 0) (quad_utils.py:97-101,157-177).
       // acos(du.cu) with the sign of (du x cu)_z == atan2(|du x cu|, du.cu), which is invariant
       // to the lengths of both vectors, so neither is normalised.
-      const T g6 = T(w.goal[6]), g7 = T(w.goal[7]), g8 = T(w.goal[8]);
-      const T dot = g6 * R[0] + g7 * R[1];
-      const T cz = g6 * R[1] - g7 * R[0];
-      const T hy2 = R[0] * R[0] + R[1] * R[1];
-      const float sabs = sqrtf((float)(g8 * g8 * hy2 + cz * cz));
-      float ang = atan2_fast(sabs, (float)dot);
-      if (cz < T(0)) ang = -ang;
-      const T eb1 = T(ang) * T(1.0 / kPi);
-      const T r = -T(c.Cx) * eX2 - T(c.Cb1) * fabs(eb1) - T(c.Cv) * eV2 - T(c.CW) * W2;
-      rraw[0] = (float)r;
-      rwd[0] = (float)clampT((r - T(c.rmin_mono)) * T(c.inv_nrmin_mono), T(0), T(1));
-      // done_wrapper (quad.py:301-318): roll = atan2(R21,R22), pitch = -asin(R20)
-      // (bitwise | on purpose: straight-line compares, no short-circuit branches)
+      const float r00 = (float)R00, r10 = (float)R10;
+      const float g6 = w.goal[6], g7 = w.goal[7], g8 = w.goal[8];
+      const float dot = g6 * r00 + g7 * r10;
+      const float cz = g6 * r10 - g7 * r00;
+      const float hy2 = r00 * r00 + r10 * r10;
+      const float sabs = sqrtf(g8 * g8 * hy2 + cz * cz);
+      float ang = atan2_fast(sabs, dot);
+      if (cz < 0.0f) ang = -ang;
+      const float eb1 = ang * (float)(1.0 / kPi);
+      const float r = -c.Cx * eX2 - c.Cb1 * fabsf(eb1) - c.Cv * eV2 - c.CW * W2;
+      rraw[0] = r;
+      rwd[0] = interp01(r, c.rmin_mono, c.inv_nrmin_mono);
+      // done_wrapper (quad.py:301-318): roll = atan2(R21,R22), pitch = -asin(R20); |angle| >= 85 deg
+      // without inverse trig.  x, v: float32 numbers compared with the limit rounded UP to float32,
+      // which decides exactly as the float64 comparison does.  (bitwise | on purpose: no branches)
+      X xl, vl;
+      if constexpr (std::is_same<X, float>::value) { xl = c.x_lim_up; vl = c.v_lim_up; } else { xl = X(c.x_lim); vl = X(c.v_lim); }
       bool d = false;
 #pragma unroll
       for (int j = 0; j < 3; ++j)
-        d = d | !(fabs(w.x[j]) < T(c.x_lim)) | !(fabs(w.y[j]) < T(c.v_lim)) | !(fabs(w.y[7 + j]) < T(c.W_lim));
-      d = d | !(fabs(R[2]) < T(c.sin_euler_lim));           // |pitch| >= lim
-      d = d | !(fabs(R[5]) < T(c.tan_euler_lim) * R[8]);    // |atan2(R21,R22)| >= lim
+        d = d | !(fabs(w.x[j]) < xl) | !(fabs(w.v[j]) < vl) | !(fabs(w.W[j]) < T(c.W_lim));
+      d = d | !(fabs(R20) < T(c.sin_euler_lim));          // |pitch| >= lim
+      d = d | !(fabs(R21) < T(c.tan_euler_lim) * R22);    // |atan2(R21,R22)| >= lim
       dn[0] = d;
     } else {
-      error_obs<KIND, T>(w, R, c, o0, o1);
+      quat_to_R(w.q, R);
+      error_obs<KIND, T, X>(w, R, c, o0, o1);
       if constexpr (KIND == QR_KIND_COUPLED) {  // coupled:78-110, float32 arithmetic on the float32 obs
-        const float r = -(float)c.Cx * sq3(&o0[0]) + -(float)c.CIx * sq3(&o0[3]) + -(float)c.Cv * sq3(&o0[6]) +
-                        -(float)c.Cb1 * fabsf(o0[18]) + -(float)c.CIb1 * (o0[19] * o0[19]) + -(float)c.CW * sq3(&o0[20]);
+        const float r = -c.Cx * sq3(&o0[0]) + -c.CIx * sq3(&o0[3]) + -c.Cv * sq3(&o0[6]) +
+                        -c.Cb1 * fabsf(o0[18]) + -c.CIb1 * (o0[19] * o0[19]) + -c.CW * sq3(&o0[20]);
         rraw[0] = r;
-        rwd[0] = interp01(r, (float)c.rmin_mono, (float)c.inv_nrmin_mono);
+        rwd[0] = interp01(r, c.rmin_mono, c.inv_nrmin_mono);
         dn[0] = out3(&o0[0]) | out3(&o0[6]) | out3(&o0[20]);
       } else {  // decoupled:92-140
-        const float r1 = -(float)c.Cx * sq3(&o0[0]) + -(float)c.CIx * sq3(&o0[3]) + -(float)c.Cv * sq3(&o0[6]) +
-                         -(float)c.Cw12 * sq3(&o0[12]);
-        const float r2 = -(float)c.Cb1 * fabsf(o1[0]) + -(float)c.CIb1 * (o1[1] * o1[1]) + -(float)c.CW3 * (o1[2] * o1[2]);
+        const float r1 = -c.Cx * sq3(&o0[0]) + -c.CIx * sq3(&o0[3]) + -c.Cv * sq3(&o0[6]) + -c.Cw12 * sq3(&o0[12]);
+        const float r2 = -c.Cb1 * fabsf(o1[0]) + -c.CIb1 * (o1[1] * o1[1]) + -c.CW3 * (o1[2] * o1[2]);
         rraw[0] = r1; rraw[NAG - 1] = r2;
-        rwd[0] = interp01(r1, (float)c.rmin_1, (float)c.inv_nrmin_1); rwd[NAG - 1] = interp01(r2, (float)c.rmin_2, (float)c.inv_nrmin_2);
+        rwd[0] = interp01(r1, c.rmin_1, c.inv_nrmin_1); rwd[NAG - 1] = interp01(r2, c.rmin_2, c.inv_nrmin_2);
         dn[0] = out3(&o0[0]) | out3(&o0[6]) | out3(&o0[12]);
         dn[NAG - 1] = !(fabsf(o1[2]) < 1.0f);
       }
@@ -329,73 +384,108 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     for (int g = 0; g < NAG; ++g)
       if (dn[g]) rwd[g] = -1.0f;
 
+    QR_STAMP(4, rwd[0] + (dn[0] ? 1.0f : 0.0f));
     // ---- time limit + auto-reset ----
     steps += 1;
-    const bool trunc = a.max_episode_steps > 0 && steps >= a.max_episode_steps;
+    const bool trunc = ka.max_episode_steps > 0 && steps >= ka.max_episode_steps;
     bool any_done = trunc;
 #pragma unroll
     for (int g = 0; g < NAG; ++g) any_done = any_done | dn[g];
-    const bool need_reset = (a.flags & QR_FLAG_AUTO_RESET) && any_done && active;
-    if (__ballot(need_reset)) {  // wave-uniform: skip unless some lane of this wave resets
-      if (need_reset) episode += 1;
-      Draws d;
-#if QR_ABLATE == 3  // measurement build: reset path without the RNG
-#pragma unroll
-      for (int j = 0; j < 20; ++j) d.r[j] = 0x9E3779B9u * (uint32_t)(j + 1) + (uint32_t)episode;
+#if QR_ABLATE == 4  // measurement build: the pool is sampled but no env is ever re-sampled
+    const bool need_reset = false;
+    if (have_pool) asm volatile("" ::"v"(pool.x[0]), "v"(pool.q[3]), "v"(pool.prm[5]), "v"(pool.W[2]), "v"(pool.v[1]));
 #else
-      coop_draw20(d, need_reset, a.seed, (uint64_t)(a.env_offset + i), (uint32_t)episode);
+    const bool need_reset = auto_reset && any_done && active;
 #endif
-#if QR_ABLATE == 4  // measurement build: RNG only, trivial consumption
-      if (need_reset) {
-        uint32_t acc = 0;
+    const int64_t row0 = (int64_t)t * N + first;
+    const unsigned long long rmask = __ballot(need_reset);
+    if (rmask) {  // wave-uniform: skipped unless some lane of this wave starts a new episode
+      // the terminal observation of the episode that ends here (what a learner bootstraps from):
+      // written for the resetting lanes only
+      if (need_reset && ka.final_obs0 != nullptr) {
+        if constexpr (KIND == QR_KIND_QUAD) {
+          T Rf[9];
+          quat_to_R(w.q, Rf);
+          float* fo = ka.final_obs0 + (row0 + lane) * D0;
 #pragma unroll
-        for (int j = 0; j < 20; ++j) acc ^= d.r[j];
-        w.x[0] = T((float)(acc & 0xFFFF) * 1e-5f);
-        a.episode[i] = episode;
+          for (int j = 0; j < 3; ++j) { fo[j] = (float)w.x[j]; fo[3 + j] = (float)w.v[j]; fo[15 + j] = (float)w.W[j]; }
+#pragma unroll
+          for (int j = 0; j < 9; ++j) fo[6 + j] = (float)Rf[j];
+        } else {
+          float* fo = ka.final_obs0 + (row0 + lane) * D0;
+#pragma unroll
+          for (int j = 0; j < D0; ++j) fo[j] = o0[j];
+          if constexpr (KT::D1 > 0) {
+            float* f1 = ka.final_obs1 + (row0 + lane) * D1;
+#pragma unroll
+            for (int j = 0; j < D1; ++j) f1[j] = o1[j];
+          }
+        }
       }
-#else
+      const int rank = __popcll(rmask & ((1ull << lane) - 1ull));  // rank among the wave's resetting lanes
+      const int total = __popcll(rmask);
+      uint32_t r19 = 0;
+      for (int pass = 0; 12 * pass < total; ++pass) {  // one pass unless more than 12 lanes reset at once
+        if (!(have_pool && pass == 0)) make_pool<T, X>(pool, ka.seed, gfirst, rcount + (uint32_t)t, pass, randomise, eval_reset, c);
+        const int slot = rank - 12 * pass;
+#if QR_ABLATE != 7
+        take_from_pool<T, X, TRAJ>(pool, need_reset && slot >= 0 && slot < 12, slot, w, r19);
+#else  // measurement build: the lane's own pool registers, no cross-lane reads
+        if (need_reset && slot >= 0 && slot < 12) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) { w.x[j] = pool.x[j]; w.v[j] = pool.v[j]; w.W[j] = T(pool.W[j]); }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w.q[j] = pool.q[j];
+#pragma unroll
+          for (int j = 0; j < 6; ++j) w.prm[j] = pool.prm[j];
+        }
+#endif
+      }
       if (need_reset) {
-        const bool eval = (a.flags & QR_FLAG_EVAL_RESET) != 0;
-        const bool randomise = !eval && !(a.flags & QR_FLAG_NO_UDM) && a.params != nullptr;
-        sample_reset(w, d, randomise, eval, c);
+        w.nominal = !randomise;
+#if QR_ABLATE != 5
         if (a.params != nullptr) params_dirty = true;
-        (a.episode + first)[lane] = episode;
+#endif
+        // episode counter (stream id of qr_reset / qr_traj_start): fire-and-forget, nothing here waits for it
+#if QR_ABLATE != 6
+        __hip_atomic_fetch_add(ka.episode + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         steps = 0;
         if constexpr (TRAJ) {  // mark_traj_start + first get_desired of the episode (main.py:227-229)
           float th, tt, wb, b1d_dot[3];
-          traj_draws(d.r[19], th, tt, wb);
-#if QR_ABLATE != 5 && QR_ABLATE != 7
+          traj_draws(r19, th, tt, wb);
           traj_start(w, tr, goal_mode, th, tt, wb);
-#endif
-#if QR_ABLATE != 6 && QR_ABLATE != 7
           traj_goal(w, tr, goal_mode, c, b1d_dot);
-#endif
           traj_dirty = true;
         }
-        quat_to_R(&w.y[3], R);
         if constexpr (KIND != QR_KIND_QUAD) {
+          quat_to_R(w.q, R);
 #pragma unroll
           for (int f = 0; f < 8; ++f) w.integ[f] = 0.0f;
-          error_obs<KIND, T>(w, R, c, o0, o1);  // first observation of the new episode (main.py:226-230)
+          error_obs<KIND, T, X>(w, R, c, o0, o1);  // first observation of the new episode (main.py:226-230)
         }
       }
-#endif
     }
+    have_pool = false;  // the speculative pool belongs to step 0's counter value
+    QR_STAMP(5, (float)w.q[0] + (float)w.x[0] + w.prm[0]);
+#ifdef QR_STAMPS
+    if (g_stamps != nullptr && lane == 0) g_stamps[(size_t)blockIdx.x * 8 + 7] = rmask;
+#endif
 
     // ---- outputs of step t ----
-    const int64_t row0 = (int64_t)t * N + first;
     if constexpr (KIND == QR_KIND_QUAD) {
-      if (a.obs0 != nullptr) {  // next state in the reference's order (x, v, vec_F(R), W)
+      if (ka.obs0 != nullptr) {  // next state in the reference's order (x, v, vec_F(R), W)
+        quat_to_R(w.q, R);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { o0[j] = (float)w.x[j]; o0[3 + j] = (float)w.y[j]; o0[15 + j] = (float)w.y[7 + j]; }
+        for (int j = 0; j < 3; ++j) { o0[j] = (float)w.x[j]; o0[3 + j] = (float)w.v[j]; o0[15 + j] = (float)w.W[j]; }
 #pragma unroll
         for (int j = 0; j < 9; ++j) o0[6 + j] = (float)R[j];
-        store_rows<B, D0>(a.obs0 + row0 * D0, o0, smem, tid, rows);
+        store_rows<B, D0>(ka.obs0 + row0 * D0, o0, smem, tid, rows);
       }
     } else {
-      store_rows<B, D0>(a.obs0 + row0 * D0, o0, smem, tid, rows);
+      store_rows<B, D0>(ka.obs0 + row0 * D0, o0, smem, tid, rows);
     }
-    if constexpr (KT::D1 > 0) store_rows<B, D1>(a.obs1 + row0 * D1, o1, smem, tid, rows);
+    if constexpr (KT::D1 > 0) store_rows<B, D1>(ka.obs1 + row0 * D1, o1, smem, tid, rows);
     if constexpr (POLICY) {
 #pragma unroll
       for (int j = 0; j < D0; ++j) po0[j] = o0[j];
@@ -404,21 +494,21 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     }
     if (active) {
       if constexpr (NAG == 1) {
-        (a.reward + row0)[lane] = rwd[0];
-        if (a.reward_raw) (a.reward_raw + row0)[lane] = rraw[0];
-        (a.done + row0)[lane] = dn[0] ? 1 : 0;
+        (ka.reward + row0)[lane] = rwd[0];
+        if (ka.reward_raw) (ka.reward_raw + row0)[lane] = rraw[0];
+        (ka.done + row0)[lane] = dn[0] ? 1 : 0;
       } else {
-        (reinterpret_cast<float2*>(a.reward) + row0)[lane] = make_float2(rwd[0], rwd[NAG - 1]);
-        if (a.reward_raw) (reinterpret_cast<float2*>(a.reward_raw) + row0)[lane] = make_float2(rraw[0], rraw[NAG - 1]);
-        (reinterpret_cast<uchar2*>(a.done) + row0)[lane] = make_uchar2(dn[0] ? 1 : 0, dn[NAG - 1] ? 1 : 0);
+        (reinterpret_cast<float2*>(ka.reward) + row0)[lane] = make_float2(rwd[0], rwd[NAG - 1]);
+        if (ka.reward_raw) (reinterpret_cast<float2*>(ka.reward_raw) + row0)[lane] = make_float2(rraw[0], rraw[NAG - 1]);
+        (reinterpret_cast<uchar2*>(ka.done) + row0)[lane] = make_uchar2(dn[0] ? 1 : 0, dn[NAG - 1] ? 1 : 0);
       }
-      if (a.truncated) (a.truncated + row0)[lane] = trunc ? 1 : 0;
+      if (ka.truncated) (ka.truncated + row0)[lane] = trunc ? 1 : 0;
     }
   }
 
   // ---- write the working set back ----
   if (active) {
-    store_state<XV, QW, T>(a, first, lane, w);
+    store_state<XV, QW>(a, first, lane, w);
     if (KIND != QR_KIND_QUAD) {
       const SoA<float> integ(a.integ, 8, L);
 #pragma unroll
@@ -439,6 +529,8 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       for (int f = 0; f < 6; ++f) prm.store(f, ufirst, lane, w.prm[f]);
     }
   }
+  if (auto_reset && lane == 0) a.reset_count[blockIdx.x] = (int32_t)(rcount + (uint32_t)ka.n_steps);  // never reuse a (tile, counter)
+  QR_STAMP(6, tid);
 }
 
 // get_norm_error_state on the current state (quad.py:421-466)
@@ -454,10 +546,10 @@ __global__ __launch_bounds__(64) void error_obs_kernel(const Args a) {
   const int64_t N = a.n, L = a.ld;
   const int rows = (int)((N - first) < B ? (N - first) : B);
   const bool active = tid < rows;
-  Work<T> w;
-  idle_work(w);
+  Work<T, XV> w;
+  idle_work(w, a.c);
   if (active) {
-    load_state<XV, QW, T>(a, first, (unsigned)tid, w);
+    load_state<XV, QW>(a, first, (unsigned)tid, w);
     if (a.goal) {
 #pragma unroll
       for (int f = 0; f < 12; ++f) w.goal[f] = a.goal[(int64_t)f * L + i];
@@ -466,10 +558,10 @@ __global__ __launch_bounds__(64) void error_obs_kernel(const Args a) {
     for (int f = 0; f < 8; ++f) w.integ[f] = a.integ[(int64_t)f * L + i];
   }
   T R[9];
-  quat_to_R(&w.y[3], R);
+  quat_to_R(w.q, R);
   float o0[D0];
   float o1[D1];
-  error_obs<KIND, T>(w, R, a.c, o0, o1);
+  error_obs<KIND, T, XV>(w, R, a.c, o0, o1);
   store_rows<B, D0>(a.obs0 + first * D0, o0, smem, tid, rows);
   if constexpr (KT::D1 > 0) store_rows<B, D1>(a.obs1 + first * D1, o1, smem, tid, rows);
   if (active) {
@@ -489,11 +581,11 @@ __global__ __launch_bounds__(64) void reset_kernel(const Args a) {
   const int32_t episode = a.episode[i] + 1;
   const bool eval = (a.flags & QR_FLAG_EVAL_RESET) != 0;
   const bool randomise = !eval && !(a.flags & QR_FLAG_NO_UDM);
-  Work<T> w;
+  Work<T, XV> w;
   Draws d;
   draw20(d, a.seed, (uint64_t)(a.env_offset + i), (uint32_t)episode);
   sample_reset(w, d, randomise, eval, a.c);
-  store_state<XV, QW, T>(a, (int64_t)blockIdx.x * 64, threadIdx.x, w);
+  store_state<XV, QW>(a, (int64_t)blockIdx.x * 64, threadIdx.x, w);
   if (a.params) {
 #pragma unroll
     for (int f = 0; f < 6; ++f) a.params[(int64_t)f * L + i] = w.prm[f];
@@ -511,32 +603,42 @@ template <typename XV, typename QW>
 __global__ __launch_bounds__(64) void get_state_kernel(const Args a) {
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= a.n) return;
-  Work<double> w;
-  load_state<XV, QW, double>(a, (int64_t)blockIdx.x * 64, threadIdx.x, w);
-  double R[9];
-  quat_to_R(&w.y[3], R);
+  Work<QW, XV> w;
+  load_state<XV, QW>(a, (int64_t)blockIdx.x * 64, threadIdx.x, w);
+  double q[4], R[9];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) q[j] = (double)w.q[j];
+  quat_to_R(q, R);
   double* o = a.rows_out + i * 18;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) { o[j] = w.x[j]; o[3 + j] = w.y[j]; o[15 + j] = w.y[7 + j]; }
+  for (int j = 0; j < 3; ++j) { o[j] = (double)w.x[j]; o[3 + j] = (double)w.v[j]; o[15 + j] = (double)w.W[j]; }
 #pragma unroll
   for (int j = 0; j < 9; ++j) o[6 + j] = R[j];
 }
 
-// state injection: float64 18-vector rows -> 13-word internal state (R -> nearest rotation -> q)
+// state injection: float64 18-vector rows -> 13-word internal state (R -> nearest rotation -> q).
+// A row whose attitude block has no nearest rotation in SO(3) (det R <= 0, or non-finite entries:
+// quad_utils.py:123-142 would hand such an R to the SVD and return a reflection-corrected matrix
+// that has nothing to do with the input) is REJECTED: the env keeps its state and the row is
+// counted in *status, which the host side turns into an error.
 template <typename XV, typename QW>
 __global__ __launch_bounds__(64) void set_state_kernel(const Args a) {
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= a.n) return;
   if (a.mask && !a.mask[i]) return;
   const double* r = a.rows_in + i * 18;
-  Work<double> w;
+  Work<QW, XV> w;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) { w.x[j] = r[j]; w.y[j] = r[3 + j]; w.y[7 + j] = r[15 + j]; }
+  for (int j = 0; j < 3; ++j) { w.x[j] = (XV)r[j]; w.v[j] = (XV)r[3 + j]; w.W[j] = (QW)r[15 + j]; }
   double q[4];
-  R_to_quat(r + 6, q);
+  const bool ok = R_to_quat(r + 6, q);
+  if (!ok) {
+    if (a.status) atomicAdd(a.status, 1);
+    return;
+  }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) w.y[3 + j] = q[j];
-  store_state<XV, QW, double>(a, (int64_t)blockIdx.x * 64, threadIdx.x, w);
+  for (int j = 0; j < 4; ++j) w.q[j] = (QW)q[j];
+  store_state<XV, QW>(a, (int64_t)blockIdx.x * 64, threadIdx.x, w);
 }
 
 // mark_traj_start for masked envs, from the current state
@@ -548,8 +650,8 @@ __global__ __launch_bounds__(64) void traj_start_kernel(const Args a) {
   const int64_t i = first + lane;
   if (i >= a.n) return;
   if (a.mask && !a.mask[i]) return;
-  Work<T> w;
-  load_state<XV, QW, T>(a, first, lane, w);
+  Work<T, XV> w;
+  load_state<XV, QW>(a, first, lane, w);
   float th, tt, wb;
   if (a.draws) {
     th = a.draws[i]; tt = a.draws[a.n + i]; wb = a.draws[2 * a.n + i];
@@ -574,9 +676,9 @@ __global__ __launch_bounds__(64) void get_desired_kernel(const Args a) {
   const int64_t i = first + lane;
   if (i >= a.n) return;
   if (a.mask && !a.mask[i]) return;
-  Work<T> w;
-  idle_work(w);
-  load_state<XV, QW, T>(a, first, lane, w);
+  Work<T, XV> w;
+  idle_work(w, a.c);
+  load_state<XV, QW>(a, first, lane, w);
   const SoA<float> traj(a.traj, 8, a.ld);
   Traj tr;
 #pragma unroll
@@ -656,18 +758,31 @@ __global__ __launch_bounds__(64) void gae_kernel(const GaeArgs g) {
 // ------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------
+static float round_up_to_float(double v) {  // smallest float >= v
+  float f = (float)v;
+  if ((double)f < v) f = nextafterf(f, INFINITY);
+  return f;
+}
+
 static void fill_coeffs(Coeffs& o, const QrCoeffs& q) {
-  o.Cx = q.Cx; o.CIx = q.CIx; o.Cv = q.Cv; o.Cb1 = q.Cb1; o.CIb1 = q.CIb1; o.CW = q.CW; o.Cw12 = q.Cw12; o.CW3 = q.CW3;
-  o.alpha = q.alpha; o.beta = q.beta; o.dt = q.dt;
-  o.x_lim = q.x_lim; o.v_lim = q.v_lim; o.W_lim = q.W_lim; o.eIx_lim = q.eIx_lim; o.eIb1_lim = q.eIb1_lim;
+  o.Cx = (float)q.Cx; o.CIx = (float)q.CIx; o.Cv = (float)q.Cv; o.Cb1 = (float)q.Cb1; o.CIb1 = (float)q.CIb1; o.CW = (float)q.CW;
+  o.Cw12 = (float)q.Cw12; o.CW3 = (float)q.CW3;
+  o.alpha = (float)q.alpha; o.beta = (float)q.beta; o.dt = q.dt; o.hdt = (float)(q.dt * 0.5);
+  o.x_lim = q.x_lim; o.v_lim = q.v_lim; o.W_lim = q.W_lim;
+  o.x_lim_f = (float)q.x_lim; o.x_lim_up = round_up_to_float(q.x_lim); o.v_lim_up = round_up_to_float(q.v_lim);
   const double lim = q.euler_lim_deg * kPi / 180.0;
-  o.sin_euler_lim = sin(lim); o.tan_euler_lim = tan(lim); o.udm = q.udm_fraction;
-  o.rmin_mono = -ceil(q.Cx + q.CIx + q.Cv + q.Cb1 + q.CIb1 + q.CW);  // quad.py:81
-  o.rmin_1 = -ceil(q.Cx + q.CIx + q.Cv + q.Cw12);                    // quad.py:85
-  o.rmin_2 = -ceil(q.Cb1 + q.CW3 + q.CIb1);                          // quad.py:88
+  o.sin_euler_lim = sin(lim); o.tan_euler_lim = tan(lim); o.udm = (float)q.udm_fraction;
+  o.reset_v = (float)(q.v_lim * 0.5); o.reset_W = (float)(q.W_lim * 0.5);
+  const double rmin_mono = -ceil(q.Cx + q.CIx + q.Cv + q.Cb1 + q.CIb1 + q.CW);  // quad.py:81
+  const double rmin_1 = -ceil(q.Cx + q.CIx + q.Cv + q.Cw12);                    // quad.py:85
+  const double rmin_2 = -ceil(q.Cb1 + q.CW3 + q.CIb1);                          // quad.py:88
+  o.rmin_mono = (float)rmin_mono; o.rmin_1 = (float)rmin_1; o.rmin_2 = (float)rmin_2;
   o.inv_x_lim = 1.0 / q.x_lim; o.inv_v_lim = 1.0 / q.v_lim; o.inv_W_lim = 1.0 / q.W_lim;
-  o.inv_eIx_lim = 1.0 / q.eIx_lim; o.inv_eIb1_lim = 1.0 / q.eIb1_lim;
-  o.inv_nrmin_mono = -1.0 / o.rmin_mono; o.inv_nrmin_1 = -1.0 / o.rmin_1; o.inv_nrmin_2 = -1.0 / o.rmin_2;
+  o.inv_eIx_lim = (float)(1.0 / q.eIx_lim); o.inv_eIb1_lim = (float)(1.0 / q.eIb1_lim);
+  o.inv_nrmin_mono = (float)(-1.0 / rmin_mono); o.inv_nrmin_1 = (float)(-1.0 / rmin_1); o.inv_nrmin_2 = (float)(-1.0 / rmin_2);
+  const double nom[6] = {q.m_nominal, q.d_nominal, q.J1_nominal, q.J3_nominal, q.c_tf_nominal, q.c_tw_nominal};
+  for (int j = 0; j < 6; ++j) { o.nom[j] = nom[j]; o.nom_f[j] = (float)nom[j]; }
+  o.g = q.g; o.g_f = (float)q.g; o.min_force = q.min_force;
   const double T8 = q.eight_T > 0 ? q.eight_T : 9.0;
   o.e8_w1 = (float)(2.0 * kPi / T8); o.e8_w2 = (float)(4.0 * kPi / T8);                // :102-103
   o.e8_k = (float)(-log(q.eight_eps > 0 ? q.eight_eps : 0.01) / T8);                   // :107-108
@@ -684,10 +799,13 @@ static int fill_env(Args& a, const QrEnv* e) {
   if (e->goal_mode < 0 || e->goal_mode > 3) return QR_E_KIND;
   if (e->goal_mode != QR_GOAL_EXTERNAL && !e->traj) return QR_E_NULL;
   if (!e->pos_vel || !e->att_rate) return QR_E_NULL;
+  const QrCoeffs& q = e->coeffs;
+  if (!(q.m_nominal > 0 && q.d_nominal > 0 && q.J1_nominal > 0 && q.J3_nominal > 0 && q.c_tf_nominal > 0 && q.c_tw_nominal > 0 &&
+        q.g > 0 && q.min_force >= 0 && q.dt > 0)) return QR_E_SIZE;  // a zero-initialised QrCoeffs: call qr_default_coeffs first
   if ((reinterpret_cast<uintptr_t>(e->pos_vel) | reinterpret_cast<uintptr_t>(e->att_rate)) & 15u) return QR_E_ALIGN;
   a.pos_vel = e->pos_vel; a.att_rate = e->att_rate; a.integ = e->integ; a.params = e->params; a.goal = e->goal;
   a.traj = e->traj; a.goal_mode = e->goal_mode;
-  a.episode = e->episode; a.steps = e->steps;
+  a.episode = e->episode; a.steps = e->steps; a.reset_count = e->reset_count;
   a.n = e->num_envs; a.ld = e->field_stride > 0 ? e->field_stride : e->num_envs;
   a.env_offset = e->env_offset; a.seed = e->seed;
   a.max_episode_steps = e->max_episode_steps; a.flags = e->flags;
@@ -733,23 +851,34 @@ static void launch_kind(const Args& a, hipStream_t s) {
 #undef QR_STEP_ARGS
 }
 
+// QR_ONLY_KIND / QR_ONLY_LAYOUT: experiment builds that instantiate one env kind / one layout only
+// (seconds instead of a minute to compile; tools/ab_libs.py); the product build has neither.
 template <typename XV, typename QW>
 static int launch_step(const Args& a, int kind, hipStream_t s) {
   if (a.n == 0) return 0;
+#ifdef QR_ONLY_KIND
+  if (kind != QR_ONLY_KIND) return QR_E_KIND;
+  launch_kind<QR_ONLY_KIND, XV, QW>(a, s);
+#else
   switch (kind) {
     case QR_KIND_QUAD: launch_kind<QR_KIND_QUAD, XV, QW>(a, s); break;
     case QR_KIND_COUPLED: launch_kind<QR_KIND_COUPLED, XV, QW>(a, s); break;
     default: launch_kind<QR_KIND_DECOUPLED, XV, QW>(a, s); break;
   }
+#endif
   return (int)hipGetLastError();
 }
 
+#ifdef QR_ONLY_LAYOUT
+#define QR_DISPATCH_LAYOUT(layout, CALL) { using XV = float; using QW = double; CALL; }
+#else
 #define QR_DISPATCH_LAYOUT(layout, CALL)                                        \
   switch (layout) {                                                             \
     case QR_LAYOUT_MIXED: { using XV = float; using QW = double; CALL; } break; \
     case QR_LAYOUT_F64:   { using XV = double; using QW = double; CALL; } break; \
     default:              { using XV = float; using QW = float; CALL; } break;  \
   }
+#endif
 
 template <typename XV, typename QW>
 static void launch_error_obs(const Args& a, int kind, unsigned grid, hipStream_t s) {
@@ -797,7 +926,8 @@ static int do_rollout(const QrEnv* env, const float* action, const QrPolicyRollo
   if (substeps < 1 || n_steps < 1) return QR_E_SIZE;
   if (env->kind != QR_KIND_QUAD && (!env->integ || !out->obs0)) return QR_E_NULL;
   if (env->kind == QR_KIND_DECOUPLED && !out->obs1) return QR_E_NULL;
-  if ((env->flags & QR_FLAG_AUTO_RESET) && !env->episode) return QR_E_NULL;
+  if ((env->flags & QR_FLAG_AUTO_RESET) && (!env->episode || !env->reset_count)) return QR_E_NULL;
+  if (env->kind == QR_KIND_DECOUPLED && out->final_obs0 && !out->final_obs1) return QR_E_NULL;
   if (pol) {
     if (env->kind == QR_KIND_QUAD) return QR_E_KIND;
     if (!pol->actors || !pol->obs0_in || !pol->action_out) return QR_E_NULL;
@@ -819,7 +949,7 @@ static int do_rollout(const QrEnv* env, const float* action, const QrPolicyRollo
     // action rows: A = 4 is read with one 16-byte load per lane; A = 5 (DECOUPLED) with dword loads
     if (reinterpret_cast<uintptr_t>(action) & (env->kind == QR_KIND_DECOUPLED ? 3u : 15u)) return QR_E_ALIGN;
   }
-  a.action = action; a.obs0 = out->obs0; a.obs1 = out->obs1;
+  a.action = action; a.obs0 = out->obs0; a.obs1 = out->obs1; a.final_obs0 = out->final_obs0; a.final_obs1 = out->final_obs1;
   a.reward = out->reward; a.reward_raw = out->reward_raw; a.done = out->done; a.truncated = out->truncated;
   a.n_steps = n_steps; a.substeps = substeps;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -831,6 +961,13 @@ static int do_rollout(const QrEnv* env, const float* action, const QrPolicyRollo
 }  // namespace qr
 
 extern "C" {
+
+#ifdef QR_STAMPS
+int qr_debug_set_stamps(void* buf) {  // diagnostic builds only: device buffer of 8 x uint64 per wave (NULL = off)
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(qr::g_stamps), &p, sizeof(p));
+}
+#endif
 
 int qr_abi_version(void) { return QR_ABI_VERSION; }
 
@@ -844,6 +981,8 @@ void qr_default_coeffs(QrCoeffs* c) {
   c->eight_T = 9.0; c->eight_A1 = 1.5; c->eight_A2 = 1.0; c->eight_w_b1d = 0.349066; c->eight_alt_d = -0.6;  // trajectory_generator.py:98-110
   c->eight_eps = 0.01; c->eight_count = 3.0;
   c->w_adapt = 16.0;
+  c->m_nominal = 2.15; c->d_nominal = 0.23; c->J1_nominal = 0.022; c->J3_nominal = 0.035;  // quad.py:28-33
+  c->c_tf_nominal = 0.0135; c->c_tw_nominal = 2.2; c->g = 9.81; c->min_force = 0.5;         // quad.py:31-36
 }
 
 int qr_step(const QrEnv* env, const float* action, int32_t substeps, const QrStepOut* out, void* stream) {
@@ -897,11 +1036,11 @@ int qr_get_state(const QrEnv* env, double* rows, void* stream) {
   return (int)hipGetLastError();
 }
 
-int qr_set_state(const QrEnv* env, const double* rows, const uint8_t* mask, void* stream) {
+int qr_set_state(const QrEnv* env, const double* rows, const uint8_t* mask, int32_t* rejected, void* stream) {
   qr::Args a{};
   if (int rc = qr::fill_env(a, env)) return rc;
   if (!rows) return QR_E_NULL;
-  a.rows_in = rows; a.mask = mask;
+  a.rows_in = rows; a.mask = mask; a.status = rejected;
   const unsigned grid = (unsigned)((a.n + 63) / 64);
   if (grid == 0) return 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -16,6 +16,9 @@ from . import _lib
 _NS = "gym_rotor_amd"
 
 
+_RESET_COUNTS: dict = {}
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -29,6 +32,11 @@ def _env_struct(kind, layout, pos_vel, att_rate, integ, params, goal, episode, s
     e.env_offset, e.seed, e.flags = env_offset, seed & (2 ** 64 - 1), flags
     e.pos_vel, e.att_rate, e.integ, e.params, e.goal, e.episode = _p(pos_vel), _p(att_rate), _p(integ), _p(params), _p(goal), _p(episode)
     e.coeffs = _lib.default_coeffs()
+    if flags & _lib.FLAG_AUTO_RESET:  # per-tile stream position of the in-launch reset (quadrotor_hip.h: reset_count)
+        key = (pos_vel.data_ptr(), pos_vel.shape[1])
+        if key not in _RESET_COUNTS:
+            _RESET_COUNTS[key] = torch.zeros((pos_vel.shape[1] + 63) // 64, dtype=torch.int32, device=pos_vel.device)
+        e.reset_count = _RESET_COUNTS[key].data_ptr()
     return e
 
 

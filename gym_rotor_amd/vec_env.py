@@ -65,9 +65,10 @@ class QuadVecEnv:
                     cannot trigger (the plain kernel is launched); it keeps envs that are stepped on
                     far beyond termination inside the 1e-5 trajectory bar.  0 disables it.
     layout          internal state precision (the state is 13 words: x, v, unit quaternion q, W):
-                    'mixed' (default) x,v float32 + q,W float64, float64 arithmetic: 1000-step
+                    'mixed' (default) x,v float32 + q,W float64; W integrated and q accumulated in
+                    float64, RK4 stage quaternions / thrust direction in float32: 1000-step
                     trajectories within ~4e-6 of the reference (the float32 ulp of x, v);
-                    'f64' all float64: within ~3e-7, 25 % more bytes per env-step;
+                    'f64' all float64 storage and arithmetic: within ~3e-7, 25 % more bytes per env-step;
                     'f32' all float32 (fast, outside the 1e-5 parity bar)
     use_UDM         per-env domain randomisation at reset (quad.py:359-404)
     auto_reset      re-sample terminated/truncated envs inside the step launch; the returned
@@ -80,6 +81,9 @@ class QuadVecEnv:
                     curve; parameters eight_* of QuadConstants) is evaluated
                     INSIDE the step launch from the pre-step state, as main.py:145-147 does on the
                     host every step; see mark_traj_start() / get_desired()
+    final_obs       with auto_reset: also keep the TERMINAL observation rows of the envs that were
+                    re-sampled in the last step (`final_observation()`; the reference's obs_next of
+                    that transition, main.py:163-178) — what a learner bootstraps V(s') from
     obs_rows        write float32 observation rows [N,D].  Always on for the wrappers.  For
                     kind='quad' the observation is the next state (quad.py:269-271): True writes
                     it as float32 [N,18] rows each step; False (default) writes nothing and
@@ -93,7 +97,7 @@ class QuadVecEnv:
                  UDM_percentage: float = 10.0, auto_reset: bool = False, max_episode_steps: int = 0,
                  env_offset: int = 0, want_raw_reward: bool = False, obs_rows: Optional[bool] = None,
                  field_stride: Optional[int] = None, goal_mode: Optional[int] = None, w_adapt: float = 16.0,
-                 constants: Optional[QuadConstants] = None):
+                 constants: Optional[QuadConstants] = None, final_obs: bool = False):
         if kind not in KINDS:
             raise ValueError(f"kind must be one of {KINDS}, got {kind!r}")
         if num_envs < 1:
@@ -161,6 +165,8 @@ class QuadVecEnv:
         self.goal_mode = goal_mode
         self._traj = None if goal_mode is None else self._soa(8, torch.float32)
         self._episode = torch.zeros(N, dtype=torch.int32, device=dev)
+        # stream position of the in-launch reset, one counter per 64-env tile (quadrotor_hip.h: reset_count)
+        self._reset_count = torch.zeros((N + 63) // 64, dtype=torch.int32, device=dev)
         self._steps = torch.zeros(N, dtype=torch.int32, device=dev) if self.max_episode_steps > 0 else None
         # caller-facing rows
         self.obs_rows = (kind != "quad") if obs_rows is None else bool(obs_rows)
@@ -171,6 +177,13 @@ class QuadVecEnv:
         self._reward = torch.empty(N, self.n_agents, dtype=torch.float32, device=dev)
         self._reward_raw = torch.empty(N, self.n_agents, dtype=torch.float32, device=dev) if want_raw_reward else None
         self._done = torch.zeros(N, self.n_agents, dtype=torch.bool, device=dev)
+        self._final0 = self._final1 = None
+        if final_obs:
+            if not self.auto_reset:
+                raise ValueError("final_obs=True needs auto_reset=True (without it step() already returns the terminal observation)")
+            self._final0 = torch.zeros(N, self.obs_dims[0], dtype=torch.float32, device=dev)
+            self._final1 = torch.zeros(N, self.obs_dims[1], dtype=torch.float32, device=dev) if len(self.obs_dims) > 1 else None
+        self._rejected = torch.zeros(1, dtype=torch.int32, device=dev)  # qr_set_state: rows without a nearest rotation
         self._last_obs = None    # observation rows the next policy action is computed from (rollout_actor)
         self._policy_steps = 0   # global step index of the in-kernel action-noise stream
         self._trunc = torch.zeros(N, dtype=torch.bool, device=dev)
@@ -184,7 +197,8 @@ class QuadVecEnv:
             setattr(co, name, float(getattr(c, name)))
         co.CW, co.dt, co.euler_lim_deg, co.udm_fraction = c.CW, c.dt, c.euler_lim, self.UDM_percentage / 100.0
         co.w_adapt = float(w_adapt)
-        for name in ("eight_T", "eight_A1", "eight_A2", "eight_w_b1d", "eight_alt_d", "eight_eps", "eight_count"):
+        for name in ("eight_T", "eight_A1", "eight_A2", "eight_w_b1d", "eight_alt_d", "eight_eps", "eight_count",
+                     "m_nominal", "d_nominal", "J1_nominal", "J3_nominal", "c_tf_nominal", "c_tw_nominal", "g", "min_force"):
             setattr(co, name, float(getattr(c, name)))
         self._cenv.coeffs = co
         self._sync_structs()
@@ -204,11 +218,12 @@ class QuadVecEnv:
         e.integ, e.params, e.goal = _ptr(self._integ), _ptr(self._params), _ptr(self._goal)
         e.traj = _ptr(self._traj)
         e.goal_mode = _lib.GOAL_ID[self.goal_mode]
-        e.episode, e.steps = _ptr(self._episode), _ptr(self._steps)
+        e.episode, e.steps, e.reset_count = _ptr(self._episode), _ptr(self._steps), _ptr(self._reset_count)
         e.max_episode_steps = self.max_episode_steps
         e.flags = (_lib.FLAG_AUTO_RESET if self.auto_reset else 0) | (0 if self.use_UDM else _lib.FLAG_NO_UDM)
         o.obs0, o.obs1, o.reward, o.reward_raw = _ptr(self._obs0), _ptr(self._obs1), _ptr(self._reward), _ptr(self._reward_raw)
         o.done, o.truncated = _ptr(self._done), (_ptr(self._trunc) if self._steps is not None else None)
+        o.final_obs0, o.final_obs1 = _ptr(self._final0), _ptr(self._final1)
 
     def _stream(self):
         # kernels are launched on the env's device: make it current for the call if it is not
@@ -245,7 +260,15 @@ class QuadVecEnv:
         if policy:
             want["action"] = (lead + (N, self.action_dim), torch.float32)
         optional = {"reward_raw": (lead + (N, self.n_agents), torch.float32), "truncated": (lead + (N,), torch.bool),
-                    "logprob": (lead + (N, self.action_dim), torch.float32)}
+                    "logprob": (lead + (N, self.action_dim), torch.float32),
+                    "final_obs0": (lead + (N, self.obs_dims[0]), torch.float32)}
+        if len(self.obs_dims) > 1:
+            optional["final_obs1"] = (lead + (N, self.obs_dims[1]), torch.float32)
+        if out.get("final_obs0") is not None:
+            if not self.auto_reset:
+                raise ValueError("out['final_obs0'] needs auto_reset=True")
+            if len(self.obs_dims) > 1 and out.get("final_obs1") is None:
+                raise ValueError("out['final_obs1'] is required with out['final_obs0'] for kind 'decoupled'")
         for k, (shape, dtype) in list(want.items()) + [(k, v) for k, v in optional.items() if out.get(k) is not None]:
             t = out.get(k)
             if t is None:
@@ -280,6 +303,7 @@ class QuadVecEnv:
         o.obs0, o.obs1, o.reward = _ptr(out.get("obs0")), _ptr(out.get("obs1")), _ptr(out["reward"])
         o.reward_raw, o.done = _ptr(out.get("reward_raw")), _ptr(out["terminated"])
         o.truncated = _ptr(out.get("truncated")) if self._steps is not None else None
+        o.final_obs0, o.final_obs1 = _ptr(out.get("final_obs0")), _ptr(out.get("final_obs1"))
         rc = self._lib.qr_step(C.byref(self._cenv), a.data_ptr(), self.substeps, C.byref(o), self._stream())
         _lib.check(rc, "qr_step")
         obs = out.get("obs0") if "obs1" not in out else (out["obs0"], out["obs1"])
@@ -307,6 +331,7 @@ class QuadVecEnv:
         o.obs0, o.obs1, o.reward = _ptr(out.get("obs0")), _ptr(out.get("obs1")), _ptr(out["reward"])
         o.reward_raw, o.done = _ptr(out.get("reward_raw")), _ptr(out["terminated"])
         o.truncated = _ptr(out["truncated"]) if self._steps is not None else None
+        o.final_obs0, o.final_obs1 = _ptr(out.get("final_obs0")), _ptr(out.get("final_obs1"))
         rc = self._lib.qr_rollout(C.byref(self._cenv), a.data_ptr(), T, self.substeps, C.byref(o), self._stream())
         _lib.check(rc, "qr_rollout")
         out["obs"] = out["obs0"] if self._obs1 is None else (out["obs0"], out["obs1"])
@@ -376,6 +401,7 @@ class QuadVecEnv:
         o.obs0, o.obs1, o.reward = _ptr(out.get("obs0")), _ptr(out.get("obs1")), _ptr(out["reward"])
         o.reward_raw, o.done = _ptr(out.get("reward_raw")), _ptr(out["terminated"])
         o.truncated = _ptr(out["truncated"]) if self._steps is not None else None
+        o.final_obs0, o.final_obs1 = _ptr(out.get("final_obs0")), _ptr(out.get("final_obs1"))
         rc = self._lib.qr_rollout_actor(C.byref(self._cenv), C.byref(pol), T, self.substeps, C.byref(o), self._stream())
         _lib.check(rc, "qr_rollout_actor")
         self._policy_steps += T
@@ -407,6 +433,7 @@ class QuadVecEnv:
         finally:
             self._cenv.flags = flags
         _lib.check(rc, "qr_reset")
+        self._last_obs = None  # the rows of the previous episode are not this episode's observation
         if self.goal_mode is not None:  # main.py:226-227: reset, then mark_traj_start(state)
             _lib.check(self._lib.qr_traj_start(C.byref(self._cenv), _ptr(m), None, self._stream()), "qr_traj_start")
         return self.get_current_state().to(torch.float32)
@@ -442,6 +469,7 @@ class QuadVecEnv:
         self._goal[3:6] = self._rows3(vd, "vd")
         self._goal[6:9] = self._rows3(b1d, "b1d")
         self._goal[9:12] = self._rows3(np.zeros(3) if Wd is None else Wd, "Wd")
+        self._last_obs = None  # observations are errors w.r.t. the goal: ask get_norm_error_state() again
 
     # ---- goal generation (utils/trajectory_generator.py modes 0 / 1) ----------------
     def mark_traj_start(self, mask: Optional[torch.Tensor] = None, theta_b1d=None, t_traj=None, w_b1d=None):
@@ -483,24 +511,51 @@ class QuadVecEnv:
         return rows
 
     def set_state(self, state, integ=None, params=None, mask=None):
-        """Inject states (and optionally integrator terms / parameters): [N,18] / [N,8] / [N,6].
-        R goes through the reference's ensure_SO3 rule and is stored as a unit quaternion."""
+        """Inject states (and optionally integrator terms / parameters): [N,18] / [N,8] / [N,6]; with
+        `mask` only the masked envs change (state, integ and params alike).  R goes through the
+        reference's ensure_SO3 rule and is stored as a unit quaternion.  A row whose attitude block
+        has no nearest rotation (det R <= 0, NaN/Inf) raises ValueError and leaves that env untouched."""
         s = torch.as_tensor(state, device=self.device).to(torch.float64).contiguous()
         if tuple(s.shape) != (self.num_envs, 18):
             raise ValueError(f"state must be [{self.num_envs}, 18]")
         m = None if mask is None else torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
-        _lib.check(self._lib.qr_set_state(C.byref(self._cenv), s.data_ptr(), _ptr(m), self._stream()), "qr_set_state")
+        if m is not None and tuple(m.shape) != (self.num_envs,):
+            raise ValueError("mask must be a [num_envs] tensor")
+        self._rejected.zero_()
+        _lib.check(self._lib.qr_set_state(C.byref(self._cenv), s.data_ptr(), _ptr(m), self._rejected.data_ptr(), self._stream()), "qr_set_state")
+        sel = None if m is None else m.bool()[None, :]
+
+        def put(dst, rows):
+            src = torch.as_tensor(rows, device=self.device).to(torch.float32).t()
+            if tuple(src.shape) != tuple(dst.shape):
+                raise ValueError(f"expected [{self.num_envs}, {dst.shape[0]}] rows")
+            dst.copy_(src if sel is None else torch.where(sel, src, dst))
+
         if integ is not None and self._integ is not None:
-            self._integ.copy_(torch.as_tensor(integ, device=self.device).to(torch.float32).t())
+            put(self._integ, integ)
         if params is not None:
             if self._params is None:
                 self._params = self._soa(6, torch.float32)
+                self._params.copy_(torch.tensor(self.constants.nominal_params, dtype=torch.float32, device=self.device)[:, None].expand(6, self.num_envs))
                 self._cenv.params = self._params.data_ptr()
-            self._params.copy_(torch.as_tensor(params, device=self.device).to(torch.float32).t())
+            put(self._params, params)
+        self._last_obs = None
+        bad = int(self._rejected.item())  # off the hot path: one host sync per injection
+        if bad:
+            raise ValueError(f"set_state: {bad} row(s) rejected — the attitude block has det R <= 0 or non-finite entries "
+                             "(no nearest rotation); those envs keep their previous state")
+
+    def final_observation(self):
+        """Terminal observation rows of the envs re-sampled by the LAST step() (final_obs=True): rows of
+        envs that did not reset hold whatever an earlier reset left there — select with the step's
+        terminated/truncated flags."""
+        if self._final0 is None:
+            raise RuntimeError("construct the env with final_obs=True")
+        return self._final0 if self._final1 is None else (self._final0, self._final1)
 
     def state_dict(self) -> dict:
         """Checkpoint of everything the env owns (18 + 8 words per env + params/goal/counters)."""
-        keys = ("_pos_vel", "_att_rate", "_integ", "_params", "_goal", "_traj", "_episode", "_steps")
+        keys = ("_pos_vel", "_att_rate", "_integ", "_params", "_goal", "_traj", "_episode", "_steps", "_reset_count")
         sd = {k[1:]: (None if getattr(self, k) is None else getattr(self, k).clone()) for k in keys}
         sd["policy_steps"] = int(self._policy_steps)   # position of the in-kernel action-noise stream (rollout_actor)
         sd["seed"] = int(self.seed)
@@ -516,6 +571,7 @@ class QuadVecEnv:
             self.seed = int(sd.pop("seed"))
             self._cenv.seed = self.seed & (2 ** 64 - 1)
         last = sd.pop("last_obs", None)
+        self._last_obs = None
         if last is not None:
             last = tuple(o.to(self.device).clone() for o in last)
             self._last_obs = last[0] if len(last) == 1 else last

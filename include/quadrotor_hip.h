@@ -28,7 +28,10 @@
  *     The reference's 18-vector (x, v, vec_F(R) column-major, W; quad.py:146,
  *     quad_utils.py:12-16) is produced / consumed by qr_get_state / qr_set_state.
  *   - precision (`layout`): QR_LAYOUT_MIXED (default) stores x,v as float32 and q,W as
- *     float64 and integrates in float64; QR_LAYOUT_F64 stores everything as float64;
+ *     float64; W is integrated and q ACCUMULATED in float64, the RK4 stage quaternions and
+ *     the thrust direction are formed in float32 (same 1000-step error as
+ *     all-float64 arithmetic).  QR_LAYOUT_F64 stores and computes everything in float64 (the
+ *     reference-grade mode: 4th-order convergence to the reference down to 1e-10);
  *     QR_LAYOUT_F32 stores and computes in float32 (fast, NOT inside the 1e-5/1000-step
  *     parity bar).  See DESIGN.md §4 for the measurements behind this.
  */
@@ -41,7 +44,7 @@
 extern "C" {
 #endif
 
-#define QR_ABI_VERSION 9
+#define QR_ABI_VERSION 10
 
 /* env kinds */
 #define QR_KIND_QUAD      0 /* QuadEnv            gym_rotor/envs/quad.py:19            */
@@ -49,14 +52,15 @@ extern "C" {
 #define QR_KIND_DECOUPLED 2 /* DecoupledWrapper   wrappers/decoupled_yaw_wrapper.py:12 */
 
 /* state layouts */
-#define QR_LAYOUT_MIXED 0 /* pos_vel float32, att_rate float64, float64 arithmetic */
+#define QR_LAYOUT_MIXED 0 /* pos_vel float32, att_rate float64; float64 W + q accumulation, float32 RK4 stages */
 #define QR_LAYOUT_F64   1 /* all float64                                           */
 #define QR_LAYOUT_F32   2 /* all float32                                           */
 
 /* argument errors */
 #define QR_E_NULL   (-1) /* a required pointer is NULL             */
 #define QR_E_KIND   (-2) /* kind / layout / actor.squash out of range, or an entry point undefined for the kind */
-#define QR_E_SIZE   (-3) /* num_envs < 0 or > 22 369 621 (32-bit SoA offsets), bad field_stride, substeps < 1, n_steps < 1 */
+#define QR_E_SIZE   (-3) /* num_envs < 0 or > 22 369 621 (32-bit SoA offsets), bad field_stride, substeps < 1, n_steps < 1,
+                            or a QrCoeffs with non-positive nominal parameters / dt (not filled by qr_default_coeffs) */
 #define QR_E_ALIGN  (-4) /* a buffer is not 16-byte aligned        */
 
 /* goal sources */
@@ -95,6 +99,12 @@ typedef struct QrCoeffs {
    * error leaves its bound; goal rates |Wd| <= W_lim / 2) it can never trigger, so the launcher
    * then uses the kernel compiled without it.  0 disables it. */
   double w_adapt;
+  /* Nominal vehicle and environment constants (QuadEnv.__init__, quad.py:28-36): what a reset without
+   * domain randomisation restores, what UDM scatters around, and what an env without a params
+   * buffer flies with. */
+  double m_nominal, d_nominal, J1_nominal, J3_nominal; /* 2.15 kg, 0.23 m, 0.022 (= J2), 0.035 kg m^2 */
+  double c_tf_nominal, c_tw_nominal;                   /* 0.0135, 2.2                                 */
+  double g, min_force;                                 /* 9.81 m/s^2, 0.5 N                           */
 } QrCoeffs;
 
 /* Per-env device buffers owned by the caller (the Python env object). */
@@ -106,7 +116,10 @@ typedef struct QrEnv {
                           A multiple of 4, >= N.  Padding it off a power of two avoids all
                           fields of an env landing on one HBM channel.        */
   int64_t env_offset;  /* global id of local env 0 (multi-GPU shard offset; RNG key)      */
-  uint64_t seed;       /* RNG seed; draws depend only on (seed, global env id, episode)   */
+  uint64_t seed;       /* RNG seed.  qr_reset draws depend only on (seed, global env id, episode); in-launch
+                          resets (QR_FLAG_AUTO_RESET) on (seed, global id of the 64-env tile's first env,
+                          reset_count of that tile, rank of the env among the tile's envs that reset in
+                          that step) — see reset_count                                                */
   void*    pos_vel;    /* [6][N]  x, v                                         in/out      */
   void*    att_rate;   /* [7][N]  q(w,x,y,z), W                                in/out      */
   float*   integ;      /* [8][N]  eIx(3), g_x prev(3), eIb1, g_b prev (quad_utils.py:38-63); NULL for QUAD */
@@ -121,6 +134,13 @@ typedef struct QrEnv {
   int32_t  reserved0;
   int32_t* episode;    /* [N]     episode counter (RNG stream id); required for resets     */
   int32_t* steps;      /* [N]     steps since reset; NULL = no time-limit bookkeeping      */
+  int32_t* reset_count;/* [ceil(N/64)] stream position of the in-launch reset of each 64-env tile (one
+                          wavefront): advanced by 1 per env-step by qr_step / qr_rollout(_actor) with
+                          QR_FLAG_AUTO_RESET (required then), so that a (tile, count) pair is never
+                          used twice — also when a captured hipGraph is replayed.  The draws of tile
+                          j depend only on (seed, env_offset + 64 j, count, slot): results do not
+                          depend on how the batch is sharded as long as every shard starts at a
+                          multiple of 64 envs.  Zero-initialise.                                     */
   int32_t  max_episode_steps; /* >0: truncated[i]=1 when steps reaches it (gym_rotor/__init__.py:3-7) */
   uint32_t flags;      /* QR_FLAG_*                                                       */
   QrCoeffs coeffs;
@@ -137,6 +157,12 @@ typedef struct QrStepOut {
   float*   reward_raw;  /* optional: hook output before np.interp / crash override        */
   uint8_t* done;        /* terminated flags (done_wrapper)                                */
   uint8_t* truncated;   /* optional [N]                                                   */
+  /* Optional, with QR_FLAG_AUTO_RESET: rows [N][D0] / [N][D1] (same shapes as obs0 / obs1; QUAD: [N][18])
+   * that receive the TERMINAL observation of every env that is re-sampled in this step — the
+   * obs_next the reference stores for that transition (main.py:163-178; obs0/obs1 then already hold
+   * the first observation of the new episode).  Rows of envs that did not reset are left untouched. */
+  float*   final_obs0;
+  float*   final_obs1;
 } QrStepOut;
 
 /* Replaces QuadEnv.step(action) (quad.py:142-168) = action_wrapper -> observation_wrapper
@@ -227,8 +253,11 @@ int qr_get_state(const QrEnv* env, double* rows, void* stream);
 /* Replaces assignment to QuadEnv.state: reads float64 rows [N][18] for envs with
  * mask[i] != 0 (NULL = all).  R is first passed through the reference's ensure_SO3 rule
  * (quad_utils.py:123-142) — and, because the internal attitude is a unit quaternion, always
- * projected onto SO(3) (nearest rotation, the same U V^T the reference's SVD yields). */
-int qr_set_state(const QrEnv* env, const double* rows, const uint8_t* mask, void* stream);
+ * projected onto SO(3) (nearest rotation, the same U V^T the reference's SVD yields).
+ * A row whose attitude block has det R <= 0 or a non-finite entry has no nearest rotation: it is
+ * REJECTED (that env keeps its previous state) and counted in *rejected (device int32, optional,
+ * zero it before the call; the host wrapper raises when it is non-zero). */
+int qr_set_state(const QrEnv* env, const double* rows, const uint8_t* mask, int32_t* rejected, void* stream);
 
 /* Replaces TrajectoryGenerator.mark_traj_start(state) (utils/trajectory_generator.py:176-204)
  * plus the episode-start branch of calculate_desired (mode 0 :141-148: b1d = Rz(theta) b1_proj,

@@ -533,35 +533,118 @@ def test_one_million_envs_ten_substeps_and_shard_equivalence():
     assert (r[d] == -1.0).all() and ((r[~d] >= 0) & (r[~d] <= 1)).all()
 
 
-@pytest.mark.parametrize("kind", KINDS)
-def test_in_launch_reset_draws_equal_the_reset_kernel(kind):
-    """The wave-cooperative Philox path of the in-launch reset (one pass serves up to 12 resetting
-    lanes; several passes when more reset) produces exactly the state, parameters and counters that
-    qr_reset's per-lane draws give for the same (seed, env id, episode) — checked with 1, a few,
-    13..63 and all 64 lanes of a wave resetting in the same step."""
-    n = 64 * 40 + 17
-    env = _env(kind, n, seed=77, auto_reset=True, obs_rows=True)
-    env.reset("train")
-    # make a chosen set of lanes terminate in this step: x far outside the arena
-    kill = torch.zeros(n, dtype=torch.bool, device="cuda")
-    for w_, cnt in enumerate([1, 2, 3, 11, 12, 13, 24, 25, 37, 63, 64, 5]):
-        idx = torch.randperm(64, device="cuda")[:cnt] + 64 * w_
-        kill[idx] = True
-    kill[n - 3:] = True                                             # ragged tail wave
+def _kill(env, kill):
+    """Make the envs in `kill` terminate in the next step: x far outside the arena."""
     st = _np(env.get_current_state())
     st[_np(kill), 0] = 5.0
     env.set_state(st, mask=kill)
-    ep_before = env._episode.clone()
-    obs, rwd, done, _, _ = env.step(torch.zeros(n, env.action_dim, device="cuda"))
-    assert bool(done[kill].any(1).all()) and bool((env._episode == ep_before + kill.int()).all())
-    twin = _env(kind, n, seed=77, auto_reset=False, obs_rows=True)
-    twin.load_state_dict({k: v for k, v in env.state_dict().items() if k not in ("last_obs",)})
-    twin._episode.copy_(ep_before)
-    twin.reset("train", mask=kill)
-    assert torch.equal(twin._episode, env._episode)
-    a, b = _np(env.get_current_state()), _np(twin.get_current_state())
-    assert np.array_equal(a[_np(kill)], b[_np(kill)])
-    assert torch.equal(env.params[kill], twin.params[kill])
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_in_launch_reset_pool_keying(kind):
+    """In-launch resets take episode starts from the wavefront's pool (qr_rng.h): the stream is keyed by
+    (seed, global id of the 64-env tile's first env, the tile's reset counter, slot), slot = rank of the
+    lane among the tile's lanes that reset in that step.  Checked with 1, a few, 12, 13..63 and all 64
+    lanes of a tile resetting at once (more than 12 = further pools drawn on demand):
+      * the r-th resetting lane of a tile receives the same start whichever lane it is;
+      * slots, tiles and counter values give different starts; a tile's counter advances by one per
+        env-step whether or not anything reset;
+      * a shard that starts at a multiple of 64 envs reproduces the global batch bit for bit;
+      * episode counters of the re-sampled envs advance by one."""
+    counts = [1, 2, 3, 11, 12, 13, 24, 25, 37, 63, 64, 5]
+    n = 64 * 40 + 17
+    g = torch.Generator(device="cuda"); g.manual_seed(123)
+
+    def make(offset=0, n_=n):
+        e = _env(kind, n_, seed=77, auto_reset=True, obs_rows=True, env_offset=offset)
+        e.reset("train")
+        if kind != "quad":
+            e.get_norm_error_state()
+        return e
+
+    def kill_sets():
+        k = torch.zeros(n, dtype=torch.bool, device="cuda")
+        for w_, cnt in enumerate(counts):
+            k[torch.randperm(64, device="cuda", generator=g)[:cnt] + 64 * w_] = True
+        k[n - 3:] = True                                            # ragged tail wave
+        return k
+
+    A, B = make(), make()
+    ka, kb = kill_sets(), kill_sets()
+    assert not torch.equal(ka, kb)
+    zero = torch.zeros(n, A.action_dim, device="cuda")
+    ep0 = A._episode.clone()
+    for e, k in ((A, ka), (B, kb)):
+        _kill(e, k)
+        _, _, done, _, _ = e.step(zero)
+        assert bool(done[k].any(1).all())
+    assert bool((A._episode == ep0 + ka.int()).all())
+    assert bool((A._reset_count == 1).all())                         # every tile, with or without a reset
+    sa, sb = _np(A.get_current_state()), _np(B.get_current_state())
+    pa, pb = _np(A.params), _np(B.params)
+    starts = []
+    for w_, cnt in enumerate(counts):
+        la = np.flatnonzero(_np(ka)[64 * w_:64 * w_ + 64]) + 64 * w_   # lanes in rank order
+        lb = np.flatnonzero(_np(kb)[64 * w_:64 * w_ + 64]) + 64 * w_
+        assert np.array_equal(sa[la], sb[lb]) and np.array_equal(pa[la], pb[lb])   # slot = rank, not lane
+        starts.append(sa[la])
+    allst = np.concatenate(starts)
+    assert len(np.unique(allst[:, 15:18].round(12), axis=0)) >= 0.75 * len(allst)   # (20 % start at rest: W = 0)
+    nz = np.abs(allst[:, 0:3]).max(1) > 0
+    assert len(np.unique(allst[nz, 0:3], axis=0)) == nz.sum()        # distinct slots / tiles: distinct starts
+    # envs that did not reset are untouched by the pool
+    keep = ~_np(ka | kb)
+    assert np.array_equal(sa[keep], sb[keep])
+    # next step, same lanes: the counter moved on, so the same slots hold new starts
+    _kill(A, ka)
+    A.step(zero)
+    assert bool((A._reset_count == 2).all())
+    s2 = _np(A.get_current_state())
+    la = np.flatnonzero(_np(ka))
+    assert not np.array_equal(s2[la][:, 15:18], sa[la][:, 15:18])
+    # a 64-aligned shard reproduces its part of the global batch
+    lo, hi = 64 * 5, 64 * 15
+    C = make(offset=lo, n_=hi - lo)
+    assert np.array_equal(_np(C.get_current_state()), _np(make().get_current_state())[lo:hi])
+    _kill(C, ka[lo:hi].clone())
+    C.step(zero[lo:hi].contiguous())
+    assert np.array_equal(_np(C.get_current_state()), sa[lo:hi])
+    assert np.array_equal(_np(C.params), pa[lo:hi])
+
+
+def test_in_launch_reset_pool_distribution():
+    """Starts drawn from the pools follow quad.py:338-404 like qr_reset's: all 64 lanes of 2000 tiles
+    re-sampled in one step (six pools per tile)."""
+    n = 64 * 2000
+    env = _env("coupled", n, seed=5, auto_reset=True, obs_rows=True)
+    env.reset("train")
+    env.get_norm_error_state()
+    _kill(env, torch.ones(n, dtype=torch.bool, device="cuda"))
+    _, _, done, _, _ = env.step(torch.zeros(n, 4, device="cuda"))
+    assert bool(done.all())
+    s, p = _np(env.get_current_state()), _np(env.params)
+    rel = p / orc.NOMINAL_PARAMS - 1.0
+    width = np.array([0.1, 0.1, 0.1, 0.1, 0.1, 0.05])
+    assert (np.abs(rel) <= width * (1 + 1e-6)).all()
+    assert np.allclose(rel.mean(0), 0, atol=3e-3) and np.allclose(rel.std(0), width / np.sqrt(3), rtol=0.03)
+    zero = np.abs(s[:, 0:6]).max(1) == 0
+    assert abs(zero.mean() - 0.2) < 0.01
+    nz = ~zero
+    assert np.abs(s[nz, 0:3]).max() <= 0.6 and np.abs(s[nz, 3:6]).max() <= 2.0 and np.abs(s[nz, 15:18]).max() <= np.pi + 1e-6
+    assert np.abs(s[nz, 0:3]).max() > 0.59 and np.abs(s[nz, 15:18]).max() > 3.1
+    for col in (0, 4, 16):                                            # uniform: mean 0, variance range^2 / 3
+        rng_ = {0: 0.6, 4: 2.0, 16: np.pi}[col]
+        assert abs(s[nz, col].mean()) < 0.02 * rng_ and abs(s[nz, col].std() - rng_ / np.sqrt(3)) < 0.02 * rng_
+    R = np.swapaxes(s[:, 6:15].reshape(n, 3, 3), 1, 2)
+    assert np.abs(np.swapaxes(R, 1, 2) @ R - np.eye(3)).max() < 1e-13
+    roll = np.arctan2(R[:, 2, 1], R[:, 2, 2]); pitch = -np.arcsin(R[:, 2, 0]); yaw = np.arctan2(R[:, 1, 0], R[:, 0, 0])
+    lim = np.deg2rad(50.0)
+    assert np.abs(roll).max() <= lim + 1e-6 and np.abs(pitch).max() <= lim + 1e-6 and np.abs(roll[zero]).max() < 1e-7
+    assert abs(yaw.mean()) < 0.03 and abs(yaw.std() - np.pi / np.sqrt(3)) < 0.03
+    # lanes of one tile are independent of each other (slots of six different pools)
+    c = np.corrcoef(np.stack([s[nz, 0][:-1], s[nz, 0][1:], s[nz, 16][:-1], s[nz, 16][1:]]))
+    assert np.abs(c - np.eye(4)).max() < 0.02
+    assert np.abs(_np(env.integ)[:, [0, 1, 2, 6]]).max() < 0.05         # integrators restarted (advanced once by the first obs)
 
 
 @pytest.mark.parametrize("kind", KINDS)

@@ -53,7 +53,11 @@ def test_shard_range_properties():
         assert rs[0][0] == 0 and rs[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
         sizes = [e - s for s, e in rs]
-        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+        if n >= 64 * w:   # tile-aligned shards: every boundary a multiple of 64 envs (one wavefront), tiles dealt evenly
+            assert all(s % 64 == 0 for s, _ in rs) and max(sizes) - min(sizes) <= 64 + 63
+            assert sizes[:-1] == sorted(sizes[:-1], reverse=True)
+        else:
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
 
     prop()
     with pytest.raises(ValueError):
@@ -98,6 +102,10 @@ def test_abi_argument_errors_without_gpu():
     lib = L.load()
     e, o = L.QrEnv(), L.QrStepOut()
     assert lib.qr_step(None, None, 1, None, None) == -1
+    z = L.QrEnv()
+    z.num_envs, z.pos_vel, z.att_rate = 4, 0x1000, 0x2000
+    assert lib.qr_reset(C.byref(z), None, None) == -3                         # zero QrCoeffs: qr_default_coeffs not called
+    lib.qr_default_coeffs(C.byref(e.coeffs))
     e.kind = 7
     assert lib.qr_step(C.byref(e), None, 1, C.byref(o), None) == -2
     e.kind, e.layout = 0, 5
@@ -120,9 +128,10 @@ def test_abi_argument_errors_without_gpu():
     assert lib.qr_error_obs(C.byref(e), None, None, None) == -1
     e.kind = 0
     assert lib.qr_error_obs(C.byref(e), 0x6000, None, None) == -2            # undefined for Quad-v0
-    assert lib.qr_get_state(C.byref(e), None, None) == -1 and lib.qr_set_state(C.byref(e), None, None, None) == -1
+    assert lib.qr_get_state(C.byref(e), None, None) == -1 and lib.qr_set_state(C.byref(e), None, None, None, None) == -1
     # empty batch: a no-op that succeeds; oversize batch (32-bit buffer offsets): refused
     e2, o2 = L.QrEnv(), L.QrStepOut()
+    lib.qr_default_coeffs(C.byref(e2.coeffs))
     e2.kind, e2.num_envs, e2.pos_vel, e2.att_rate = 0, 0, 0x1000, 0x2000
     o2.reward, o2.done = 0x4000, 0x5000
     assert lib.qr_step(C.byref(e2), 0x3000, 1, C.byref(o2), None) == 0
@@ -134,6 +143,7 @@ def test_abi_argument_errors_without_gpu():
     assert lib.qr_step(C.byref(e2), 0x3000, 1, C.byref(o2), None) == -1      # fused goals without traj buffer
     # qr_rollout_actor: argument checks before any launch
     e3, o3, pol = L.QrEnv(), L.QrStepOut(), L.QrPolicyRollout()
+    lib.qr_default_coeffs(C.byref(e3.coeffs))
     e3.kind, e3.num_envs, e3.pos_vel, e3.att_rate, e3.integ = 0, 64, 0x1000, 0x2000, 0x7000
     o3.reward, o3.done, o3.obs0, o3.obs1 = 0x4000, 0x5000, 0x8000, 0x9000
     assert lib.qr_rollout_actor(C.byref(e3), None, 1, 1, C.byref(o3), None) == -1
@@ -162,6 +172,14 @@ def test_abi_argument_errors_without_gpu():
     co = L.default_coeffs()
     assert (co.Cx, co.CIx, co.Cv, co.Cb1, co.CIb1, co.CW, co.Cw12, co.CW3) == (6.0, 0.1, 0.4, 6.0, 0.1, 0.6, 0.6, 0.1)
     assert (co.alpha, co.beta, co.dt, co.W_lim) == (0.01, 0.05, 1 / 200, 2 * np.pi)
+    assert (co.m_nominal, co.d_nominal, co.J1_nominal, co.J3_nominal, co.c_tf_nominal, co.c_tw_nominal, co.g, co.min_force) == \
+           (2.15, 0.23, 0.022, 0.035, 0.0135, 2.2, 9.81, 0.5)                # quad.py:28-36
+    # in-launch resets need the per-tile stream counters
+    e4, o4 = L.QrEnv(), L.QrStepOut()
+    lib.qr_default_coeffs(C.byref(e4.coeffs))
+    e4.kind, e4.num_envs, e4.pos_vel, e4.att_rate, e4.episode, e4.flags = 0, 64, 0x1000, 0x2000, 0x3000, L.FLAG_AUTO_RESET
+    o4.reward, o4.done = 0x4000, 0x5000
+    assert lib.qr_step(C.byref(e4), 0x6000, 1, C.byref(o4), None) == -1      # reset_count missing
 
 
 def test_no_cpu_fallback():

@@ -20,7 +20,7 @@ dev = torch.device("cuda", 0)
 K, R = 100, 8
 out = {}
 for n in [int(x) for x in os.environ.get('QR_AB_SIZES', '65536,1048576').split(',')]:
-    for kind in ("quad", "coupled", "decoupled"):
+    for kind in os.environ.get('QR_AB_KINDS', 'quad,coupled,decoupled').split(','):
         for ar in (1, 0):
             env = QuadVecEnv(kind, n, device=dev, auto_reset=bool(ar), obs_rows=(kind != "quad"))
             env.reset("train")
@@ -47,7 +47,7 @@ print(json.dumps(out))
 
 libs = [os.path.abspath(p) for p in sys.argv[1:]]
 res = {p: [] for p in libs}
-for rep in range(2):
+for rep in range(int(os.environ.get("QR_AB_REPS", "2"))):
     for p in libs:
         r = subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, QR_LIB=p), capture_output=True, text=True)
         if r.returncode:
@@ -58,3 +58,5 @@ keys = list(res[libs[0]][0]) if res[libs[0]] else []
 print("%-28s" % "us/launch" + "".join("%26s" % os.path.basename(p)[-24:] for p in libs))
 for k in keys:
     print("%-28s" % k + "".join("%26s" % " / ".join("%.2f" % r[k] for r in res[p]) for p in libs))
+if os.environ.get("QR_AB_JSON"):
+    json.dump({os.path.basename(p): res[p] for p in libs}, open(os.environ["QR_AB_JSON"], "w"), indent=1)
