@@ -62,8 +62,6 @@ __device__ __forceinline__ void sincos_small(float x, float& sn, float& cs) {
   cs = ((q + 1) & 2) ? -c0 : c0;
 }
 
-// sin/cos of a random angle re-normalised in f64, so every factor, hence q, has unit norm to
-// f64 round-off.
 // atan2 for float arguments, ~1.5e-7 rad: octant reduction (cephes atanf: [0, tan(pi/8)] by
 // (a - 1)/(a + 1)), quotients by v_rcp_f32 + one Newton step, degree-4 polynomial in a^2.
 // Branch-free and ~30 instructions (the OCML atan2f carries an IEEE float division and special-case
@@ -86,57 +84,69 @@ __device__ __forceinline__ float atan2_fast(float y, float x) {
   return copysignf(p, y);
 }
 
-__device__ __forceinline__ void unit_sincos(float ang, double& s, double& c) {
-  float sf, cf;
-  sincos_small(ang, sf, cf);
-  s = (double)sf; c = (double)cf;
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {  // r = 1/sqrt(n2) to first order around 1: 1e-6 -> 1e-12 -> 1e-24
-    const double r = 1.5 - 0.5 * (s * s + c * c);
-    s *= r; c *= r;
+// Unit quaternion of R = Rz(yaw) Ry(pitch) Rx(roll) (scipy 'xyz' extrinsic, quad.py:199)  <=>
+// q = qz(yaw) qy(pitch) qx(roll), for |roll|, |pitch| <= 50 deg + margin and |yaw| <= pi.  The six
+// half-angle sines / cosines and the products are float32 (the angles are random draws); the result
+// is normalised in float64 (two first-order steps: 1e-7 -> 1e-14 -> 1e-28), so q has unit norm to
+// float64 round-off.  Half roll / pitch are below 0.45 rad: plain Taylor polynomials, no reduction.
+template <typename T>
+__device__ __forceinline__ void sample_attitude(float yaw, float roll, float pitch, T (&q)[4]) {
+  float sr, cr, sp, cp, sy, cy;
+  {
+    const float x = 0.5f * roll, x2 = x * x;
+    sr = x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 2.7557319e-6f, -1.9841270e-4f), 8.3333333e-3f), -1.6666667e-1f), 1.0f);
+    cr = fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 2.4801587e-5f, -1.3888889e-3f), 4.1666667e-2f), -0.5f), 1.0f);
   }
+  {
+    const float x = 0.5f * pitch, x2 = x * x;
+    sp = x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 2.7557319e-6f, -1.9841270e-4f), 8.3333333e-3f), -1.6666667e-1f), 1.0f);
+    cp = fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 2.4801587e-5f, -1.3888889e-3f), 4.1666667e-2f), -0.5f), 1.0f);
+  }
+  sincos_small(0.5f * yaw, sy, cy);
+  const float crcp = cr * cp, srsp = sr * sp, srcp = sr * cp, crsp = cr * sp;
+  double qd[4] = {(double)fmaf(crcp, cy, srsp * sy), (double)fmaf(srcp, cy, -crsp * sy), (double)fmaf(crsp, cy, srcp * sy),
+                  (double)fmaf(crcp, sy, -srsp * cy)};
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const double r = fma(-0.5, fma(qd[0], qd[0], fma(qd[1], qd[1], fma(qd[2], qd[2], qd[3] * qd[3]))), 1.5);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qd[j] *= r;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) q[j] = T(qd[j]);
 }
 
-// QuadEnv.reset + sample_init_error + set_random_parameters (quad.py:171-222, 338-404).
-// Draw order: 0..5 m,d,J1,J3,c_tf,c_tw; 6 yaw; 7 zero-error branch; 8..10 x; 11..13 v;
-// 14..16 W; 17,18 roll,pitch.  R = Rz(yaw) Ry(pitch) Rx(roll) (scipy 'xyz' extrinsic,
-// quad.py:199)  <=>  q = qz(yaw) qy(pitch) qx(roll).  Every sampled value is a float32 number
-// (W is returned as such); q has unit norm to float64 round-off.
+// QuadEnv.reset + sample_init_error + set_random_parameters (quad.py:171-222, 338-404) from the 20
+// draws of one env.  Draw order: 0..5 m,d,J1,J3,c_tf,c_tw; 6,7 x0,x1; 8 x2; 9..11 v; 12..14 W;
+// 15 zero-error branch; 16 yaw; 17 roll; 18 pitch; 19 goal-generator draws.
+// Every sampled value is a float32 number (W is returned as such).
 template <typename T, typename X>
 __device__ __forceinline__ void sample_start(const Draws& d, bool randomise, bool eval, const Coeffs& c, X (&x)[3], X (&v)[3],
                                              T (&q)[4], float (&Wf)[3], float (&prm)[6]) {
   if (randomise) {  // float32 values: that is how the params buffer stores them
     const float p = c.udm;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) prm[j] = c.nom_f[j] * fmaf(p, d.sym(j), 1.0f);
-    prm[5] = c.nom_f[5] * fmaf(0.5f * p, d.sym(5), 1.0f);
+    for (int j = 0; j < 5; ++j) prm[j] = fmaf(c.nom_f[j] * p, d.sym(j), c.nom_f[j]);
+    prm[5] = fmaf(c.nom_f[5] * (0.5f * p), d.sym(5), c.nom_f[5]);
   } else {
 #pragma unroll
     for (int j = 0; j < 6; ++j) prm[j] = c.nom_f[j];
   }
-  const float yaw = (float)kPi * d.sym(6);
   float ix, iv, iR, iW;
   if (eval) {  // quad.py:352-356
     ix = 0.4f; iv = 0.0f; iR = 0.0f; iW = 0.0f;
-  } else if (d.u01(7) < 0.2f) {  // quad.py:342-346
+  } else if (d.u01(15) < 0.2f) {  // quad.py:342-346
     ix = 0.0f; iv = 0.0f; iR = 0.0f; iW = 0.0f;
   } else {  // quad.py:348-351
     ix = 0.6f; iv = c.reset_v; iR = (float)(50.0 * kPi / 180.0); iW = c.reset_W;
   }
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    x[j] = X(ix * d.sym(8 + j));
-    v[j] = X(iv * d.sym(11 + j));
-    Wf[j] = iW * d.sym(14 + j);
+    x[j] = X(ix * d.sym(6 + j));
+    v[j] = X(iv * d.sym(9 + j));
+    Wf[j] = iW * d.sym(12 + j);
   }
-  double sr, cr, sp, cp, sy, cy;
-  unit_sincos(0.5f * iR * d.sym(17), sr, cr);
-  unit_sincos(0.5f * iR * d.sym(18), sp, cp);
-  unit_sincos(0.5f * yaw, sy, cy);
-  q[0] = T(cr * cp * cy + sr * sp * sy);
-  q[1] = T(sr * cp * cy - cr * sp * sy);
-  q[2] = T(cr * sp * cy + sr * cp * sy);
-  q[3] = T(cr * cp * sy - sr * sp * cy);
+  sample_attitude<T>((float)kPi * d.sym(16), iR * d.sym(17), iR * d.sym(18), q);
 }
 
 template <typename T, typename X>
@@ -151,52 +161,66 @@ __device__ __forceinline__ void sample_reset(Work<T, X>& w, const Draws& d, bool
 // ------------------------------------------------------------------------------------
 // In-launch auto-reset: a POOL of freshly sampled episode starts per wavefront.
 //
-// Only ~1 % of the envs reset in a given step, but ~50 % of the waves contain one and a launch
-// ends with its slowest wave, so the reset's instructions sit on the critical path of the whole
-// launch.  Nothing about WHICH lane resets is known before the step has been integrated — but
-// what a resetting lane needs (Philox draws + the sampling arithmetic) does not depend on the
-// lane at all if the stream is keyed by the wave instead of by the env:
-//     draws(slot s) = Philox4x32-10(key = seed; ctr = (global id of the wave's first env [64 bit],
-//                                   reset counter of this wave's tile, 0x40000000 | s << 8 | block))
-// One cooperative Philox pass (lane 5k+b computes block b of slot k; 12 slots) plus the sampling
-// of the 12 starts (lane 5k) is therefore issued right after the wave's state loads and runs
-// while they are in flight, when the SIMD has nothing else to do.  A lane that resets takes the
-// slot given by its rank among the wave's resetting lanes (ds_bpermute from lane 5 * rank);
-// ranks >= 12 (e.g. a time limit ending all 64 episodes at once) draw further pools on demand
-// (slots 12 p + k).  The tile's counter advances by one per env-step, so no (tile, counter, slot)
-// is ever used twice — also under hipGraph replay, because the counter lives in device memory.
-// Results are independent of how the batch is sharded as long as shards start at multiples of 64.
+// Only ~1 % of the envs reset in a given step, but more than half of the waves contain one and a
+// launch ends with its slowest wave, so the reset's instructions sit on the critical path of the
+// whole launch (measured with in-kernel clock stamps, tools/stamp_timeline.py).  Nothing about WHICH
+// lane resets is known before the step has been integrated — but what a resetting lane needs
+// (Philox draws + the sampling arithmetic) does not depend on the lane at all if the stream is
+// keyed by the wave instead of by the env:
+//     block b of slot s = Philox4x32-10(key = seed; ctr = (global id of the wave's first env [64 bit],
+//                                       reset counter of this wave's tile, 0x40000000 | s << 8 | b))
+// The wave samples 12 slots cooperatively — the five lanes 5s .. 5s+4 of slot s each take one
+// Philox block (4 words) AND turn it into its share of the episode start:
+//     b = 0: m, d, J1, J3      b = 1: c_tf, c_tw, x0, x1      b = 2: x2, v0, v1, v2
+//     b = 3: W0, W1, W2, zero-error branch      b = 4: yaw, roll, pitch -> unit quaternion; word 3 = goal-generator draws
+// so one pass is ~95 instructions of Philox + ~110 of sampling for up to 12 resets, issued right
+// after the wave's loads and run while they are in flight, when the SIMD has nothing else to do
+// (the per-lane scale / offset table of the roles is formed even before the tile counter has
+// arrived).  A lane that resets takes the slot given by its rank among the wave's resetting lanes
+// (ds_bpermute from lanes 5 * rank + b); ranks >= 12 (e.g. a time limit ending all 64 episodes at
+// once) draw further pools on demand (slots 12 p + s).  The tile's counter advances by one per
+// env-step, so no (tile, counter, slot) is ever used twice — also under hipGraph replay, because
+// the counter lives in device memory.  Results are independent of how the batch is sharded as
+// long as shards start at multiples of 64 envs.
 // ------------------------------------------------------------------------------------
-template <typename T, typename X>
-struct ResetPool {  // meaningful in lanes 5k, k = 0..11
-  X x[3], v[3];
-  T q[4];
-  float W[3];
-  float prm[6];
-  uint32_t r19;  // the word the goal generator's episode-start draws are taken from
+struct PoolRole {  // per-lane constants of the lane's role: value_j = off_j + (zero-error ? scl_z_j : scl_j) * sym(word_j)
+  float off[4], scl[4], scl_z[4];
 };
 
-template <typename T, typename X>
-__device__ __forceinline__ void make_pool(ResetPool<T, X>& p, uint64_t seed, uint64_t gfirst, uint32_t count, int pass, bool randomise,
-                                          bool eval, const Coeffs& c) {
+// The role table is formed on the host (fill_pool_roles) and lives in the kernarg segment; a lane reads the
+// 12 constants of its role with three 16-byte loads, issued with the wave's first loads.
+__device__ __forceinline__ void pool_role(PoolRole& r, const float (*tab)[12]) {
+  const int lane = (int)__lane_id();
+  const int b = lane - 5 * (lane / 5);
+  float4 o, s, z;  // (the table is only 4-byte aligned in the kernarg segment: copies, not float4 dereferences)
+  __builtin_memcpy(&o, &tab[b][0], 16); __builtin_memcpy(&s, &tab[b][4], 16); __builtin_memcpy(&z, &tab[b][8], 16);
+  r.off[0] = o.x; r.off[1] = o.y; r.off[2] = o.z; r.off[3] = o.w;
+  r.scl[0] = s.x; r.scl[1] = s.y; r.scl[2] = s.z; r.scl[3] = s.w;
+  r.scl_z[0] = z.x; r.scl_z[1] = z.y; r.scl_z[2] = z.z; r.scl_z[3] = z.w;
+}
+
+template <typename T>
+struct ResetPool {  // this lane's share of its slot
+  float v[4];       // the four sampled values of the lane's role (role 4, word 3: the raw draw, as bits)
+  T q[4];           // role 4: the unit quaternion
+};
+
+template <typename T>
+__device__ __forceinline__ void make_pool(ResetPool<T>& p, const PoolRole& role, uint64_t seed, uint64_t gfirst, uint32_t count, int pass) {
   const int lane = (int)__lane_id();
   const int k = lane / 5, b = lane - 5 * k;  // slot / block of this lane (k = 12: lanes 60..63 idle)
   uint32_t ctr[4] = {(uint32_t)gfirst, (uint32_t)(gfirst >> 32), count, 0x40000000u | ((uint32_t)(12 * pass + k) << 8) | (uint32_t)b};
   philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
-  // lane 5k gathers blocks 1..4 of its slot from lanes 5k+1 .. 5k+4 (all reads issued, one wait)
-  Draws d;
-  int got[16];
+  // zero-error branch of the slot (quad.py:342-346): word 3 of role 3, broadcast to the slot's lanes
+  const float u = fmaf((float)(ctr[3] >> 8), 0x1p-24f, 0x1p-25f);
+  const bool zero = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((5 * k + 3) << 2, __builtin_bit_cast(int, u))) < 0.2f;
 #pragma unroll
-  for (int bb = 1; bb < 5; ++bb) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) got[4 * (bb - 1) + j] = __builtin_amdgcn_ds_bpermute((lane + bb) << 2, (int)ctr[j]);
+  for (int j = 0; j < 4; ++j) {
+    const float sym = fmaf((float)(ctr[j] >> 8), 0x1p-23f, 0x1p-24f - 1.0f);
+    p.v[j] = fmaf(zero ? role.scl_z[j] : role.scl[j], sym, role.off[j]);
   }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) d.r[j] = ctr[j];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) d.r[4 + j] = (uint32_t)got[j];
-  sample_start<T, X>(d, randomise, eval, c, p.x, p.v, p.q, p.W, p.prm);
-  p.r19 = d.r[19];
+  sample_attitude<T>(p.v[0], p.v[1], p.v[2], p.q);  // meaningful in role 4 (yaw, roll, pitch)
+  if (b == 4) p.v[3] = __builtin_bit_cast(float, ctr[3]);
 }
 
 __device__ __forceinline__ float bperm(int addr4, float v) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr4, __builtin_bit_cast(int, v))); }
@@ -209,26 +233,29 @@ __device__ __forceinline__ double bperm(int addr4, double v) {
 
 // Lanes with take == true copy slot `slot` of the pool into their working set.  Executed by the whole wave.
 template <typename T, typename X, bool TRAJ>
-__device__ __forceinline__ void take_from_pool(const ResetPool<T, X>& p, bool take, int slot, Work<T, X>& w, uint32_t& r19) {
-  const int addr = (take ? 5 * slot : 0) << 2;
-  X x[3], v[3]; T q[4]; float W[3], prm[6];
+__device__ __forceinline__ void take_from_pool(const ResetPool<T>& p, bool take, int slot, Work<T, X>& w, uint32_t& r19) {
+  const int a0 = (take ? 5 * slot : 0) << 2, a1 = a0 + 4, a2 = a0 + 8, a3 = a0 + 12, a4 = a0 + 16;
+  float prm[6], x[3], v[3], W[3];
+  T q[4];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) { x[j] = bperm(addr, p.x[j]); v[j] = bperm(addr, p.v[j]); W[j] = bperm(addr, p.W[j]); }
+  for (int j = 0; j < 4; ++j) prm[j] = bperm(a0, p.v[j]);
+  prm[4] = bperm(a1, p.v[0]); prm[5] = bperm(a1, p.v[1]);
+  x[0] = bperm(a1, p.v[2]); x[1] = bperm(a1, p.v[3]); x[2] = bperm(a2, p.v[0]);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) q[j] = bperm(addr, p.q[j]);
+  for (int j = 0; j < 3; ++j) { v[j] = bperm(a2, p.v[1 + j]); W[j] = bperm(a3, p.v[j]); }
 #pragma unroll
-  for (int j = 0; j < 6; ++j) prm[j] = bperm(addr, p.prm[j]);
-  uint32_t r = 0;
-  if constexpr (TRAJ) r = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)p.r19);
+  for (int j = 0; j < 4; ++j) q[j] = bperm(a4, p.q[j]);
+  float rb = 0.0f;
+  if constexpr (TRAJ) rb = bperm(a4, p.v[3]);
   __builtin_amdgcn_sched_barrier(0);  // all cross-lane reads are in flight before the first select waits for one
   if (take) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { w.x[j] = x[j]; w.v[j] = v[j]; w.W[j] = T(W[j]); }
+    for (int j = 0; j < 3; ++j) { w.x[j] = X(x[j]); w.v[j] = X(v[j]); w.W[j] = T(W[j]); }
 #pragma unroll
     for (int j = 0; j < 4; ++j) w.q[j] = q[j];
 #pragma unroll
     for (int j = 0; j < 6; ++j) w.prm[j] = prm[j];
-    if constexpr (TRAJ) r19 = r;
+    if constexpr (TRAJ) r19 = __builtin_bit_cast(uint32_t, rb);
   }
 }
 

@@ -57,8 +57,8 @@
 
 namespace qr {
 
-// byte offset of the Args block in the step kernel's kernarg segment: 5 pointers + 2 x int64 precede it
-constexpr int kArgsOffset = 5 * 8 + 2 * 8;
+// byte offset of the Args block in the step kernel's kernarg segment: 6 pointers + 2 x int32 precede it
+constexpr int kArgsOffset = 6 * 8 + 2 * 4;
 static_assert(alignof(Args) == 8, "Args follows the leading scalar arguments without padding");
 
 // QR_STAMPS: diagnostic build (tools/stamp_timeline.py).  Every wave records the 100 MHz real-time clock at
@@ -89,14 +89,18 @@ __device__ unsigned long long* g_stamps = nullptr;
 // POLICY != 0 = qr_rollout_actor: the action of every step comes from the actor(s) evaluated on the
 // env's current observation, which stays in registers from one step to the next.  1: PPO / TD3 actors
 // (parameter log_std, tanh-of-mean rule); 2: any reference MLP actor (adds SAC's log_std head and rule).
-template <int KIND, typename XV, typename QW, int B, bool TRAJ, bool ADAPT, int POLICY = 0>
+// SINGLE = exactly one env-step per launch (qr_step): no loop over steps, so nothing is hoisted out of it and kept
+// live across the whole kernel (fewer SGPRs to spill, a shorter prologue).
+template <int KIND, typename XV, typename QW, int B, bool TRAJ, bool ADAPT, int POLICY = 0, bool SINGLE = false>
 __global__ __launch_bounds__(B, ((TRAJ || POLICY) ? 1 : QR_WAVES_PER_SIMD))
-void step_kernel(void* pos_vel, void* att_rate, const float* action, float* params, float* integ, int64_t n_envs,
-                 int64_t ld_envs, const Args a_in) {
-  // The leading scalar arguments duplicate the fields of Args the first loads depend on: as
+void step_kernel(void* pos_vel, void* att_rate, const float* action, float* params, float* integ, int32_t* reset_count,
+                 int32_t n_envs, int32_t ld_envs, const Args a_in) {
+  // The leading scalar arguments duplicate the fields of Args that the wave's loads depend on: as
   // plain kernel arguments they are preloaded into SGPRs by the dispatcher (gfx950 kernarg
-  // preload, -mllvm -amdgpu-kernarg-preload-count), so the state loads are issued without first
-  // waiting for a scalar-load round trip to the kernarg segment.
+  // preload, -mllvm -amdgpu-kernarg-preload-count=16: 14 dwords is what the hardware hands over), so
+  // every load of the working set — and the scalar load of the tile's reset counter — is issued in
+  // the wave's first instructions, without waiting for a scalar-load round trip to the kernarg
+  // segment (host-visible memory: ~0.7 us, measured with in-kernel clock stamps).
   // Everything else is read from the kernarg segment WHERE IT IS USED: referenced as a by-value
   // struct, every used field of Args would be loaded in the kernel's entry block (that is how the
   // AMDGPU backend lowers kernel arguments) and stay live in SGPRs from there on — far more than the
@@ -109,10 +113,10 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 #else
   const Args& ka = a_in;  // (host pass of the single-source compile: never executed)
 #endif
-  Args a;  // the fields the hot path touches, assembled from the preloaded scalars
+  Args a;  // the fields the helpers touch, assembled from the preloaded scalars
   a.pos_vel = pos_vel; a.att_rate = att_rate; a.action = action; a.params = params; a.integ = integ;
+  a.reset_count = reset_count;
   a.n = n_envs; a.ld = ld_envs;
-  a.goal = ka.goal; a.traj = ka.traj; a.steps = ka.steps; a.reset_count = ka.reset_count;
   using T = QW;  // q, W are held and accumulated in their storage type
   using X = XV;  // and so are x, v
   using KT = KindTraits<KIND>;
@@ -121,89 +125,102 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   const int tid = threadIdx.x;
   const unsigned lane = threadIdx.x;
   const unsigned ufirst = blockIdx.x * (unsigned)B;
-  const int64_t first = (int64_t)blockIdx.x * B;
+  const int64_t first = (int64_t)ufirst;
   const int64_t i = first + tid;
   const int64_t N = a.n, L = a.ld;
-  const int rows = (int)((N - first) < B ? (N - first) : B);
+  const int rows = min(n_envs - (int)ufirst, B);   // (n_envs < 2^31: checked on the host)
   const bool active = tid < rows;
+  // lanes past a ragged tail read the tail's last env (valid memory, finite numbers) and store nothing
+  const unsigned ll = min(lane, (unsigned)(rows - 1));
   const Coeffs& c = ka.c;
 #if QR_ABLATE == 1  // measurement build: launch floor only
   return;
 #endif
-
   QR_STAMP(0, tid);
-  Work<T, X> w;
-  // ---- load the env's working set (SoA, lane-contiguous) ----
-  idle_work(w, c);
-  if (active) {
-    load_state<XV, QW>(a, first, lane, w);
-    if (a.params) {
-      const SoA<float> prm(a.params, 6, L);
-#pragma unroll
-      for (int f = 0; f < 6; ++f) w.prm[f] = prm.load(f, ufirst, lane);
-      w.nominal = false;
-    }
-    if (!TRAJ && a.goal) {  // (with the fused generator the goal is formed in registers every step)
-      const SoA<float> goal(a.goal, 12, L);
-#pragma unroll
-      for (int f = 0; f < 12; ++f) w.goal[f] = goal.load(f, ufirst, lane);
-    }
-    if (KIND != QR_KIND_QUAD) {
-      const SoA<float> integ(a.integ, 8, L);
-#pragma unroll
-      for (int f = 0; f < 8; ++f) w.integ[f] = integ.load(f, ufirst, lane);
-    }
-  }
-  Traj tr;
-  const int goal_mode = TRAJ ? ka.goal_mode : QR_GOAL_EXTERNAL;  // wave-uniform
-  if (TRAJ && active) {
-    const SoA<float> traj(a.traj, 8, L);
-#pragma unroll
-    for (int f = 0; f < 7; ++f) tr.set(f, traj.load(f, ufirst, lane));
-  }
-  int32_t steps = (a.steps && active) ? (a.steps + first)[lane] : 0;
-  bool params_dirty = false;
-  bool traj_dirty = false;  // this lane started a new episode: its generator state changed
 
+  // ---- issue the loads of the env's working set (SoA, lane-contiguous) and of its action row ----
+  Work<T, X> w;
+  float act_next[A];
+#pragma unroll
+  for (int j = 0; j < A; ++j) act_next[j] = 0.f;
   // Action rows [N][A] -> lane registers.  A = 4: one 16-byte load per lane.  A = 5: five dword
   // loads per lane (a wave covers 1280 contiguous bytes; L1 merges the sectors).  In a rollout
   // the row of step t+1 is requested before the arithmetic of step t, so its latency is hidden.
-  float act_next[A];
   auto load_action = [&](int t, float (&dst)[A]) {
     const float* abase = a.action + ((int64_t)t * N + first) * A;
     if constexpr (A == 4) {
-      const float4 v = reinterpret_cast<const float4*>(abase)[lane];
+      const float4 v = reinterpret_cast<const float4*>(abase)[ll];
       dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
     } else {
 #pragma unroll
-      for (int j = 0; j < A; ++j) dst[j] = abase[lane * A + j];
+      for (int j = 0; j < A; ++j) dst[j] = abase[ll * A + j];
     }
   };
+  // (first in the wave's load queue, so that waiting for them does not wait for the working set: vmcnt is in order)
+  const bool auto_reset = reset_count != nullptr;  // passed only with QR_FLAG_AUTO_RESET: its presence IS the flag, known without a load
+  PoolRole role;
+  if (auto_reset) pool_role(role, c.role_tab);
+  load_state<XV, QW>(a, first, ll, w);
+  w.nominal = a.params == nullptr;
+  if (a.params) {
+    const SoA<float> prm(a.params, 6, L);
 #pragma unroll
-  for (int j = 0; j < A; ++j) act_next[j] = 0.f;
-  if constexpr (!POLICY) {
-    if (active) load_action(0, act_next);
+    for (int f = 0; f < 6; ++f) w.prm[f] = prm.load(f, ufirst, ll);
+  } else {
+#pragma unroll
+    for (int f = 0; f < 6; ++f) w.prm[f] = 0.0f;
+  }
+  if constexpr (!POLICY) load_action(0, act_next);
+  if constexpr (KIND != QR_KIND_QUAD) {
+    const SoA<float> integ(a.integ, 8, L);
+#pragma unroll
+    for (int f = 0; f < 8; ++f) w.integ[f] = integ.load(f, ufirst, ll);
+  } else {
+#pragma unroll
+    for (int f = 0; f < 8; ++f) w.integ[f] = 0.0f;
+  }
+  // the tile's position in the in-launch reset stream: a scalar load behind the vector loads
+  uint32_t rcount = 0;
+  if (auto_reset) rcount = (uint32_t)reset_count[blockIdx.x];
+  // ---- the rest of the arguments: one batch of scalar loads from the kernarg segment ----
+  const uint32_t flags = ka.flags;
+  const uint64_t seed = ka.seed;
+  const uint64_t gfirst = (uint64_t)(ka.env_offset + first);
+  float* const goal_ptr = ka.goal;
+  int32_t* const steps_ptr = ka.steps;
+  const int n_steps = SINGLE ? 1 : ka.n_steps;
+  const bool eval_reset = (flags & QR_FLAG_EVAL_RESET) != 0;
+  const bool randomise = !eval_reset && !(flags & QR_FLAG_NO_UDM) && a.params != nullptr;
+#pragma unroll
+  for (int f = 0; f < 12; ++f) w.goal[f] = f == 6 ? 1.0f : 0.0f;  // hover default (quad.py:98-101)
+  if (!TRAJ && goal_ptr) {  // (with the fused generator the goal is formed in registers every step)
+    const SoA<float> goal(goal_ptr, 12, L);
+#pragma unroll
+    for (int f = 0; f < 12; ++f) w.goal[f] = goal.load(f, ufirst, ll);
   }
 
   // ---- in-launch reset: this wave's pool of episode starts (qr_rng.h), sampled while the loads are in flight ----
-  const bool auto_reset = (ka.flags & QR_FLAG_AUTO_RESET) != 0;
-  const bool eval_reset = (ka.flags & QR_FLAG_EVAL_RESET) != 0;
-  const bool randomise = !eval_reset && !(ka.flags & QR_FLAG_NO_UDM) && a.params != nullptr;
-  const uint64_t gfirst = (uint64_t)(ka.env_offset + first);
-  uint32_t rcount = 0;
-  ResetPool<T, X> pool;
+  ResetPool<T> pool;
   bool have_pool = false;
-  if (auto_reset) {
-    rcount = (uint32_t)a.reset_count[blockIdx.x];  // wave-uniform: a scalar load
 #if QR_ABLATE != 3
-    if (gridDim.x <= QR_SPEC_GRID) {
-      make_pool<T, X>(pool, ka.seed, gfirst, rcount, 0, randomise, eval_reset, c);
-      have_pool = true;
-    }
-#endif
+  if (auto_reset && gridDim.x <= QR_SPEC_GRID) {
+    make_pool<T>(pool, role, seed, gfirst, rcount, 0);
+    have_pool = true;
   }
+#endif
+  QR_STAMP(1, have_pool ? (float)pool.q[0] + pool.v[0] : 0.0f);
 
-  QR_STAMP(1, have_pool ? (float)pool.q[0] + pool.x[0] + pool.prm[5] : 0.0f);
+  Traj tr;
+  const int goal_mode = TRAJ ? ka.goal_mode : QR_GOAL_EXTERNAL;  // wave-uniform
+  if constexpr (TRAJ) {
+    const SoA<float> traj(ka.traj, 8, L);
+#pragma unroll
+    for (int f = 0; f < 7; ++f) tr.set(f, traj.load(f, ufirst, ll));
+  }
+  int32_t steps = (steps_ptr && active) ? (steps_ptr + first)[lane] : 0;
+  bool params_dirty = false;
+  bool traj_dirty = false;  // this lane started a new episode: its generator state changed
+
   // POLICY: the observation the next action is computed from (rows -> lane registers once, then
   // carried from step to step)
   float po0[D0], po1[D1];
@@ -221,7 +238,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     __syncthreads();
   }
 
-  for (int t = 0; t < ka.n_steps; ++t) {
+  for (int t = 0; t < n_steps; ++t) {
     float act[A];
     if constexpr (POLICY) {
       float pre[A], ls[A], eps[A], logp[A];
@@ -281,7 +298,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     } else {
 #pragma unroll
       for (int j = 0; j < A; ++j) act[j] = act_next[j];
-      if (active && t + 1 < ka.n_steps) load_action(t + 1, act_next);
+      if (t + 1 < n_steps) load_action(t + 1, act_next);
     }
 
 #if QR_ABLATE == 2  // measurement build: memory traffic only (no integration)
@@ -393,7 +410,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     for (int g = 0; g < NAG; ++g) any_done = any_done | dn[g];
 #if QR_ABLATE == 4  // measurement build: the pool is sampled but no env is ever re-sampled
     const bool need_reset = false;
-    if (have_pool) asm volatile("" ::"v"(pool.x[0]), "v"(pool.q[3]), "v"(pool.prm[5]), "v"(pool.W[2]), "v"(pool.v[1]));
+    if (have_pool) asm volatile("" ::"v"(pool.v[0]), "v"(pool.q[3]), "v"(pool.v[3]), "v"(pool.v[2]), "v"(pool.v[1]));
 #else
     const bool need_reset = auto_reset && any_done && active;
 #endif
@@ -426,19 +443,10 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       const int total = __popcll(rmask);
       uint32_t r19 = 0;
       for (int pass = 0; 12 * pass < total; ++pass) {  // one pass unless more than 12 lanes reset at once
-        if (!(have_pool && pass == 0)) make_pool<T, X>(pool, ka.seed, gfirst, rcount + (uint32_t)t, pass, randomise, eval_reset, c);
+        if (!(have_pool && pass == 0)) make_pool<T>(pool, role, seed, gfirst, rcount + (uint32_t)t, pass);
         const int slot = rank - 12 * pass;
 #if QR_ABLATE != 7
         take_from_pool<T, X, TRAJ>(pool, need_reset && slot >= 0 && slot < 12, slot, w, r19);
-#else  // measurement build: the lane's own pool registers, no cross-lane reads
-        if (need_reset && slot >= 0 && slot < 12) {
-#pragma unroll
-          for (int j = 0; j < 3; ++j) { w.x[j] = pool.x[j]; w.v[j] = pool.v[j]; w.W[j] = T(pool.W[j]); }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) w.q[j] = pool.q[j];
-#pragma unroll
-          for (int j = 0; j < 6; ++j) w.prm[j] = pool.prm[j];
-        }
 #endif
       }
       if (need_reset) {
@@ -514,9 +522,9 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 #pragma unroll
       for (int f = 0; f < 8; ++f) integ.store(f, ufirst, lane, w.integ[f]);
     }
-    if (a.steps) (a.steps + first)[lane] = steps;
+    if (steps_ptr) (steps_ptr + first)[lane] = steps;
     if constexpr (TRAJ) {
-      const SoA<float> traj(a.traj, 8, L);
+      const SoA<float> traj(ka.traj, 8, L);
       traj.store(0, ufirst, lane, tr.calls);
       if (traj_dirty) {  // the rest changes only at a reset
 #pragma unroll
@@ -529,7 +537,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       for (int f = 0; f < 6; ++f) prm.store(f, ufirst, lane, w.prm[f]);
     }
   }
-  if (auto_reset && lane == 0) a.reset_count[blockIdx.x] = (int32_t)(rcount + (uint32_t)ka.n_steps);  // never reuse a (tile, counter)
+  if (auto_reset && lane == 0) a.reset_count[blockIdx.x] = (int32_t)(rcount + (uint32_t)n_steps);  // never reuse a (tile, counter)
   QR_STAMP(6, tid);
 }
 
@@ -758,6 +766,26 @@ __global__ __launch_bounds__(64) void gae_kernel(const GaeArgs g) {
 // ------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------
+// Role table of the in-launch reset pool (qr_rng.h): what sample_start does, as (offset, scale, scale in the
+// zero-error branch) per word of the five roles of a slot.
+static void fill_pool_roles(Coeffs& o, bool eval, bool randomise) {
+  const float pi = (float)kPi, deg50 = (float)(50.0 * kPi / 180.0);
+  {
+    const float p = randomise ? o.udm : 0.0f;
+    const float ix = eval ? 0.4f : 0.6f, iv = eval ? 0.0f : o.reset_v, iW = eval ? 0.0f : o.reset_W, iR = eval ? 0.0f : deg50;
+    const float zx = eval ? ix : 0.0f;  // (the zero-error branch exists in 'train' only: quad.py:342-356)
+    const float* n = o.nom_f;
+    const float tab[5][12] = {
+        {n[0], n[1], n[2], n[3], n[0] * p, n[1] * p, n[2] * p, n[3] * p, n[0] * p, n[1] * p, n[2] * p, n[3] * p},   // m, d, J1, J3
+        {n[4], n[5], 0, 0, n[4] * p, n[5] * (0.5f * p), ix, ix, n[4] * p, n[5] * (0.5f * p), zx, zx},               // c_tf, c_tw, x0, x1
+        {0, 0, 0, 0, ix, iv, iv, iv, zx, 0, 0, 0},                                                                  // x2, v0, v1, v2
+        {0, 0, 0, 0, iW, iW, iW, 0, 0, 0, 0, 0},                                                                    // W0, W1, W2, branch
+        {0, 0, 0, 0, pi, iR, iR, 0, pi, 0, 0, 0}};                                                                  // yaw, roll, pitch, raw
+    for (int b = 0; b < 5; ++b)
+      for (int j = 0; j < 12; ++j) o.role_tab[b][j] = tab[b][j];
+  }
+}
+
 static float round_up_to_float(double v) {  // smallest float >= v
   float f = (float)v;
   if ((double)f < v) f = nextafterf(f, INFINITY);
@@ -810,6 +838,8 @@ static int fill_env(Args& a, const QrEnv* e) {
   a.env_offset = e->env_offset; a.seed = e->seed;
   a.max_episode_steps = e->max_episode_steps; a.flags = e->flags;
   fill_coeffs(a.c, e->coeffs);
+  const bool eval = (e->flags & QR_FLAG_EVAL_RESET) != 0;
+  fill_pool_roles(a.c, eval, !eval && !(e->flags & QR_FLAG_NO_UDM) && e->params != nullptr);
   return 0;
 }
 
@@ -830,7 +860,7 @@ static void launch_kind(const Args& a, hipStream_t s) {
   // and w_adapt >= 2.5 W_lim (the default 16 rad/s is) the plain kernel computes the same bits.
   const bool adapt = a.c.inv_w_adapt > 0 &&
                      (!(a.flags & QR_FLAG_AUTO_RESET) || a.c.inv_w_adapt * a.c.W_lim * 2.5 > 1.0);
-#define QR_STEP_ARGS a.pos_vel, a.att_rate, a.action, a.params, a.integ, a.n, a.ld, a
+#define QR_STEP_ARGS a.pos_vel, a.att_rate, a.action, a.params, a.integ, ((a.flags & QR_FLAG_AUTO_RESET) ? a.reset_count : nullptr), (int32_t)a.n, (int32_t)a.ld, a
   if constexpr (KIND != QR_KIND_QUAD) {
     if (a.act_out != nullptr) {  // qr_rollout_actor
       const bool general = a.actor[0].ls_w || a.actor[0].squash != QR_ACTOR_TANH_MEAN ||
@@ -840,6 +870,18 @@ static void launch_kind(const Args& a, hipStream_t s) {
       else if (traj) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true, 1>), grid, dim3(64), 0, s, QR_STEP_ARGS);
       else if (general) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 2>), grid, dim3(64), 0, s, QR_STEP_ARGS);
       else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 1>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+      return;
+    }
+  }
+  // qr_step in the default layout: the instantiation without the loop over env-steps
+  constexpr bool kHasSingle = std::is_same<XV, float>::value && std::is_same<QW, double>::value;
+  if constexpr (kHasSingle) {
+    if (a.n_steps == 1) {
+      if (a.goal_mode != QR_GOAL_EXTERNAL) {
+        if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+        else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, false, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+      } else if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+      else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
       return;
     }
   }
