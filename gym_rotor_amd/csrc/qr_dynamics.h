@@ -12,14 +12,27 @@ namespace qr {
 // ------------------------------------------------------------------------------------
 // Attitude helpers
 // ------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T fmaT(T a, T b, T c) {
+  if constexpr (std::is_same<T, double>::value) return fma(a, b, c); else return fmaf(a, b, c);
+}
+template <typename T> __device__ __forceinline__ T fma_ss(T a, T b, T c, T d) {  // a b + c d
+  if constexpr (std::is_same<T, double>::value) return fma(a, b, c * d); else return fmaf(a, b, c * d);
+}
+template <typename T> __device__ __forceinline__ T fma_sd(T a, T b, T c, T d) {  // a b - c d
+  if constexpr (std::is_same<T, double>::value) return fma(a, b, -(c * d)); else return fmaf(a, b, -(c * d));
+}
+template <typename T> __device__ __forceinline__ T fma_1m2(T s) {  // 1 - 2 s
+  if constexpr (std::is_same<T, double>::value) return fma(-2.0, s, 1.0); else return fmaf(-2.0f, s, 1.0f);
+}
 // R(q), column-major like the reference's vec_F(R): R[3c + r].
 template <typename T>
 __device__ __forceinline__ void quat_to_R(const T* q, T (&R)[9]) {
   const T w = q[0], x = q[1], y = q[2], z = q[3];
-  const T xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
-  R[0] = T(1) - T(2) * (yy + zz); R[1] = T(2) * (xy + wz);        R[2] = T(2) * (xz - wy);
-  R[3] = T(2) * (xy - wz);        R[4] = T(1) - T(2) * (xx + zz); R[5] = T(2) * (yz + wx);
-  R[6] = T(2) * (xz + wy);        R[7] = T(2) * (yz - wx);        R[8] = T(1) - T(2) * (xx + yy);
+  const T two = T(2);
+  // 1 - 2 (a^2 + b^2) and 2 (a b +- c d) as explicit fma chains (see renorm_quat)
+  R[0] = fma_1m2(fma_ss(y, y, z, z)); R[1] = two * fma_ss(x, y, w, z);  R[2] = two * fma_sd(x, z, w, y);
+  R[3] = two * fma_sd(x, y, w, z);    R[4] = fma_1m2(fma_ss(x, x, z, z)); R[5] = two * fma_ss(y, z, w, x);
+  R[6] = two * fma_ss(x, z, w, y);    R[7] = two * fma_sd(y, z, w, x);  R[8] = fma_1m2(fma_ss(x, x, y, y));
 }
 
 // ensure_SO3 (quad_utils.py:123-142) + attitude import.  The reference replaces R by the
@@ -91,20 +104,21 @@ template <typename T>
 __device__ __forceinline__ void rhs(const T* __restrict__ y, T* __restrict__ k, const Dyn<T>& p) {
   const T qw = y[3], qx = y[4], qy = y[5], qz = y[6];
   const T W1 = y[7], W2 = y[8], W3 = y[9];
-  // v' = g e3 - (f/m) R e3,  R e3 = (2(xz + wy), 2(yz - wx), 1 - 2(xx + yy))
+  // v' = g e3 - (f/m) R e3,  R e3 = (2(xz + wy), 2(yz - wx), 1 - 2(xx + yy))     (explicit fma chains: see renorm_quat)
   const T c2 = T(2) * p.c;
-  k[0] = -c2 * (qx * qz + qw * qy);
-  k[1] = -c2 * (qy * qz - qw * qx);
-  k[2] = (p.g - p.c) + c2 * (qx * qx + qy * qy);
+  k[0] = -c2 * fma_ss(qx, qz, qw, qy);
+  k[1] = -c2 * fma_sd(qy, qz, qw, qx);
+  k[2] = fmaT(c2, fma_ss(qx, qx, qy, qy), p.g - p.c);
   // q' = q (0, W) / 2   (<=> R' = R hat(W))
   const T h = T(0.5);
-  k[3] = -h * (qx * W1 + qy * W2 + qz * W3);
-  k[4] = h * (qw * W1 + qy * W3 - qz * W2);
-  k[5] = h * (qw * W2 + qz * W1 - qx * W3);
-  k[6] = h * (qw * W3 + qx * W2 - qy * W1);
+  k[3] = -h * fmaT(qx, W1, fmaT(qy, W2, qz * W3));
+  k[4] = h * fmaT(qw, W1, fmaT(qy, W3, -(qz * W2)));
+  k[5] = h * fmaT(qw, W2, fmaT(qz, W1, -(qx * W3)));
+  k[6] = h * fmaT(qw, W3, fmaT(qx, W2, -(qy * W1)));
   // W' = J^-1 (-W x JW + M), J = diag(J1, J1, J3): the (J1 - J2) W1 W2 term of W3' vanishes
-  k[7] = p.A1 * W2 * W3 + p.U1;
-  k[8] = p.U2 - p.A1 * W3 * W1;
+  const T a3 = p.A1 * W3;
+  k[7] = fmaT(a3, W2, p.U1);
+  k[8] = fmaT(-a3, W1, p.U2);
   k[9] = p.U3;
 }
 
@@ -114,30 +128,32 @@ __device__ __forceinline__ void rk4_step(T (&x)[3], T (&y)[10], T h, const Dyn<T
   const T h2 = T(0.5) * h, h6 = h * T(1.0 / 6.0);
   rhs(y, k, p);
 #pragma unroll
-  for (int i = 0; i < 10; ++i) { acc[i] = k[i]; yt[i] = y[i] + h2 * k[i]; }
+  for (int i = 0; i < 10; ++i) { acc[i] = k[i]; yt[i] = fmaT(h2, k[i], y[i]); }
 #pragma unroll
   for (int i = 0; i < 3; ++i) xs[i] = y[i];
   rhs(yt, k, p);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) xs[i] += T(2) * yt[i];
+  for (int i = 0; i < 3; ++i) xs[i] = fmaT(T(2), yt[i], xs[i]);
 #pragma unroll
-  for (int i = 0; i < 10; ++i) { acc[i] += T(2) * k[i]; yt[i] = y[i] + h2 * k[i]; }
+  for (int i = 0; i < 10; ++i) { acc[i] = fmaT(T(2), k[i], acc[i]); yt[i] = fmaT(h2, k[i], y[i]); }
   rhs(yt, k, p);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) xs[i] += T(2) * yt[i];
+  for (int i = 0; i < 3; ++i) xs[i] = fmaT(T(2), yt[i], xs[i]);
 #pragma unroll
-  for (int i = 0; i < 10; ++i) { acc[i] += T(2) * k[i]; yt[i] = y[i] + h * k[i]; }
+  for (int i = 0; i < 10; ++i) { acc[i] = fmaT(T(2), k[i], acc[i]); yt[i] = fmaT(h, k[i], y[i]); }
   rhs(yt, k, p);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) x[i] += h6 * (xs[i] + yt[i]);
+  for (int i = 0; i < 3; ++i) x[i] = fmaT(h6, xs[i] + yt[i], x[i]);
 #pragma unroll
-  for (int i = 0; i < 10; ++i) y[i] += h6 * (acc[i] + k[i]);
+  for (int i = 0; i < 10; ++i) y[i] = fmaT(h6, acc[i] + k[i], y[i]);
 }
 
-// The flow keeps |q| = 1; RK4 only to truncation order.  Restore it to first order.
+// (explicit fma chains: with -ffp-contract=fast the compiler is otherwise free to contract a sum of products
+// differently in every instantiation of the kernel, and instantiations must agree to the bit)
 template <typename T>
 __device__ __forceinline__ void renorm_quat(T* q) {
-  const T r = T(1.5) - T(0.5) * (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const T n2 = fmaT(q[0], q[0], fmaT(q[1], q[1], fmaT(q[2], q[2], q[3] * q[3])));
+  const T r = fmaT(T(-0.5), n2, T(1.5));
 #pragma unroll
   for (int i = 0; i < 4; ++i) q[i] *= r;
 }
@@ -178,32 +194,64 @@ __device__ __forceinline__ void integrate(T (&x)[3], T (&v)[3], T (&q)[4], T (&W
 // substeps R 9e-7 — the bar is 1e-5.  On gfx950 an f32 VALU instruction issues at up to twice
 // the f64 rate once two waves share a SIMD, and the float32 stage code needs half the registers.
 // ------------------------------------------------------------------------------------
+#ifndef QR_PK_QCHAIN
+#define QR_PK_QCHAIN 1  // 1: quaternion stages on packed-float32 instructions (v_pk_*_f32); 0: the same arithmetic, scalar
+#endif
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// q' = q (0, W/2) on register pairs Q0 = (w, x), Q1 = (y, z), WA = (W1, W2)/2, W3/2 in half SEL of Z: six
+// v_pk_*_f32 — every swizzle and sign is an operand modifier (op_sel / neg) of the packed instruction.
+//   (k_w, k_x) = (-x, w) W1 + (-y, -z) W2 + (-z, y) W3        (k_y, k_z) = (z, -y) W1 + (w, x) W2 + (-x, w) W3
+// (hipcc's own packing of the scalar form inserts v_mov / v_xor for the swizzles and negations.)
+template <int SEL>
+__device__ __forceinline__ void qdot_pk(f2& K0, f2& K1, const f2 Q0, const f2 Q1, const f2 WA, const f2 Z) {
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[1,0]" : "=v"(K0) : "v"(Q0), "v"(WA));
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(K1) : "v"(Q1), "v"(WA));
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(K0) : "v"(Q1), "v"(WA));
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(K1) : "v"(Q0), "v"(WA));
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,%3,0] op_sel_hi:[0,%3,1] neg_lo:[1,0,0]" : "+v"(K0) : "v"(Q1), "v"(Z), "n"(SEL));
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,%3,0] op_sel_hi:[0,%3,1] neg_lo:[1,0,0]" : "+v"(K1) : "v"(Q0), "v"(Z), "n"(SEL));
+}
+// (W1, W2)/2 ' = (a W2/2 + U1/2, -a W1/2 + U2/2), a = A1 W3(t) in half SEL of Bp
+template <int SEL>
+__device__ __forceinline__ f2 wdot_pk(const f2 WA, const f2 Bp, const f2 U) {
+  f2 K;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,%4,0] op_sel_hi:[0,%4,1] neg_hi:[1,0,0]" : "=v"(K) : "v"(WA), "v"(Bp), "v"(U), "n"(SEL));
+  return K;
+}
+
 __device__ __forceinline__ void integrate(float (&x)[3], float (&v)[3], double (&q)[4], double (&W)[3], const Dyn<double>& p, int nsub,
                                           double h) {
   const float hf = (float)h, h2f = 0.5f * hf, h6f = hf * (1.0f / 6.0f);
   const double h2 = 0.5 * h, h6 = h * (1.0 / 6.0);
-  float qs[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) qs[j] = (float)q[j];
   // half body rates (q' = q (0, W/2)); a(t) = A1 W3(t) and W3(t)/2 advance by a constant per half substep
-  float w1 = 0.5f * (float)W[0], w2 = 0.5f * (float)W[1], w3 = 0.5f * (float)W[2];
   double a3 = p.A1 * W[2];
   const double da = p.A1 * p.U3 * h2;
-  float a3f = (float)a3;
+  float a3f = (float)a3, w3 = 0.5f * (float)W[2];
   const float daf = (float)da, dw3 = (float)(0.5 * p.U3 * h2);
   const float u1 = (float)(0.5 * p.U1), u2 = (float)(0.5 * p.U2);
   double W1 = W[0], W2 = W[1];
   float g1[3] = {0.f, 0.f, 0.f}, g23[3] = {0.f, 0.f, 0.f}, g4[3] = {0.f, 0.f, 0.f}, xx[3] = {0.f, 0.f, 0.f};
-  // thrust direction, un-normalised: R e3 = (2 u0, 2 u1, 1 - 2 u2)
-#define QR_THRUST(G, Q)                                         \
-  G[0] = fmaf(Q[1], Q[3], fmaf(Q[0], Q[2], G[0]));              \
-  G[1] = fmaf(Q[2], Q[3], fmaf(-Q[0], Q[1], G[1]));             \
-  G[2] = fmaf(Q[1], Q[1], fmaf(Q[2], Q[2], G[2]));
+  // thrust direction, un-normalised: R e3 = (2 u0, 2 u1, 1 - 2 u2), u = (xz + wy, yz - wx, xx + yy)
+#define QR_THRUST(G, Qw, Qx, Qy, Qz)                            \
+  G[0] = fmaf(Qx, Qz, fmaf(Qw, Qy, G[0]));                      \
+  G[1] = fmaf(Qy, Qz, fmaf(-Qw, Qx, G[1]));                     \
+  G[2] = fmaf(Qx, Qx, fmaf(Qy, Qy, G[2]));
+#if QR_PK_QCHAIN
+  f2 QS0 = {(float)q[0], (float)q[1]}, QS1 = {(float)q[2], (float)q[3]};
+  f2 WA = {0.5f * (float)W[0], 0.5f * (float)W[1]};
+  const f2 U = {u1, u2}, H2 = {h2f, h2f}, H1 = {hf, hf}, H6 = {h6f, h6f}, TWO = {2.0f, 2.0f};
+#else
+  float qs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) qs[j] = (float)q[j];
+  float w1 = 0.5f * (float)W[0], w2 = 0.5f * (float)W[1];
 #define QR_QDOT(K, Q, A, B, C)                                  \
   K[0] = -fmaf(Q[1], A, fmaf(Q[2], B, Q[3] * C));               \
   K[1] = fmaf(Q[0], A, fmaf(Q[2], C, -Q[3] * B));               \
   K[2] = fmaf(Q[0], B, fmaf(Q[3], A, -Q[1] * C));               \
   K[3] = fmaf(Q[0], C, fmaf(Q[1], B, -Q[2] * A));
+#endif
   for (int s = 0; s < nsub; ++s) {
     if (s > 0) {  // prefix sums of the substeps' thrust sums: the double integral for x
 #pragma unroll
@@ -221,41 +269,77 @@ __device__ __forceinline__ void integrate(float (&x)[3], float (&v)[3], double (
     // ---- stage rates in float32 (half units) for the quaternion ----
     const float b0 = a3f, bm = a3f + daf, b1 = bm + daf;
     const float z0 = w3, zm = w3 + dw3, z1 = zm + dw3;
+#if QR_PK_QCHAIN
+    const f2 B01 = {b0, bm}, B1 = {b1, b1}, Z01 = {z0, zm}, Z1 = {z1, z1};
+    f2 K0, K1, A0, A1v, QT0, QT1, KW, WT;
+    // stage 1
+    qdot_pk<0>(K0, K1, QS0, QS1, WA, Z01);
+    QR_THRUST(g1, QS0.x, QS0.y, QS1.x, QS1.y)
+    KW = wdot_pk<0>(WA, B01, U);
+    WT = KW * H2 + WA;
+    A0 = K0; A1v = K1;
+    QT0 = K0 * H2 + QS0; QT1 = K1 * H2 + QS1;
+    // stage 2
+    qdot_pk<1>(K0, K1, QT0, QT1, WT, Z01);
+    QR_THRUST(g23, QT0.x, QT0.y, QT1.x, QT1.y)
+    KW = wdot_pk<1>(WT, B01, U);
+    WT = KW * H2 + WA;
+    A0 = K0 * TWO + A0; A1v = K1 * TWO + A1v;
+    QT0 = K0 * H2 + QS0; QT1 = K1 * H2 + QS1;
+    // stage 3
+    qdot_pk<1>(K0, K1, QT0, QT1, WT, Z01);
+    QR_THRUST(g23, QT0.x, QT0.y, QT1.x, QT1.y)
+    KW = wdot_pk<1>(WT, B01, U);
+    WT = KW * H1 + WA;
+    A0 = K0 * TWO + A0; A1v = K1 * TWO + A1v;
+    QT0 = K0 * H1 + QS0; QT1 = K1 * H1 + QS1;
+    // stage 4
+    qdot_pk<0>(K0, K1, QT0, QT1, WT, Z1);
+    QR_THRUST(g4, QT0.x, QT0.y, QT1.x, QT1.y)
+    const f2 D0 = (A0 + K0) * H6, D1 = (A1v + K1) * H6;
+    q[0] += (double)D0.x; q[1] += (double)D0.y; q[2] += (double)D1.x; q[3] += (double)D1.y;  // the float64 state takes the increment exactly
+    QS0 += D0; QS1 += D1;  // float32 track for the next substep's stages (re-synchronised every env-step)
+#else
     float kq[4], acc[4], qt[4];
     // stage 1
     QR_QDOT(kq, qs, w1, w2, z0)
-    QR_THRUST(g1, qs)
+    QR_THRUST(g1, qs[0], qs[1], qs[2], qs[3])
     float ka = fmaf(b0, w2, u1), kb = fmaf(-b0, w1, u2);
     float t1 = fmaf(h2f, ka, w1), t2 = fmaf(h2f, kb, w2);
 #pragma unroll
     for (int j = 0; j < 4; ++j) { acc[j] = kq[j]; qt[j] = fmaf(h2f, kq[j], qs[j]); }
     // stage 2
     QR_QDOT(kq, qt, t1, t2, zm)
-    QR_THRUST(g23, qt)
+    QR_THRUST(g23, qt[0], qt[1], qt[2], qt[3])
     ka = fmaf(bm, t2, u1); kb = fmaf(-bm, t1, u2);
     t1 = fmaf(h2f, ka, w1); t2 = fmaf(h2f, kb, w2);
 #pragma unroll
     for (int j = 0; j < 4; ++j) { acc[j] = fmaf(2.0f, kq[j], acc[j]); qt[j] = fmaf(h2f, kq[j], qs[j]); }
     // stage 3
     QR_QDOT(kq, qt, t1, t2, zm)
-    QR_THRUST(g23, qt)
+    QR_THRUST(g23, qt[0], qt[1], qt[2], qt[3])
     ka = fmaf(bm, t2, u1); kb = fmaf(-bm, t1, u2);
     t1 = fmaf(hf, ka, w1); t2 = fmaf(hf, kb, w2);
 #pragma unroll
     for (int j = 0; j < 4; ++j) { acc[j] = fmaf(2.0f, kq[j], acc[j]); qt[j] = fmaf(hf, kq[j], qs[j]); }
     // stage 4
     QR_QDOT(kq, qt, t1, t2, z1)
-    QR_THRUST(g4, qt)
+    QR_THRUST(g4, qt[0], qt[1], qt[2], qt[3])
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float dq = h6f * (acc[j] + kq[j]);
       q[j] += (double)dq;   // the float64 state takes the increment exactly
       qs[j] += dq;          // float32 track for the next substep's stages (re-synchronised every env-step)
     }
+#endif
     W1 = fma(h6, fma(2.0, k2a + k3a, k1a + k4a), W1);
     W2 = fma(h6, fma(2.0, k2b + k3b, k1b + k4b), W2);
     a3 = a1; a3f = b1; w3 = z1;
+#if QR_PK_QCHAIN
+    WA.x = 0.5f * (float)W1; WA.y = 0.5f * (float)W2;
+#else
     w1 = 0.5f * (float)W1; w2 = 0.5f * (float)W2;
+#endif
   }
 #undef QR_THRUST
 #undef QR_QDOT
@@ -342,15 +426,21 @@ __device__ __forceinline__ void action_map(const float* a, const Work<T, X>& w, 
     } else {  // M1 = b1.tau + J3 W3 W2, M2 = b2.tau - J3 W3 W1 from (R, W) at step start
       const T t1 = T(a[1]), t2 = T(a[2]), t3 = T(a[3]);
       const T qw = w.q[0], qx = w.q[1], qy = w.q[2], qz = w.q[3];  // b1, b2 = first two columns of R(q)
-      const T b1t = (T(1) - T(2) * (qy * qy + qz * qz)) * t1 + T(2) * (qx * qy + qw * qz) * t2 + T(2) * (qx * qz - qw * qy) * t3;
-      const T b2t = T(2) * (qx * qy - qw * qz) * t1 + (T(1) - T(2) * (qx * qx + qz * qz)) * t2 + T(2) * (qy * qz + qw * qx) * t3;
-      M1 = b1t + ph.J3 * w.W[2] * w.W[1];
-      M2 = b2t - ph.J3 * w.W[2] * w.W[0];
+      const T two = T(2);
+      const T b1x = fma_1m2(fma_ss(qy, qy, qz, qz)), b1y = two * fma_ss(qx, qy, qw, qz), b1z = two * fma_sd(qx, qz, qw, qy);
+      const T b2x = two * fma_sd(qx, qy, qw, qz), b2y = fma_1m2(fma_ss(qx, qx, qz, qz)), b2z = two * fma_ss(qy, qz, qw, qx);
+      const T b1t = fmaT(b1x, t1, fmaT(b1y, t2, b1z * t3));
+      const T b2t = fmaT(b2x, t1, fmaT(b2y, t2, b2z * t3));
+      const T j3w3 = ph.J3 * w.W[2];
+      M1 = fmaT(j3w3, w.W[1], b1t);
+      M2 = fmaT(-j3w3, w.W[0], b2t);
       M3 = T(a[4]);
     }
   }
-  const T iJ1 = recip(ph.J1), iJ3 = recip(ph.J3);
-  p.c = f * recip(ph.m);
+  // 1/m, 1/J1, 1/J3 from ONE reciprocal (of their product): a v_rcp_f64 + Newton steps is ~9 VALU slots
+  const T mJ1 = ph.m * ph.J1, r = recip(mJ1 * ph.J3);
+  const T iJ3 = r * mJ1, rJ3 = r * ph.J3, iJ1 = rJ3 * ph.m;
+  p.c = f * (rJ3 * ph.J1);
   p.A1 = (ph.J1 - ph.J3) * iJ1;
   p.U1 = M1 * iJ1; p.U2 = M2 * iJ1; p.U3 = M3 * iJ3;
   p.g = T(c.g);
@@ -367,18 +457,18 @@ __device__ __forceinline__ void error_obs(Work<T, X>& w, const T (&R)[9], const 
   T ex[3], ev[3], eW[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {  // x/x_lim - xd/x_lim etc. (quad.py:423-434)
-    ex[j] = T(w.x[j]) * ixl - T(w.goal[j]) * ixl;
-    ev[j] = T(w.v[j]) * ivl - T(w.goal[3 + j]) * ivl;
-    eW[j] = w.W[j] * iWl - T(w.goal[9 + j]) * iWl;
+    ex[j] = fmaT(T(w.x[j]), ixl, -(T(w.goal[j]) * ixl));   // (explicit fma chains: see renorm_quat)
+    ev[j] = fmaT(T(w.v[j]), ivl, -(T(w.goal[3 + j]) * ivl));
+    eW[j] = fmaT(w.W[j], iWl, -(T(w.goal[9 + j]) * iWl));
   }
   const T* b1 = &R[0]; const T* b2 = &R[3]; const T* b3 = &R[6];
   const T b1d[3] = {T(w.goal[6]), T(w.goal[7]), T(w.goal[8])};
-  const T db3 = b1d[0] * b3[0] + b1d[1] * b3[1] + b1d[2] * b3[2];
+  const T db3 = fmaT(b1d[0], b3[0], fmaT(b1d[1], b3[1], b1d[2] * b3[2]));
   T b1c[3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) b1c[j] = b1d[j] - db3 * b3[j];
-  const T sn = -(b1c[0] * b2[0] + b1c[1] * b2[1] + b1c[2] * b2[2]);
-  const T cs = b1c[0] * b1[0] + b1c[1] * b1[1] + b1c[2] * b1[2];
+  for (int j = 0; j < 3; ++j) b1c[j] = fmaT(-db3, b3[j], b1d[j]);
+  const T sn = -fmaT(b1c[0], b2[0], fmaT(b1c[1], b2[1], b1c[2] * b2[2]));
+  const T cs = fmaT(b1c[0], b1[0], fmaT(b1c[1], b1[1], b1c[2] * b1[2]));
   const float eb1 = atan2_fast((float)sn, (float)cs);  // [rad]
   const float eb1n = eb1 * (float)(1.0 / kPi);
   // integrators: I += (g_prev + g) dt/2 ; g uses I before the update.  They are float32 words
@@ -408,7 +498,7 @@ __device__ __forceinline__ void error_obs(Work<T, X>& w, const T (&R)[9], const 
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       o0[3 + j] = eIxn[j]; o0[6 + j] = (float)ev[j]; o0[9 + j] = (float)b3[j];
-      o0[12 + j] = (float)(eW[0] * b1[j] + eW[1] * b2[j]);
+      o0[12 + j] = (float)fma_ss(eW[0], b1[j], eW[1], b2[j]);
     }
     o1[0] = eb1n; o1[1] = eIb1n; o1[2] = (float)eW[2];
   }

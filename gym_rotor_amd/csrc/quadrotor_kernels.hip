@@ -76,7 +76,12 @@ __device__ unsigned long long* g_stamps = nullptr;
 #endif
 
 #ifndef QR_SPEC_GRID
-#define QR_SPEC_GRID 4096  // grids up to this many waves sample their reset pool speculatively (under the load latency)
+// Grids up to this many waves sample their reset pool SPECULATIVELY, right after issuing their loads.  Measured on
+// MI355X at 65 536 envs (profiles/r02/ab_reset_pool.json): the wave's loads are back ~0.7 us after its first
+// instruction but the pool's inputs (seed, flags: kernarg segment) only after ~0.5 us, so of the pool's ~0.6 us
+// only ~0.25 us hide and EVERY wave pays the rest (5.45 us per launch), while sampling on demand costs the ~70 %
+// of the waves that hold a resetting lane ~0.45 us (5.18 us).  Default: on demand (0).
+#define QR_SPEC_GRID 0
 #endif
 
 // ------------------------------------------------------------------------------------
@@ -202,7 +207,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   // ---- in-launch reset: this wave's pool of episode starts (qr_rng.h), sampled while the loads are in flight ----
   ResetPool<T> pool;
   bool have_pool = false;
-#if QR_ABLATE != 3
+#if QR_ABLATE != 3 && QR_SPEC_GRID > 0
   if (auto_reset && gridDim.x <= QR_SPEC_GRID) {
     make_pool<T>(pool, role, seed, gfirst, rcount, 0);
     have_pool = true;
@@ -220,6 +225,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   int32_t steps = (steps_ptr && active) ? (steps_ptr + first)[lane] : 0;
   bool params_dirty = false;
   bool traj_dirty = false;  // this lane started a new episode: its generator state changed
+  bool stored_early = false;  // (SINGLE) this lane's state went out before its wave sampled a reset pool
 
   // POLICY: the observation the next action is computed from (rows -> lane registers once, then
   // carried from step to step)
@@ -320,16 +326,22 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     // multiplier is the wave's maximum (found with ballots, so the substep loop stays wave-uniform
     // and in regime — |W| < 2 pi < w_adapt — this costs one ballot): every lane takes at least
     // the count its own rate asks for.
-    int nsub = ka.substeps;
     if constexpr (ADAPT) {
       const T wmax = fmax(fmax(fabs(w.W[0]), fabs(w.W[1])), fabs(w.W[2]));
       const T need = wmax * T(c.inv_w_adapt);
-      int mul = 1;
-      while (mul < 16 && __ballot(need > T(mul))) ++mul;
-      nsub *= mul;
+      if (__ballot(need > T(1)) == 0) {  // in regime: exactly the plain kernel's code path (one ballot)
+        const int nsub = ka.substeps;
+        integrate(w.x, w.v, w.q, w.W, dyn, nsub, T(c.dt) * recip(T(nsub)));
+      } else {
+        int mul = 2;
+        while (mul < 16 && __ballot(need > T(mul))) ++mul;
+        const int nsub = ka.substeps * mul;
+        integrate(w.x, w.v, w.q, w.W, dyn, nsub, T(c.dt) * recip(T(nsub)));
+      }
+    } else {
+      const int nsub = ka.substeps;
+      integrate(w.x, w.v, w.q, w.W, dyn, nsub, T(c.dt) * recip(T(nsub)));
     }
-    const T h = T(c.dt) * recip(T(nsub));
-    integrate(w.x, w.v, w.q, w.W, dyn, nsub, h);
     renorm_quat(w.q);
     QR_STAMP(3, (float)w.q[0] + (float)w.x[0] + (float)w.v[2] + (float)w.W[0]);
 #endif
@@ -342,8 +354,8 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     bool dn[NAG];
     if constexpr (KIND == QR_KIND_QUAD) {
       const T qw = w.q[0], qx = w.q[1], qy = w.q[2], qz = w.q[3];
-      const T R00 = T(1) - T(2) * (qy * qy + qz * qz), R10 = T(2) * (qx * qy + qw * qz);  // b1 = first column of R(q)
-      const T R20 = T(2) * (qx * qz - qw * qy), R21 = T(2) * (qy * qz + qw * qx), R22 = T(1) - T(2) * (qx * qx + qy * qy);
+      const T R00 = fma_1m2(fma_ss(qy, qy, qz, qz)), R10 = T(2) * fma_ss(qx, qy, qw, qz);  // b1 = first column of R(q)
+      const T R20 = T(2) * fma_sd(qx, qz, qw, qy), R21 = T(2) * fma_ss(qy, qz, qw, qx), R22 = fma_1m2(fma_ss(qx, qx, qy, qy));
       // reward_wrapper (quad.py:274-298), formed in float32 (its result is a float32 word)
       float eX2 = 0.f, eV2 = 0.f, W2 = 0.f;
 #pragma unroll
@@ -415,8 +427,34 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     const bool need_reset = auto_reset && any_done && active;
 #endif
     const int64_t row0 = (int64_t)t * N + first;
+    // ---- reward / done of step t (they belong to the step that just ended, whatever the reset does next) ----
+    if (active) {
+      if constexpr (NAG == 1) {
+        (ka.reward + row0)[lane] = rwd[0];
+        if (ka.reward_raw) (ka.reward_raw + row0)[lane] = rraw[0];
+        (ka.done + row0)[lane] = dn[0] ? 1 : 0;
+      } else {
+        (reinterpret_cast<float2*>(ka.reward) + row0)[lane] = make_float2(rwd[0], rwd[NAG - 1]);
+        if (ka.reward_raw) (reinterpret_cast<float2*>(ka.reward_raw) + row0)[lane] = make_float2(rraw[0], rraw[NAG - 1]);
+        (reinterpret_cast<uchar2*>(ka.done) + row0)[lane] = make_uchar2(dn[0] ? 1 : 0, dn[NAG - 1] ? 1 : 0);
+      }
+      if (ka.truncated) (ka.truncated + row0)[lane] = trunc ? 1 : 0;
+    }
     const unsigned long long rmask = __ballot(need_reset);
     if (rmask) {  // wave-uniform: skipped unless some lane of this wave starts a new episode
+      if constexpr (SINGLE) {
+        // This wave is about to spend ~0.5 us sampling episode starts.  The state of its lanes that do NOT
+        // reset is final: hand it to the memory system first, so that those stores drain meanwhile.
+        if (active && !need_reset) {
+          store_state<XV, QW>(a, first, lane, w);
+          if (KIND != QR_KIND_QUAD) {
+            const SoA<float> integ(a.integ, 8, L);
+#pragma unroll
+            for (int f = 0; f < 8; ++f) integ.store(f, ufirst, lane, w.integ[f]);
+          }
+        }
+        stored_early = !need_reset;
+      }
       // the terminal observation of the episode that ends here (what a learner bootstraps from):
       // written for the resetting lanes only
       if (need_reset && ka.final_obs0 != nullptr) {
@@ -500,27 +538,17 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 #pragma unroll
       for (int j = 0; j < D1; ++j) po1[j] = o1[j];
     }
-    if (active) {
-      if constexpr (NAG == 1) {
-        (ka.reward + row0)[lane] = rwd[0];
-        if (ka.reward_raw) (ka.reward_raw + row0)[lane] = rraw[0];
-        (ka.done + row0)[lane] = dn[0] ? 1 : 0;
-      } else {
-        (reinterpret_cast<float2*>(ka.reward) + row0)[lane] = make_float2(rwd[0], rwd[NAG - 1]);
-        if (ka.reward_raw) (reinterpret_cast<float2*>(ka.reward_raw) + row0)[lane] = make_float2(rraw[0], rraw[NAG - 1]);
-        (reinterpret_cast<uchar2*>(ka.done) + row0)[lane] = make_uchar2(dn[0] ? 1 : 0, dn[NAG - 1] ? 1 : 0);
-      }
-      if (ka.truncated) (ka.truncated + row0)[lane] = trunc ? 1 : 0;
-    }
   }
 
   // ---- write the working set back ----
   if (active) {
-    store_state<XV, QW>(a, first, lane, w);
-    if (KIND != QR_KIND_QUAD) {
-      const SoA<float> integ(a.integ, 8, L);
+    if (!(SINGLE && stored_early)) {
+      store_state<XV, QW>(a, first, lane, w);
+      if (KIND != QR_KIND_QUAD) {
+        const SoA<float> integ(a.integ, 8, L);
 #pragma unroll
-      for (int f = 0; f < 8; ++f) integ.store(f, ufirst, lane, w.integ[f]);
+        for (int f = 0; f < 8; ++f) integ.store(f, ufirst, lane, w.integ[f]);
+      }
     }
     if (steps_ptr) (steps_ptr + first)[lane] = steps;
     if constexpr (TRAJ) {
