@@ -17,10 +17,22 @@ config.other_reset_mode.  Envs are sharded over ranks
 with NO collective on the step path (weak scaling: 65 536 envs per GPU); `value` = all ranks'
 env-steps / the max-over-ranks time of the K timed steps, inputs resident in HBM.
 
-The K timed steps are issued as one hipGraph replay of K captured qr_step launches (default)
-or eagerly (--mode eager); HIP events recorded on the launch stream bracket exactly those K
-launches.  `roofline.achieved` = SURVEY.md §8(d) algorithmic bytes per launch / (event time / K);
-`roofline.traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed under
+Timing.  The K steps are one hipGraph of K captured qr_step launches (default) or K eager calls
+(--mode eager).  One timed REPETITION = barrier + synchronize, an untimed lead-in replay of
+max(10, 300 - K) steps (so that the K timed launches are queued behind running work — no host
+submission latency inside the timed region — and run at busy clocks, not on the ramp that
+follows the barrier's idle gap), HIP event, the K steps, HIP event, synchronize + barrier.  For
+K < 300 the timed graph holds ceil(300 / K) back-to-back copies of the K steps and the event
+time is divided by that count: a graph launch costs a fixed ~9 us on the device, which would
+otherwise weigh 8 % at K = 20 and 0.2 % at K = 1000.  Repetitions
+are made until >= 20 of them AND >= 50 ms of timed work exist (at most 200); the MEDIAN
+repetition is reported, after a MAX over ranks.  ONE clock feeds every figure of the line: the
+HIP-event time of the K steps on the launch stream -> `ms_per_step`, `value` = envs x K / that
+time, `roofline.achieved` = SURVEY.md 8(d) algorithmic bytes per launch / (that time / K) (the
+same number again as `roofline.avg_launch_us`).  The host wall clock of the same repetitions
+(which adds the graph submission and the synchronize round trip, ~20 us per repetition whatever
+K is) is reported beside it as `wall_ms_per_step`; `--steps 20` and `--steps 1000` therefore
+agree.  `roofline.traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed under
 profiles/ (tools/profile.sh), when one exists for this configuration.
 
 Secondary figures under `config` (rank 0, --extras 1): the other reset mode, the fused `rollout(T=100)`,
@@ -50,8 +62,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=1000)   # ~5 ms timed: the post-barrier clock ramp (first ~50 launches
-    p.add_argument("--warmup", type=int, default=50)    # run 5-20 % slow) stays below 1 % of the region
+    p.add_argument("--steps", type=int, default=1000)   # K steps per timed repetition (>= 20 repetitions, >= 50 ms of timed work)
+    p.add_argument("--warmup", type=int, default=50)
     p.add_argument("--envs", type=int, default=65536, help="envs PER GPU")
     p.add_argument("--kind", default="quad", choices=["quad", "coupled", "decoupled"])
     p.add_argument("--substeps", type=int, default=1)
@@ -131,8 +143,8 @@ def cpu_baseline(kind: str, seconds: float):
             "numpy": np.__version__, "scipy": scipy.__version__}
 
 
-def committed_traffic(kind, envs, layout, auto_reset):
-    """HBM bytes per launch from the PMC profile committed under profiles/ (None if absent)."""
+def committed_traffic(kind, envs, layout, auto_reset, substeps=1):
+    """HBM bytes per launch from the PMC profile committed under profiles/ (None if absent); the newest file wins."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     if not os.path.isdir(pdir):
@@ -141,48 +153,72 @@ def committed_traffic(kind, envs, layout, auto_reset):
         if fn.endswith("_traffic.json"):
             try:
                 for rec in json.load(open(os.path.join(pdir, fn))):
-                    if (rec["kind"], rec["envs"], rec["layout"], rec["auto_reset"]) == (kind, envs, layout, auto_reset):
+                    if (rec["kind"], rec["envs"], rec["layout"], rec["auto_reset"], rec.get("substeps", 1)) == (kind, envs, layout, auto_reset, substeps):
                         best = rec
             except Exception:
                 pass
     return best
 
 
-def main():
-    a = parse()
+def _init_dist():
+    """(dist module or None, rank, local_rank, world, backend).  torch.distributed is initialised when
+    WORLD_SIZE > 1 — or when QR_BENCH_FORCE_DIST=1 (a world of ONE rank under torch.distributed.run: lets
+    a 1-GPU box execute the exact RCCL code path of the 2/4/8-GPU runs)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # QR_BENCH_BACKEND=gloo is a test hook: it lets N ranks share the GPUs that exist (rank -> device
-        # local_rank % device_count) so that the multi-rank control flow can be exercised on a 1-GPU box
-        backend = os.environ.get("QR_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            local_rank = local_rank % torch.cuda.device_count()
-            dist.init_process_group(backend)
+    if world == 1 and os.environ.get("QR_BENCH_FORCE_DIST") != "1":
+        return None, rank, local_rank, world, None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    # QR_BENCH_BACKEND=gloo is a test hook: it lets N ranks share the GPUs that exist (rank -> device
+    # local_rank % device_count) so that the multi-rank control flow can be exercised on a 1-GPU box
+    backend = os.environ.get("QR_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+    else:
+        local_rank = local_rank % torch.cuda.device_count()
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return dist, rank, local_rank, world, backend
+
+
+def _ensure_library(dist, local_rank):
+    """A checkout without the (git-ignored) library: local rank 0 builds it (to a temporary name, renamed
+    into place), everyone else waits.  Every rank takes the same decision and the same barrier."""
+    lib = os.path.join(ROOT, "gym_rotor_amd", "libquadrotor_hip.so")
+    if os.environ.get("QR_LIB"):
+        return
+    need = torch.tensor([0 if os.path.exists(lib) else 1], dtype=torch.int32)
+    if dist is not None:  # rank 0's view decides for all (a later rank may already see the finished file)
+        if dist.get_backend() == "nccl":
+            need = need.cuda()
+        dist.broadcast(need, src=0)
+    if int(need.item()):
+        if local_rank == 0:
+            import subprocess
+            tmp = lib + f".tmp{os.getpid()}"
+            subprocess.run(["make", "-C", os.path.join(ROOT, "gym_rotor_amd", "csrc"), f"OUT={tmp}"], check=True, stdout=sys.stderr)
+            os.replace(tmp, lib)
+        if dist is not None:
+            dist.barrier()
+
+
+def main():
+    a = parse()
+    dist, rank, local_rank, world, backend = _init_dist()
     n_gpus = world
     if a.gpus != world and rank == 0:
         print(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-
-    if not os.path.exists(os.path.join(ROOT, "gym_rotor_amd", "libquadrotor_hip.so")) and not os.environ.get("QR_LIB"):
-        # a checkout without the (git-ignored) library: build it once (local rank 0), others wait
-        import subprocess
-        if local_rank == 0:
-            subprocess.run(["make", "-C", os.path.join(ROOT, "gym_rotor_amd", "csrc")], check=True, stdout=sys.stderr)
-        if dist is not None:
-            dist.barrier()
+    _ensure_library(dist, local_rank)
     from gym_rotor_amd import ALGO_BYTES, QuadVecEnv
     from gym_rotor_amd.constants import ALGO_BYTES_PARAMS
     N = a.envs
     auto_reset = a.auto_reset
+    on_dev = dist is None or backend == "nccl"
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -191,87 +227,137 @@ def main():
         torch.cuda.synchronize(dev)
 
     def run(ar: bool, timed: bool):
-        """W warmup steps, then exactly K timed steps."""
+        """W warm-up steps, then repetitions of exactly K timed steps; returns the per-repetition
+        (HIP-event ms, wall ms) lists and a few facts about the final state."""
         env = QuadVecEnv(a.kind, N, device=dev, seed=0, substeps=a.substeps, layout=a.layout, use_UDM=True,
                          auto_reset=ar, env_offset=rank * N)
-        env.reset("train")
-        if a.kind != "quad":
-            env.get_norm_error_state()
+
+        def fresh():  # the timed steps start from reset-distribution states (configs[1])
+            env.reset("train")
+            if a.kind != "quad":
+                env.get_norm_error_state()
+
+        fresh()
         gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
         acts = [torch.rand(N, env.action_dim, device=dev, generator=gen) * 2 - 1 for _ in range(a.action_batches)]
         for i in range(a.warmup):
             env.step(acts[i % len(acts)])
-        graph = None
+        # untimed lead-in of every repetition: long enough (~1.5 ms) to bring the chip back to its busy clocks after the
+        # barrier's idle gap — the first ~50 launches after an idle period run 5-20 % slow — and to keep the queue ahead
+        n_lead = max(10, 300 - a.steps)
+        # a graph launch costs a fixed ~9 us on the device whatever it holds (measured: the 20-step graph ran 8 % slower per step
+        # than the 1000-step one): for small K the timed graph holds `copies` back-to-back copies of the K steps
+        copies = max(1, -(-300 // a.steps)) if a.mode == "graph" else 1
+        graph = lead = None
+        side = torch.cuda.Stream(dev)
         if a.mode == "graph":
             torch.cuda.synchronize(dev)
-            side = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
-            graph = torch.cuda.CUDAGraph()
+            graph, lead = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.stream(side):
                 with torch.cuda.graph(graph, stream=side):
-                    for i in range(a.steps):
+                    for i in range(a.steps * copies):
                         env.step(acts[i % len(acts)])
+                with torch.cuda.graph(lead, stream=side):
+                    for i in range(n_lead):
+                        env.step(acts[(a.steps + i) % len(acts)])
             torch.cuda.current_stream(dev).wait_stream(side)
             # untimed: the first replay uploads the graph; keep replaying for ~50 ms so the timed
-            # replay runs at the clocks a training loop sees, not at the idle-to-busy ramp
+            # repetitions run at the clocks a training loop sees, not at the idle-to-busy ramp
             t_w = time.perf_counter()
             while True:
                 graph.replay()
                 torch.cuda.synchronize(dev)
                 if time.perf_counter() - t_w > 0.05:
                     break
-        # the timed steps start from reset-distribution states (configs[1]), not from wherever the
-        # untimed warm-up left the envs
-        env.reset("train")
-        if a.kind != "quad":
-            env.get_norm_error_state()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        barrier() if timed else torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        ev0.record()
-        if graph is not None:
-            graph.replay()
-        else:
-            for i in range(a.steps):
-                env.step(acts[i % len(acts)])
-        ev1.record()
-        barrier() if timed else torch.cuda.synchronize(dev)
-        wall = time.perf_counter() - t0
-        dev_ms = ev0.elapsed_time(ev1)
+
+        def issue_lead():
+            if lead is not None:
+                lead.replay()
+            else:
+                for i in range(n_lead):
+                    env.step(acts[(a.steps + i) % len(acts)])
+
+        def issue_steps():
+            if graph is not None:
+                graph.replay()
+            else:
+                for i in range(a.steps):
+                    env.step(acts[i % len(acts)])
+
+        dev_ms, wall_ms = [], []
+        reps_min, reps_max, budget_ms = 20, 200, 50.0
+        while True:
+            if not ar:
+                fresh()  # free run: every repetition is the K steps that follow one reset
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            barrier() if timed else torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            issue_lead()          # untimed lead-in: the timed launches queue up behind running work
+            ev0.record()
+            issue_steps()         # exactly K steps
+            ev1.record()
+            barrier() if timed else torch.cuda.synchronize(dev)
+            wall_ms.append((time.perf_counter() - t0) * 1e3)
+            dev_ms.append(ev0.elapsed_time(ev1) / copies)
+            done_reps = len(dev_ms)
+            stop = done_reps >= reps_max or (done_reps >= reps_min and sum(dev_ms) >= budget_ms)
+            if dist is not None and timed:  # all ranks stop together (the barrier count must match)
+                flag = torch.tensor([1 if stop else 0], dtype=torch.int32, device=dev if on_dev else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                stop = bool(flag.item())
+            if stop:
+                break
         finite = bool(torch.isfinite(env.get_current_state()).all())
         done_rate = float(env._done.float().mean())
-        return wall, dev_ms, finite, done_rate, env.kernel_info()
+        return dev_ms, wall_ms, finite, done_rate, env.kernel_info(), n_lead, copies
 
-    wall, dev_ms, finite, done_rate, kinfo = run(auto_reset, True)
-    tmax = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev if dist is None or dist.get_backend() == "nccl" else "cpu")
+    dev_ms, wall_ms, finite, done_rate, kinfo, n_lead, copies = run(auto_reset, True)
+    reps = len(dev_ms)
+    med_dev, med_wall = float(np.median(dev_ms)), float(np.median(wall_ms))
+    tmax = torch.tensor([med_dev, med_wall], dtype=torch.float64, device=dev if on_dev else "cpu")
+    n_ranks_rccl = None
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    wall, dev_ms = float(tmax[0]), float(tmax[1])
+        if backend == "nccl":  # the world as RCCL sees it: every rank contributes 1
+            ones = torch.ones(1, dtype=torch.int32, device=dev)
+            dist.all_reduce(ones)
+            n_ranks_rccl = int(ones.item())
+    med_dev, med_wall = float(tmax[0]), float(tmax[1])
 
     if rank == 0:
-        ms_per_step = wall * 1e3 / a.steps
-        launch_us = dev_ms * 1e3 / a.steps
+        ms_per_step = med_dev / a.steps              # THE clock of this line: HIP events around the K steps
+        launch_us = ms_per_step * 1e3
+        wall_ms_per_step = med_wall / (a.steps * copies + n_lead)
         algo = ALGO_BYTES[a.kind] + ALGO_BYTES_PARAMS
         # bytes this layout really moves per env-step: 13-word state r/w, action, [integ r/w, obs rows],
-        # reward, done, params (+ episode counter read with auto-reset)
+        # reward, done, params
         state_b = {"mixed": 6 * 4 + 7 * 8, "f64": 13 * 8, "f32": 13 * 4}[a.layout] * 2
         layout = state_b + {"quad": 16 + 4 + 1 + 24, "coupled": 16 + 64 + 92 + 4 + 1 + 24,
-                            "decoupled": 20 + 64 + 72 + 8 + 2 + 24}[a.kind] + (4 if auto_reset else 0)
+                            "decoupled": 20 + 64 + 72 + 8 + 2 + 24}[a.kind]
         achieved = algo * N / (launch_us * 1e-6) / 1e9
         kname, grid, block = kinfo
-        traffic = committed_traffic(a.kind, N, a.layout, auto_reset)
+        traffic = committed_traffic(a.kind, N, a.layout, auto_reset, a.substeps)
         out = {
             "metric": "quadrotor env-steps/sec at 65 536 envs; 1/2/4/8 MI355X + CPU ref",
-            "value": N * n_gpus * a.steps / wall, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": a.steps,
+            "value": N * n_gpus / (ms_per_step * 1e-3), "unit": "env-steps/s", "n_gpus": n_gpus, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if a.layout == "f32" else "f64", "data": "synthetic",
             "config": {"workload": (f"BASELINE.json configs[1]: Quad-v0 batched {N} envs per GPU, random actions, fp32 I/O, "
                                     + ("terminated envs re-sampled in the launch" if auto_reset else "free run from one reset")
                                     if a.kind == "quad" else f"{a.kind} wrapper, {N} envs per GPU, random actions, fp32 I/O"),
                        "kind": a.kind, "envs_per_gpu": N, "global_envs": N * n_gpus, "substeps": a.substeps,
-                       "integrator": "RK4 on (v, unit quaternion, W), substeps x ceil(max|W|/16 rad/s) per wavefront", "state_layout": a.layout, "io_dtype": "f32",
+                       "integrator": "RK4 per substep on (v, unit quaternion, W): W and the q accumulation in float64, stage quaternions in "
+                                     "float32; substeps x ceil(max|W|/16 rad/s) per wavefront", "state_layout": a.layout, "io_dtype": "f32",
                        "auto_reset": auto_reset, "done_rate_last_step": done_rate, "launch_mode": a.mode,
-                       "parallelism": f"env-shard x{n_gpus}, no collective", "state_finite": finite},
+                       "parallelism": f"env-shard x{n_gpus}, no collective", "state_finite": finite,
+                       "n_ranks_rccl": n_ranks_rccl},
+            "timing": {"clock": "HIP events on the launch stream around the K steps of one repetition; median over repetitions, max over ranks",
+                       "repetitions": reps, "timed_ms_total": float(sum(dev_ms)) * copies, "lead_in_steps_untimed": n_lead,
+                       "copies_of_the_K_steps_per_timed_graph": copies,
+                       "ms_per_rep_min_median_max": [float(min(dev_ms)), float(np.median(dev_ms)), float(max(dev_ms))],
+                       "wall_ms_per_step": wall_ms_per_step,
+                       "wall_note": "host clock around lead-in + K steps incl. graph submission and synchronize, / (K + lead-in)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": (traffic or {}).get("bytes_per_launch"),
                          "traffic_source": (traffic or {}).get("source"),
@@ -279,14 +365,14 @@ def main():
                          "algorithmic_bytes_per_env_step": algo, "layout_bytes_per_env_step": layout,
                          "achieved_layout_GBs": layout * N / (launch_us * 1e-6) / 1e9,
                          "note": "algorithmic bytes = SURVEY.md 8(d) (165 B + 24 B per-env params for Quad-v0); "
-                                 "avg_launch_us = HIP-event time of the K back-to-back launches / K (includes the "
-                                 "~1.7 us launch floor of an empty kernel of this grid)"},
+                                 "avg_launch_us = ms_per_step: launch-to-launch time of back-to-back launches (includes the "
+                                 "~1.8 us boundary between dependent kernels)"},
         }
         if n_gpus == 1 and a.extras:
             # secondary figure: the other reset mode (no reset inside step = the reference's own semantics)
-            w2, d2, _, _, _ = run(not auto_reset, False)
-            out["config"]["other_reset_mode"] = {"auto_reset": not auto_reset, "env_steps_per_s": N * a.steps / w2,
-                                                 "avg_launch_us": d2 * 1e3 / a.steps}
+            d2, _, _, _, _, _, _ = run(not auto_reset, False)
+            us2 = float(np.median(d2)) * 1e3 / a.steps
+            out["config"]["other_reset_mode"] = {"auto_reset": not auto_reset, "env_steps_per_s": N / (us2 * 1e-6), "avg_launch_us": us2}
             # secondary figure: fused rollout, T=100 env-steps per launch with the state in registers
             # (SURVEY.md 8(d) config 2 asks for both per-launch step() and rollout(T=100))
             env = QuadVecEnv(a.kind, N, device=dev, seed=0, substeps=a.substeps, layout=a.layout, use_UDM=True,
@@ -295,10 +381,13 @@ def main():
             acts = torch.rand(100, N, env.action_dim, device=dev) * 2 - 1
             ro = env.rollout(acts)
             torch.cuda.synchronize(dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); env.rollout(acts, out=ro); e1.record(); torch.cuda.synchronize(dev)
-            out["config"]["rollout_T100"] = {"env_steps_per_s": N * 100 / (e0.elapsed_time(e1) * 1e-3),
-                                             "us_per_env_step_batch": e0.elapsed_time(e1) * 10.0}
+            ts = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); env.rollout(acts, out=ro); e1.record(); torch.cuda.synchronize(dev)
+                ts.append(e0.elapsed_time(e1))
+            t100 = float(np.median(ts))
+            out["config"]["rollout_T100"] = {"env_steps_per_s": N * 100 / (t100 * 1e-3), "us_per_env_step_batch": t100 * 10.0}
             # secondary figure: the PPO collection loop of BASELINE configs[2] with the actor inside the
             # step kernel (qr_rollout_actor): CoupledWrapper, T = 32 steps per launch, auto-reset, in-kernel noise
             from gym_rotor_amd import random_actors
@@ -308,12 +397,13 @@ def main():
             actors = random_actors("coupled", dev, generator=torch.Generator(device=dev).manual_seed(7), log_std=-0.5)
             po = penv.rollout_actor(actors, 32)
             torch.cuda.synchronize(dev)
-            best = 1e9
+            ts = []
             for _ in range(5):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(); penv.rollout_actor(actors, 32, out={k: v for k, v in po.items() if k != "obs"}); e1.record()
                 torch.cuda.synchronize(dev)
-                best = min(best, e0.elapsed_time(e1))
+                ts.append(e0.elapsed_time(e1))
+            best = float(np.median(ts))
             out["config"]["policy_rollout_coupled_T32"] = {"env_steps_per_s": N * 32 / (best * 1e-3), "us_per_env_step_batch": best * 1e3 / 32,
                                                            "what": "CoupledWrapper env + 23->16->16->4 PPO actor (MFMA) + sampling in one launch per horizon"}
         if n_gpus == 1 and a.cpu_seconds > 0:

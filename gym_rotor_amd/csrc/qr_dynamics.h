@@ -195,7 +195,9 @@ __device__ __forceinline__ void integrate(T (&x)[3], T (&v)[3], T (&q)[4], T (&W
 // the f64 rate once two waves share a SIMD, and the float32 stage code needs half the registers.
 // ------------------------------------------------------------------------------------
 #ifndef QR_PK_QCHAIN
-#define QR_PK_QCHAIN 1  // 1: quaternion stages on packed-float32 instructions (v_pk_*_f32); 0: the same arithmetic, scalar
+#define QR_PK_QCHAIN 0  // 1: quaternion stages on packed-float32 instructions (v_pk_*_f32); 0: the same arithmetic, scalar.
+// Measured equal within noise on MI355X at every size (profiles/r02/ab_pk_qchain.json: 5.20 vs 5.20 us at 65 536 envs,
+// 37.1 vs 37.5 us at 1 M, 11.4 vs 11.3 us at 131 072 x 10 substeps): default = the plain form
 #endif
 typedef float f2 __attribute__((ext_vector_type(2)));
 
