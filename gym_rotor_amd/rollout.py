@@ -20,16 +20,25 @@ from . import _lib
 class RolloutStorage:
     """[T(+1), N, ...] buffers for one PPO horizon of a QuadVecEnv.
 
-    obs[k]      [T+1, N, D_k]   observation of agent k BEFORE step t; row T = after the last step
-                               (obs_next[t] is obs[t+1]: with same-step auto-reset the row after a
-                               terminal step holds the new episode's first observation, and the
-                               GAE masks the bootstrap with (1 - done) exactly like ppo.py:138)
+    obs[k]      [T+1, N, D_k]   observation of agent k BEFORE step t; row T = after the last step.
+                               With same-step auto-reset the row after an episode's last step holds the
+                               NEW episode's first observation, so obs[t+1] is NOT the reference's
+                               obs_next of that transition (main.py:163-178 stores the true next
+                               observation and ppo.py:128-138 evaluates the critic on it).  (1 - done)
+                               hides the difference only for the agent that terminated: a time-limit
+                               truncation (done = 0) and — MODUL — the agent that did NOT terminate when
+                               the other one ended the episode both bootstrap from V(obs_next).
+    final_obs[k] [T, N, D_k]    (final_obs=True) the terminal observation of every env that was re-sampled
+                               in step t, written by the step kernel (QrStepOut.final_obs*); rows of envs
+                               that did not reset are meaningless.  `next_values(critic)` builds the
+                               reference's V(obs_next) from it: value[t+1] everywhere except on reset
+                               rows, where the critic is evaluated on final_obs.
     act[k]      [T, N, A_k]     logprob[k] [T, N, A_k]  (per-dimension log-probs, ppo.py buffer)
     reward      [T, N, n_agents]   done [T, N, n_agents] (bool)   truncated [T, N] (bool)
     value       [T+1, N, n_agents] critic outputs, row T = bootstrap
     """
 
-    def __init__(self, env, horizon: int, action_dims: Optional[List[int]] = None):
+    def __init__(self, env, horizon: int, action_dims: Optional[List[int]] = None, final_obs: Optional[bool] = None):
         self.T, self.N, self.device = int(horizon), env.num_envs, env.device
         self.n_agents = env.n_agents
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -40,6 +49,11 @@ class RolloutStorage:
         self.action_dims = list(action_dims)
         T, N = self.T, self.N
         self.obs = [torch.zeros(T + 1, N, d, **f32) for d in env.obs_dims]
+        if final_obs is None:  # needed (and possible) exactly when the env re-samples inside the step
+            final_obs = bool(env.auto_reset) and (env.kind != "quad" or env.obs_rows)
+        if final_obs and not env.auto_reset:
+            raise ValueError("final_obs needs an env with auto_reset=True")
+        self.final_obs = [torch.zeros(T, N, d, **f32) for d in env.obs_dims] if final_obs else None
         # agents' actions / log-probs concatenated along the last axis (main.py:161), which is the row
         # layout qr_rollout_actor writes; act[k] / logprob[k] are per-agent views into them
         self.act_all = torch.zeros(T, N, env.action_dim, **f32)
@@ -65,6 +79,9 @@ class RolloutStorage:
         out = {"obs0": self.obs[0][t + 1], "reward": self.reward[t], "terminated": self.done[t], "truncated": self.truncated[t]}
         if len(self.obs) > 1:
             out["obs1"] = self.obs[1][t + 1]
+        if self.final_obs is not None:
+            for k, f in enumerate(self.final_obs):
+                out[f"final_obs{k}"] = f[t]
         return out
 
     def horizon(self) -> dict:
@@ -73,7 +90,28 @@ class RolloutStorage:
                "terminated": self.done, "truncated": self.truncated}
         if len(self.obs) > 1:
             out["obs1"] = self.obs[1][1:]
+        if self.final_obs is not None:
+            for k, f in enumerate(self.final_obs):
+                out[f"final_obs{k}"] = f
         return out
+
+    def reset_mask(self) -> torch.Tensor:
+        """[T, N] bool: the env was re-sampled at the end of step t (an agent terminated or the time limit hit)."""
+        return self.done.any(-1) | self.truncated
+
+    def next_values(self, critic) -> torch.Tensor:
+        """The reference's V(obs_next) for every transition, [T, N, n_agents]: value[t+1] (which must already
+        hold V(obs[t+1]), row T = the bootstrap row) except where the env was re-sampled in step t — there
+        `critic` is evaluated on the terminal observation rows.  critic(list of per-agent [n, D_k] rows) ->
+        [n, n_agents].  Pass the result to compute_gae(next_value=...)."""
+        nv = self.value[1:].clone()
+        if self.final_obs is None:
+            return nv
+        idx = self.reset_mask().nonzero(as_tuple=True)
+        if idx[0].numel():
+            rows = [f[idx] for f in self.final_obs]
+            nv[idx] = critic(rows).reshape(-1, self.n_agents).to(nv.dtype)
+        return nv
 
     def collect(self, env, actors, **kw) -> dict:
         """One horizon with the actor(s) inside the step kernel (qr_rollout_actor): obs row 0 is the
@@ -97,8 +135,10 @@ class RolloutStorage:
     def compute_gae(self, gamma: float = 0.99, lam: float = 0.9, last_value: Optional[torch.Tensor] = None,
                     next_value: Optional[torch.Tensor] = None, want_stats: bool = True):
         """ppo.py:134-146 for every (env, agent) column in one launch.  `last_value` fills the
-        bootstrap row value[T]; `next_value` ([T,N,n_agents]) overrides Vnext_t = value[t+1]
-        (e.g. critic(obs_next) evaluated separately, as the reference does).
+        bootstrap row value[T]; `next_value` ([T,N,n_agents]) overrides Vnext_t = value[t+1] — with an
+        auto-resetting env pass `next_values(critic)`: value[t+1] is V of the NEW episode's first
+        observation on reset rows, which is not what the reference bootstraps from (see the class
+        docstring).  The recursion itself is the reference's: masked by `done` only.
         Returns (advantage, td_target[, (sum, sumsq, count) per agent as float64 [n_agents, 3]])."""
         if last_value is not None:
             self.value[self.T].copy_(last_value.reshape(self.N, self.n_agents))
@@ -106,11 +146,14 @@ class RolloutStorage:
         grid = (M + 63) // 64
         partials = torch.zeros(grid, 2, dtype=torch.float64, device=self.device) if want_stats else None
         nv = None if next_value is None else next_value.contiguous()
-        rc = self._lib.qr_gae(self.reward.data_ptr(), self.done.data_ptr(), self.value.data_ptr(),
-                              None if nv is None else nv.data_ptr(), self.T, M, float(gamma), float(lam),
-                              self.advantage.data_ptr(), self.td_target.data_ptr(),
-                              None if partials is None else partials.data_ptr(),
-                              torch.cuda.current_stream(self.device).cuda_stream)
+        if nv is not None and (tuple(nv.shape) != (self.T, self.N, self.n_agents) or nv.dtype != torch.float32 or nv.device != self.device):
+            raise ValueError(f"next_value must be float32 [{self.T}, {self.N}, {self.n_agents}] on {self.device}")
+        with torch.cuda.device(self.device):  # launch on the storage's device, whatever the caller's current device is
+            rc = self._lib.qr_gae(self.reward.data_ptr(), self.done.data_ptr(), self.value.data_ptr(),
+                                  None if nv is None else nv.data_ptr(), self.T, M, float(gamma), float(lam),
+                                  self.advantage.data_ptr(), self.td_target.data_ptr(),
+                                  None if partials is None else partials.data_ptr(),
+                                  torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(rc, "qr_gae")
         if not want_stats:
             return self.advantage, self.td_target
@@ -143,7 +186,12 @@ class RolloutStorage:
         T, N = self.T, self.N
         flat = lambda x: x.reshape(T * N, -1)
         obs = [flat(o[:-1]) for o in self.obs]
-        obs_next = [flat(o[1:]) for o in self.obs]
+        obs_next = [o[1:].clone() for o in self.obs]
+        if self.final_obs is not None:  # the true next observation of transitions that ended an episode
+            idx = self.reset_mask().nonzero(as_tuple=True)
+            for k, f in enumerate(self.final_obs):
+                obs_next[k][idx] = f[idx]
+        obs_next = [flat(o) for o in obs_next]
         act = [flat(a) for a in self.act]
         logp = [flat(l) for l in self.logprob]
         rwd = [flat(self.reward[..., k:k + 1]) for k in range(self.n_agents)]

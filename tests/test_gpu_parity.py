@@ -690,3 +690,133 @@ def test_production_mode_1000_steps_every_episode_vs_oracle(kind):
     print(f"production mode {kind}: {episodes} episodes, worst in-episode state error {worst_state:.2e}, reward {worst_rwd:.2e}, threshold ties {ties}")
     assert episodes > 2000 and ties <= 3
     assert worst_state <= 2e-6 and worst_rwd <= 2e-5
+
+
+@pytest.mark.parametrize("kind,n", [("quad", 65536), ("decoupled", 32768)])
+def test_headline_size_auto_reset_sampled_envs_vs_oracle(kind, n):
+    """The headline instantiation at the headline size (BASELINE.json configs[1]: Quad-v0, 65 536 envs; configs[3]'s
+    per-GPU share: DecoupledWrapper, 32 768 envs) in the mode the bench times: default layout, 1 substep, in-launch
+    auto-reset, randomised parameters, 200 steps.  512 sampled envs are followed by the oracle through every
+    episode (it steps from its own state and adopts the GPU's only where a new episode starts); size-independent
+    properties are checked on the whole batch."""
+    T, m = 200, 512
+    rng = np.random.default_rng(99 + n)
+    A = orc.ACTION_DIM[kind]
+    env = _env(kind, n, seed=17, auto_reset=True, obs_rows=True)
+    assert env.layout == "mixed" and env.substeps == 1 and env.use_UDM
+    env.reset("train")
+    if kind != "quad":
+        env.get_norm_error_state()
+    idx = np.sort(rng.choice(n, m, replace=False))
+    idx_t = torch.from_numpy(idx).cuda()
+    s = _np(env.get_current_state())[idx]
+    params = _np(env.params).astype(np.float64)[idx]
+    integ = _np(env.integ).astype(np.float64)[idx] if kind != "quad" else np.zeros((m, 8))
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    worst_state = worst_rwd = 0.0
+    episodes = ties = total_done = 0
+    for t in range(T):
+        act = torch.rand(n, A, device="cuda", generator=g) * 2 - 1
+        obs, rwd, done, _, _ = env.step(act)
+        total_done += int(done.any(1).sum())
+        a_s = _np(act[idx_t]).astype(np.float64)
+        o = orc.step_batch(kind, s, a_s, params, None, integ)
+        g_state = _np(env.get_current_state()[idx_t])
+        g_done, g_rwd = _np(done[idx_t]), _np(rwd[idx_t])
+        mism = (g_done != o["done"]).any(1)
+        ties += int(mism.sum())
+        ended = g_done.any(1)
+        keep = ~ended & ~mism
+        worst_state = max(worst_state, grouped_rel_err(g_state[keep], o["state"][keep]))
+        worst_rwd = max(worst_rwd, np.abs(g_rwd[~mism] - o["reward"][~mism]).max())
+        s, integ = o["state"], o["integ"]
+        adopt = ended | mism
+        if adopt.any():
+            s[adopt] = g_state[adopt]
+            params[adopt] = _np(env.params[idx_t]).astype(np.float64)[adopt]
+            if kind != "quad":
+                integ[adopt] = _np(env.integ[idx_t]).astype(np.float64)[adopt]
+            episodes += int(ended.sum())
+    print(f"{kind} {n} envs, auto-reset, {T} steps: {episodes} sampled episodes, worst in-episode state error {worst_state:.2e}, "
+          f"reward {worst_rwd:.2e}, threshold ties {ties}, done rate {total_done / (n * T):.4f}")
+    assert episodes > 500 and ties <= 3
+    assert worst_state <= 2e-6 and worst_rwd <= 2e-5
+    # whole batch
+    full = _np(env.get_current_state())
+    assert np.isfinite(full).all()
+    R = np.swapaxes(full[:, 6:15].reshape(n, 3, 3), 1, 2)
+    assert np.abs(np.swapaxes(R, 1, 2) @ R - np.eye(3)).max() < 1e-12
+    r, d = _np(rwd), _np(done)
+    assert (r[d] == -1.0).all() and ((r[~d] >= 0) & (r[~d] <= 1)).all()
+    assert 0.003 < total_done / (n * T) < 0.05                                   # random actions: ~1 % of the envs end per step
+    assert int(env._episode.sum()) == n + total_done                              # one explicit reset + every in-launch one
+    assert bool((env._reset_count == T).all())
+    p = _np(env.params) / orc.NOMINAL_PARAMS - 1.0
+    assert (np.abs(p) <= np.array([0.1, 0.1, 0.1, 0.1, 0.1, 0.05]) * (1 + 1e-6)).all() and p.std(0).min() > 0.02
+    # in regime: an env that left the arena was re-sampled in that very step
+    assert np.abs(full[:, 0:3]).max() < 1.0 and np.abs(full[:, 3:6]).max() < 4.0
+
+
+def test_long_episode_integrators_into_the_clip():
+    """A 4000-step CoupledWrapper episode (the reference's episode cap, args_parse.py:16) with a goal offset that
+    drives both integral terms far into their +-3 clip: the device holds the trapezoid integrators
+    (quad_utils.py:38-63) as float32 words, the reference in float64 — after 4000 steps they still agree to 1e-5."""
+    n, T = 16, 4000
+    rng = np.random.default_rng(8)
+    env = _env("coupled", n, use_UDM=False, obs_rows=True)
+    s0 = np.zeros((n, 18)); s0[:, 6] = s0[:, 10] = s0[:, 14] = 1.0
+    s0[:, 0:3] = rng.uniform(-0.2, 0.2, (n, 3))
+    env.set_state(s0, integ=np.zeros((n, 8)))
+    goal = np.tile(orc.DEFAULT_GOAL, (n, 1))
+    goal[:, 0:3] = s0[:, 0:3] - rng.uniform(0.15, 0.35, (n, 3)) * np.sign(rng.uniform(-1, 1, (n, 3)))
+    psi = rng.uniform(0.3, 0.8, n) * np.sign(rng.uniform(-1, 1, n))
+    goal[:, 6], goal[:, 7] = np.cos(psi), np.sin(psi)
+    goal = goal.astype(np.float32).astype(np.float64)
+    _set_goal(env, goal)
+    env.get_norm_error_state()
+    a0 = (env.m_nominal * env.g / 4.0 - env.avrg_act) / env.scale_act        # hover thrust, no torque: stays aloft
+    acts = np.zeros((T, n, 4), np.float32)
+    acts[:, :, 0] = a0 + 0.01 * rng.uniform(-1, 1, (T, n))
+    ro = env.rollout(torch.from_numpy(acts).cuda())
+    s, integ = s0.copy(), np.zeros((n, 8))
+    o = orc.error_obs_batch("coupled", s, goal, integ)
+    integ = o["integ"]
+    clipped = 0
+    for t in range(T):
+        o = orc.step_batch("coupled", s, acts[t].astype(np.float64), None, goal, integ)
+        s, integ = o["state"], o["integ"]
+        if t % 500 == 499 or t == T - 1:
+            got = _np(ro["obs"][t]).astype(np.float64)
+            ref = o["obs"][0].astype(np.float64)
+            assert np.abs(got - ref).max() <= 2e-5
+            clipped = max(clipped, int((np.abs(ref[:, 3:6]) == 1.0).sum() + (np.abs(ref[:, 19]) == 1.0).sum()))
+    gi = _np(env.integ).astype(np.float64)
+    err = np.abs(gi - integ) / np.maximum(np.abs(integ), 1.0)
+    print(f"4000-step episode: integrators up to {np.abs(integ[:, [0, 1, 2, 6]]).max():.2f} (clip 3), worst relative error {err.max():.2e}, "
+          f"{clipped} clipped observation entries at the end")
+    assert np.abs(integ[:, 0:3]).max() > 4.0 and np.abs(integ[:, 6]).max() > 4.0   # far beyond the clip
+    assert clipped >= n
+    assert err.max() <= 1e-5
+    assert grouped_rel_err(_np(env.get_current_state()), s) <= 1e-5
+
+
+def test_set_state_rejects_rows_without_a_nearest_rotation():
+    """det R <= 0 (a reflection) or non-finite attitude entries have no nearest rotation: qr_set_state leaves those
+    envs untouched, counts them, and the host wrapper raises; every other env is still updated."""
+    n = 200
+    env = _env("quad", n, layout="f64")
+    env.reset("train")
+    before = _np(env.get_current_state())
+    s = before.copy()
+    s[:, 0] += 0.125
+    bad = np.zeros(n, bool)
+    bad[[3, 77, 199]] = True
+    s[3, 6:15] = np.diag([1.0, 1.0, -1.0]).T.reshape(9)          # reflection: det = -1
+    s[77, 6:15] = 0.0                                             # singular
+    s[199, 8] = np.nan
+    with pytest.raises(ValueError, match="3 row"):
+        env.set_state(s)
+    after = _np(env.get_current_state())
+    assert np.array_equal(after[bad], before[bad])                # rejected rows: previous state kept
+    assert np.allclose(after[~bad, 0], s[~bad, 0]) and np.isfinite(after).all()
+    env.set_state(s, mask=torch.from_numpy(~bad).cuda())          # masked out: not looked at

@@ -308,16 +308,19 @@ def test_bench_multi_rank_control_flow():
     else — env sharding by rank, barrier-bracketed timing, MAX over ranks, rank-0 JSON — is the
     path the 2/4/8-GPU runs take."""
     import json
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
     env = dict(os.environ, QR_BENCH_BACKEND="gloo", PYTHONPATH=ROOT)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "200", "--warmup", "10",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "200", "--warmup", "10",
                         "--extras", "0"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                   # rank 0 only
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2 * d["config"]["envs_per_gpu"] and d["scaling"] == "weak"
-    assert d["value"] > 1e9 and abs(d["value"] - d["config"]["global_envs"] * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-3 * d["value"]
+    assert d["value"] > 1e9 and abs(d["value"] - d["config"]["global_envs"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d                           # N = 1 only
 
 
@@ -330,3 +333,54 @@ def test_readme_quick_start_runs():
     torch.cuda.synchronize()
     assert ns["obs"].shape == (65536, 23) and ns["horizon"]["action"].shape == (32, 65536, 4)
     assert torch.isfinite(ns["horizon"]["obs0"]).all()
+
+
+@pytest.mark.gpu
+def test_bench_runs_over_rccl_with_one_rank():
+    """The RCCL code path of the multi-GPU bench on a 1-GPU box: bench.py under torch.distributed.run with ONE rank and
+    QR_BENCH_FORCE_DIST=1 initialises the `nccl` process group with device_id, takes the barriers and the device-side
+    all_reduce(MAX) of the timed runs, and reports the world size RCCL saw."""
+    import json
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ, QR_BENCH_FORCE_DIST="1", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "50", "--warmup", "5",
+                        "--extras", "0", "--cpu-seconds", "0"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["n_ranks_rccl"] == 1 and d["n_gpus"] == 1 and d["value"] > 1e9
+    assert abs(d["value"] - d["config"]["global_envs"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]   # one clock
+    assert abs(d["roofline"]["avg_launch_us"] - d["ms_per_step"] * 1e3) < 1e-9
+
+
+_NCCL_GATHER = """
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from gym_rotor_amd import all_gather_rows, QuadVecEnv, RolloutStorage
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+x = torch.arange(3 * 1000, dtype=torch.float32, device="cuda").reshape(3, 1000)
+y = all_gather_rows(x, 1000)                      # RCCL all_gather, world of one
+assert torch.equal(x, y) and y.data_ptr() != x.data_ptr()
+adv = torch.randn(8, 1000, 2, device="cuda")
+a64 = adv.double()
+stats = torch.cat([torch.stack([a64.sum((0, 1)), (a64 * a64).sum((0, 1))], 1), torch.full((2, 1), 8000.0, dtype=torch.float64, device="cuda")], 1)
+nrm = RolloutStorage.normalize(adv, stats)        # RCCL all_reduce of the 3 x n_agents doubles
+ref = (adv - adv.mean((0, 1))) / (adv.reshape(-1, 2).std(0) + 1e-4)
+assert torch.allclose(nrm, ref, atol=1e-5)
+dist.barrier(); dist.destroy_process_group(); print("ok")
+"""
+
+
+@pytest.mark.gpu
+def test_learner_side_collectives_over_rccl(tmp_path):
+    """all_gather_rows and the normalisation-statistics all_reduce on the `nccl` (= RCCL) backend, world of one rank."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    script = tmp_path / "g.py"
+    script.write_text(_NCCL_GATHER.format(root=ROOT, port=port))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

@@ -100,7 +100,75 @@ def test_rollout_storage_with_env(kind):
     obs, act, rwd, obs_next, done, logp = st.sample()
     assert len(obs) == e1.n_agents and obs[0].shape == (T * N, e1.obs_dims[0]) and rwd[0].shape == (T * N, 1)
     assert act[0].shape[1] == st.action_dims[0] and done[0].dtype == torch.float32 and logp[0].shape == act[0].shape
-    assert torch.equal(obs_next[0][: (T - 1) * N], obs[0][N:])
+    keep = ~st.reset_mask()[: T - 1].reshape(-1)               # obs_next is obs[t+1] except where an episode ended
+    assert torch.equal(obs_next[0][: (T - 1) * N][keep], obs[0][N:][keep])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["coupled", "decoupled", "quad"])
+def test_final_observation_and_bootstrap_values(kind):
+    """Same-step auto-reset overwrites the observation of a finished episode with the new episode's first one;
+    the step kernel keeps the terminal observation in QrStepOut.final_obs* for exactly those envs.  Checked
+    against a twin env WITHOUT auto-reset that is loaded with the same pre-step state every step (its
+    observation IS the terminal one).  RolloutStorage.next_values then gives the reference's V(obs_next)
+    (main.py:163-178, ppo.py:128-138) — also for a time-limit truncation and for the MODUL agent that did not
+    terminate — and compute_gae(next_value=...) matches the oracle fed with the true next observations."""
+    from gym_rotor_amd import QuadVecEnv, RolloutStorage
+    N, T = 2048, 48
+    kw = dict(device="cuda", seed=4, max_episode_steps=20, obs_rows=True)
+    env = QuadVecEnv(kind, N, auto_reset=True, **kw)
+    ref = QuadVecEnv(kind, N, auto_reset=False, **kw)
+    env.reset("train"); ref.reset("train")
+    st = RolloutStorage(env, T)
+    assert st.final_obs is not None
+    first = env.get_norm_error_state() if kind != "quad" else env.get_current_state().float()
+    st.set_initial_obs(first)
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    ws = [torch.randn(d, device="cuda", generator=g) for d in env.obs_dims]
+    if kind == "quad":
+        ws = [ws[0]]
+
+    def critic(rows):  # one value per agent: a fixed map of that agent's observation
+        rows = [rows] if isinstance(rows, torch.Tensor) else list(rows)
+        cols = [torch.tanh(r @ w) for r, w in zip(rows, ws)]
+        return torch.stack(cols, 1) if len(cols) == env.n_agents else cols[0][:, None].expand(-1, env.n_agents).contiguous()
+
+    true_next = [torch.zeros(T, N, d, device="cuda") for d in env.obs_dims]
+    n_reset = n_trunc = n_other_agent = 0
+    for t in range(T):
+        a = torch.rand(N, env.action_dim, device="cuda", generator=g) * 2 - 1
+        ref.load_state_dict({k: v for k, v in env.state_dict().items() if k != "last_obs"})
+        env.step(a, out=st.slot(t))
+        o_ref, _, d_ref, t_ref, _ = ref.step(a)
+        o_ref = [o_ref] if isinstance(o_ref, torch.Tensor) else list(o_ref)
+        reset = st.done[t].any(-1) | st.truncated[t]
+        assert torch.equal(st.done[t], d_ref) and torch.equal(st.truncated[t], t_ref)
+        n_reset += int(reset.sum()); n_trunc += int((st.truncated[t] & ~st.done[t].any(-1)).sum())
+        n_other_agent += int((reset[:, None] & ~st.done[t]).sum()) if env.n_agents > 1 else 0
+        for k, o in enumerate(o_ref):
+            assert torch.equal(st.final_obs[k][t][reset], o[reset])          # terminal observation, bit for bit
+            assert torch.equal(st.obs[k][t + 1][~reset], o[~reset])          # everyone else: the plain next observation
+            true_next[k][t] = o
+    assert n_reset > 200 and n_trunc > 0
+    if kind == "decoupled":
+        assert n_other_agent > 0                                             # an agent cut off by the other one's termination
+    for t in range(T + 1):
+        st.value[t] = critic([o[t] for o in st.obs])
+    nv = st.next_values(critic)
+    nv_true = torch.stack([critic([o[t] for o in true_next]) for t in range(T)])
+    assert torch.equal(nv, nv_true)
+    adv, tgt = st.compute_gae(0.99, 0.9, next_value=nv, want_stats=False)
+    M = N * env.n_agents
+    a_ref, t_ref = go.gae(st.reward.cpu().numpy().reshape(T, M), st.done.cpu().numpy().reshape(T, M),
+                          st.value[:-1].cpu().numpy().reshape(T, M), nv_true.cpu().numpy().reshape(T, M), 0.99, 0.9)
+    assert np.abs(adv.cpu().numpy().reshape(T, M) - a_ref).max() <= 2e-6 * max(1, np.abs(a_ref).max())
+    # bootstrapping from value[t+1] instead is visibly different on the rows that ended an episode without `done`
+    a_naive, _ = go.gae(st.reward.cpu().numpy().reshape(T, M), st.done.cpu().numpy().reshape(T, M),
+                        st.value[:-1].cpu().numpy().reshape(T, M), st.value[1:].cpu().numpy().reshape(T, M), 0.99, 0.9)
+    assert np.abs(a_naive - a_ref).max() > 1e-2
+    obs, act, rwd, obs_next, done, logp = st.sample()
+    for k in range(len(env.obs_dims)):
+        assert torch.equal(obs_next[k], true_next[k].reshape(T * N, -1))
 
 
 _GLOO = textwrap.dedent("""
