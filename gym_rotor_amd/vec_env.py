@@ -224,6 +224,11 @@ class QuadVecEnv:
         o.obs0, o.obs1, o.reward, o.reward_raw = _ptr(self._obs0), _ptr(self._obs1), _ptr(self._reward), _ptr(self._reward_raw)
         o.done, o.truncated = _ptr(self._done), (_ptr(self._trunc) if self._steps is not None else None)
         o.final_obs0, o.final_obs1 = _ptr(self._final0), _ptr(self._final1)
+        # the same QrEnv scalars / QrCoeffs as plain Python values, for the torch custom ops (torch_ops.env_args):
+        # [kind, layout, flags, seed, env_offset, goal_mode, max_episode_steps]
+        self._op_cfg = [int(e.kind), int(e.layout), int(e.flags), int(self.seed) & (2 ** 63 - 1), int(self.env_offset),
+                        int(e.goal_mode), int(self.max_episode_steps)]
+        self._op_coeffs = [float(getattr(e.coeffs, n)) for n, _ in _lib.QrCoeffs._fields_]
 
     def _stream(self):
         # kernels are launched on the env's device: make it current for the call if it is not
@@ -420,6 +425,7 @@ class QuadVecEnv:
         if seed is not None:
             self.seed = int(seed)
             self._cenv.seed = self.seed & (2 ** 64 - 1)
+            self._op_cfg[3] = self.seed & (2 ** 63 - 1)
         m = None
         if mask is not None:
             if mask.shape != (self.num_envs,) or mask.device != self.device:

@@ -248,7 +248,7 @@ def test_all_gather_rows_single_process_is_identity():
 
 def test_torch_custom_ops_are_registered():
     import gym_rotor_amd  # noqa: F401
-    for name in ("qr_step", "qr_reset", "qr_gae"):
+    for name in ("qr_step", "qr_rollout", "qr_rollout_actor", "qr_error_obs", "qr_reset", "qr_get_state", "qr_set_state", "qr_gae"):
         assert hasattr(torch.ops.gym_rotor_amd, name)
     with pytest.raises(RuntimeError, match="GPU only"):
         torch.ops.gym_rotor_amd.qr_gae(torch.zeros(2, 3), torch.zeros(2, 3, dtype=torch.bool), torch.zeros(3, 3), 0.9, 0.9,
