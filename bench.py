@@ -330,9 +330,9 @@ def main():
         launch_us = ms_per_step * 1e3
         wall_ms_per_step = med_wall / (a.steps * copies + n_lead)
         algo = ALGO_BYTES[a.kind] + ALGO_BYTES_PARAMS
-        # bytes this layout really moves per env-step: 13-word state r/w, action, [integ r/w, obs rows],
+        # bytes this layout really moves per env-step: 12-word state r/w (x, v, smallest-three quaternion, W), action, [integ r/w, obs rows],
         # reward, done, params
-        state_b = {"mixed": 6 * 4 + 7 * 8, "f64": 13 * 8, "f32": 13 * 4}[a.layout] * 2
+        state_b = {"mixed": 6 * 4 + 6 * 8, "f64": 12 * 8, "f32": 12 * 4}[a.layout] * 2
         layout = state_b + {"quad": 16 + 4 + 1 + 24, "coupled": 16 + 64 + 92 + 4 + 1 + 24,
                             "decoupled": 20 + 64 + 72 + 8 + 2 + 24}[a.kind]
         achieved = algo * N / (launch_us * 1e-6) / 1e9

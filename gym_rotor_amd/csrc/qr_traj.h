@@ -165,30 +165,92 @@ struct SoA {
   }
 };
 
+// ---- attitude in memory: "smallest three" ---------------------------------------------------
+// The step is bound by bytes, so the unit quaternion is stored as THREE components: the one of
+// largest magnitude is dropped (and made positive: q and -q are the same rotation) and rebuilt on
+// load as sqrt(1 - k0^2 - k1^2 - k2^2) >= 1/2, which amplifies rounding by at most sqrt(3).  Which
+// component was dropped (2 bits) rides in the two lowest mantissa bits of k0 — a 4e-16 (float64)
+// perturbation.  -8 B read and -8 B written per env-step (-16 of 205 in the default layout).
+// A K-step rollout keeps the state in registers, so every env-step ends with pack -> unpack: what the
+// registers then hold is exactly what a single-step launch would have stored and re-loaded.
+template <typename T>
+struct QuatPack { T k[3]; };
+
+template <typename T>
+__device__ __forceinline__ void pack_quat(const T (&q)[4], QuatPack<T>& p) {
+  using U = typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type;
+  const T a0 = fabs(q[0]), a1 = fabs(q[1]), a2 = fabs(q[2]), a3 = fabs(q[3]);
+  const bool b01 = a1 > a0, b23 = a3 > a2;
+  const T m01 = b01 ? a1 : a0, m23 = b23 ? a3 : a2;
+  const bool hi = m23 > m01;
+  const int idx = hi ? (b23 ? 3 : 2) : (b01 ? 1 : 0);  // ties: the lowest index
+  const T d = hi ? (b23 ? q[3] : q[2]) : (b01 ? q[1] : q[0]);
+  const T k0 = idx == 0 ? q[1] : q[0], k1 = idx <= 1 ? q[2] : q[1], k2 = idx <= 2 ? q[3] : q[2];
+  const bool flip = d < T(0);
+  p.k[0] = flip ? -k0 : k0; p.k[1] = flip ? -k1 : k1; p.k[2] = flip ? -k2 : k2;
+  p.k[0] = __builtin_bit_cast(T, (__builtin_bit_cast(U, p.k[0]) & ~U(3)) | U(idx));
+}
+
+template <typename T>
+__device__ __forceinline__ void unpack_quat(const QuatPack<T>& p, T (&q)[4]) {
+  using U = typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type;
+  const U bits = __builtin_bit_cast(U, p.k[0]);
+  const int idx = (int)(bits & U(3));
+  const T k0 = __builtin_bit_cast(T, bits & ~U(3)), k1 = p.k[1], k2 = p.k[2];
+  const T s = fmaT(-k2, k2, fmaT(-k1, k1, fmaT(-k0, k0, T(1))));  // in [1/4, 1] for a unit quaternion
+  T w;
+  if constexpr (sizeof(T) == 8) {  // sqrt(s) = s rsqrt(s): hardware seed, two Newton steps, one correction of the product
+    double r = __builtin_amdgcn_rsq(s);
+    r = r * fma(-0.5 * s, r * r, 1.5);
+    r = r * fma(-0.5 * s, r * r, 1.5);
+    w = s * r;
+    w = fma(0.5 * r, fma(-w, w, s), w);
+  } else {
+    float r = __builtin_amdgcn_rsqf(s);
+    r = r * fmaf(-0.5f * s, r * r, 1.5f);
+    w = s * r;
+    w = fmaf(0.5f * r, fmaf(-w, w, s), w);
+  }
+  q[0] = idx == 0 ? w : k0;
+  q[1] = idx == 1 ? w : (idx == 0 ? k0 : k1);
+  q[2] = idx == 2 ? w : (idx == 3 ? k2 : k1);
+  q[3] = idx == 3 ? w : k2;
+}
+
 template <typename XV, typename QW>
 __device__ __forceinline__ void load_state(const Args& a, int64_t first64, unsigned lane, Work<QW, XV>& w) {
   const SoA<XV> pv(a.pos_vel, 6, a.ld);
-  const SoA<QW> ar(a.att_rate, 7, a.ld);
+  const SoA<QW> ar(a.att_rate, 6, a.ld);
   const unsigned first = (unsigned)first64;
+  QuatPack<QW> p;
 #pragma unroll
-  for (int f = 0; f < 4; ++f) w.q[f] = ar.load(f, first, lane);
+  for (int f = 0; f < 3; ++f) p.k[f] = ar.load(f, first, lane);
 #pragma unroll
-  for (int f = 0; f < 3; ++f) w.W[f] = ar.load(4 + f, first, lane);
+  for (int f = 0; f < 3; ++f) w.W[f] = ar.load(3 + f, first, lane);
 #pragma unroll
   for (int f = 0; f < 3; ++f) { w.x[f] = pv.load(f, first, lane); w.v[f] = pv.load(3 + f, first, lane); }
+  unpack_quat(p, w.q);
+}
+
+// (the packed attitude is passed in: the step kernel forms it once per env-step, see QuatPack)
+template <typename XV, typename QW>
+__device__ __forceinline__ void store_state(const Args& a, int64_t first64, unsigned lane, const Work<QW, XV>& w, const QuatPack<QW>& p) {
+  const SoA<XV> pv(a.pos_vel, 6, a.ld);
+  const SoA<QW> ar(a.att_rate, 6, a.ld);
+  const unsigned first = (unsigned)first64;
+#pragma unroll
+  for (int f = 0; f < 3; ++f) ar.store(f, first, lane, p.k[f]);
+#pragma unroll
+  for (int f = 0; f < 3; ++f) ar.store(3 + f, first, lane, w.W[f]);
+#pragma unroll
+  for (int f = 0; f < 3; ++f) { pv.store(f, first, lane, w.x[f]); pv.store(3 + f, first, lane, w.v[f]); }
 }
 
 template <typename XV, typename QW>
 __device__ __forceinline__ void store_state(const Args& a, int64_t first64, unsigned lane, const Work<QW, XV>& w) {
-  const SoA<XV> pv(a.pos_vel, 6, a.ld);
-  const SoA<QW> ar(a.att_rate, 7, a.ld);
-  const unsigned first = (unsigned)first64;
-#pragma unroll
-  for (int f = 0; f < 4; ++f) ar.store(f, first, lane, w.q[f]);
-#pragma unroll
-  for (int f = 0; f < 3; ++f) ar.store(4 + f, first, lane, w.W[f]);
-#pragma unroll
-  for (int f = 0; f < 3; ++f) { pv.store(f, first, lane, w.x[f]); pv.store(3 + f, first, lane, w.v[f]); }
+  QuatPack<QW> p;
+  pack_quat(w.q, p);
+  store_state<XV, QW>(a, first64, lane, w, p);
 }
 
 template <typename T, typename X>

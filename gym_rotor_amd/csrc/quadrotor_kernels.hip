@@ -226,6 +226,8 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   bool params_dirty = false;
   bool traj_dirty = false;  // this lane started a new episode: its generator state changed
   bool stored_early = false;  // (SINGLE) this lane's state went out before its wave sampled a reset pool
+  QuatPack<T> qp;             // attitude in its storage form, formed once per env-step
+  qp.k[0] = qp.k[1] = qp.k[2] = T(0);
 
   // POLICY: the observation the next action is computed from (rows -> lane registers once, then
   // carried from step to step)
@@ -309,6 +311,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 
 #if QR_ABLATE == 2  // measurement build: memory traffic only (no integration)
     w.x[0] += X(act[0]);
+    pack_quat(w.q, qp);
 #else
     // ---- goal for this step from the pre-step state (main.py:145-147) ----
     if constexpr (TRAJ) {
@@ -343,6 +346,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       integrate(w.x, w.v, w.q, w.W, dyn, nsub, T(c.dt) * recip(T(nsub)));
     }
     renorm_quat(w.q);
+    pack_quat(w.q, qp);  // the attitude as it is stored (qr_traj.h: QuatPack)
     QR_STAMP(3, (float)w.q[0] + (float)w.x[0] + (float)w.v[2] + (float)w.W[0]);
 #endif
 
@@ -446,7 +450,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         // This wave is about to spend ~0.5 us sampling episode starts.  The state of its lanes that do NOT
         // reset is final: hand it to the memory system first, so that those stores drain meanwhile.
         if (active && !need_reset) {
-          store_state<XV, QW>(a, first, lane, w);
+          store_state<XV, QW>(a, first, lane, w, qp);
           if (KIND != QR_KIND_QUAD) {
             const SoA<float> integ(a.integ, 8, L);
 #pragma unroll
@@ -510,6 +514,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
           for (int f = 0; f < 8; ++f) w.integ[f] = 0.0f;
           error_obs<KIND, T, X>(w, R, c, o0, o1);  // first observation of the new episode (main.py:226-230)
         }
+        pack_quat(w.q, qp);
       }
     }
     have_pool = false;  // the speculative pool belongs to step 0's counter value
@@ -538,12 +543,13 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 #pragma unroll
       for (int j = 0; j < D1; ++j) po1[j] = o1[j];
     }
+    if constexpr (!SINGLE) unpack_quat(qp, w.q);  // the next env-step starts from what a single-step launch would have re-loaded
   }
 
   // ---- write the working set back ----
   if (active) {
     if (!(SINGLE && stored_early)) {
-      store_state<XV, QW>(a, first, lane, w);
+      store_state<XV, QW>(a, first, lane, w, qp);
       if (KIND != QR_KIND_QUAD) {
         const SoA<float> integ(a.integ, 8, L);
 #pragma unroll

@@ -46,6 +46,17 @@ except AttributeError:  # pragma: no cover - older/newer torch without the priva
         return torch.cuda.current_device()
 
 
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_CTX = _NullCtx()
+
+
 def _field_stride(n: int) -> int:
     """Elements between consecutive fields of the SoA buffers: N rounded up to a multiple of 4.
     (Padding the stride off powers of two was measured on MI355X and makes no difference: the
@@ -152,8 +163,8 @@ class QuadVecEnv:
         xv_dt = torch.float64 if layout == "f64" else torch.float32
         qw_dt = torch.float32 if layout == "f32" else torch.float64
         self._pos_vel = self._soa(6, xv_dt)     # x(3), v(3)
-        self._att_rate = self._soa(7, qw_dt)    # q(w,x,y,z), W(3)
-        self._att_rate[0].fill_(1.0)
+        self._att_rate = self._soa(6, qw_dt)    # the 3 smaller components of q (index of the dropped one in k0's low bits), W(3):
+        #                                         all zeros = identity attitude at rest
         self._integ = None if kind == "quad" else self._soa(8, torch.float32)
         self._params = None
         if self.use_UDM:
@@ -231,11 +242,13 @@ class QuadVecEnv:
         self._op_coeffs = [float(getattr(e.coeffs, n)) for n, _ in _lib.QrCoeffs._fields_]
 
     def _stream(self):
-        # kernels are launched on the env's device: make it current for the call if it is not
-        idx = self.device.index
-        if _get_device() != idx:
-            torch.cuda.set_device(self.device)
-        return _raw_stream(idx)
+        """Raw handle of torch's current stream on the env's device (the launch stream)."""
+        return _raw_stream(self.device.index)
+
+    def _on_device(self):
+        """Context for a launch: kernels run on the env's device; if another device is current it is made current
+        for the call only and restored afterwards (the process-wide current device is not left changed)."""
+        return _NULL_CTX if _get_device() == self.device.index else torch.cuda.device(self.device)
 
     def _check_actions(self, actions: torch.Tensor, lead=()):
         if not isinstance(actions, torch.Tensor):
@@ -299,7 +312,8 @@ class QuadVecEnv:
         caller-owned contiguous tensors, e.g. slices of a [T, N, ...] rollout buffer."""
         a = self._check_actions(actions)
         if out is None:
-            rc = self._lib.qr_step(C.byref(self._cenv), a.data_ptr(), self.substeps, C.byref(self._cout), self._stream())
+            with self._on_device():
+                rc = self._lib.qr_step(C.byref(self._cenv), a.data_ptr(), self.substeps, C.byref(self._cout), self._stream())
             _lib.check(rc, "qr_step")
             self._last_obs = self._obs()
             return self._last_obs, self._reward, self._done, self._trunc, {}
@@ -309,7 +323,8 @@ class QuadVecEnv:
         o.reward_raw, o.done = _ptr(out.get("reward_raw")), _ptr(out["terminated"])
         o.truncated = _ptr(out.get("truncated")) if self._steps is not None else None
         o.final_obs0, o.final_obs1 = _ptr(out.get("final_obs0")), _ptr(out.get("final_obs1"))
-        rc = self._lib.qr_step(C.byref(self._cenv), a.data_ptr(), self.substeps, C.byref(o), self._stream())
+        with self._on_device():
+            rc = self._lib.qr_step(C.byref(self._cenv), a.data_ptr(), self.substeps, C.byref(o), self._stream())
         _lib.check(rc, "qr_step")
         obs = out.get("obs0") if "obs1" not in out else (out["obs0"], out["obs1"])
         self._last_obs = obs
@@ -337,7 +352,8 @@ class QuadVecEnv:
         o.reward_raw, o.done = _ptr(out.get("reward_raw")), _ptr(out["terminated"])
         o.truncated = _ptr(out["truncated"]) if self._steps is not None else None
         o.final_obs0, o.final_obs1 = _ptr(out.get("final_obs0")), _ptr(out.get("final_obs1"))
-        rc = self._lib.qr_rollout(C.byref(self._cenv), a.data_ptr(), T, self.substeps, C.byref(o), self._stream())
+        with self._on_device():
+            rc = self._lib.qr_rollout(C.byref(self._cenv), a.data_ptr(), T, self.substeps, C.byref(o), self._stream())
         _lib.check(rc, "qr_rollout")
         out["obs"] = out["obs0"] if self._obs1 is None else (out["obs0"], out["obs1"])
         if out["obs0"] is not None:
@@ -407,7 +423,8 @@ class QuadVecEnv:
         o.reward_raw, o.done = _ptr(out.get("reward_raw")), _ptr(out["terminated"])
         o.truncated = _ptr(out["truncated"]) if self._steps is not None else None
         o.final_obs0, o.final_obs1 = _ptr(out.get("final_obs0")), _ptr(out.get("final_obs1"))
-        rc = self._lib.qr_rollout_actor(C.byref(self._cenv), C.byref(pol), T, self.substeps, C.byref(o), self._stream())
+        with self._on_device():
+            rc = self._lib.qr_rollout_actor(C.byref(self._cenv), C.byref(pol), T, self.substeps, C.byref(o), self._stream())
         _lib.check(rc, "qr_rollout_actor")
         self._policy_steps += T
         self._last_obs = out["obs0"][T - 1] if len(self.obs_dims) == 1 else (out["obs0"][T - 1], out["obs1"][T - 1])
@@ -435,13 +452,15 @@ class QuadVecEnv:
         flags = self._cenv.flags
         self._cenv.flags = (flags & ~(_lib.FLAG_EVAL_RESET | _lib.FLAG_AUTO_RESET)) | (_lib.FLAG_EVAL_RESET if env_type == "eval" else 0)
         try:
-            rc = self._lib.qr_reset(C.byref(self._cenv), _ptr(m), self._stream())
+            with self._on_device():
+                rc = self._lib.qr_reset(C.byref(self._cenv), _ptr(m), self._stream())
         finally:
             self._cenv.flags = flags
         _lib.check(rc, "qr_reset")
         self._last_obs = None  # the rows of the previous episode are not this episode's observation
         if self.goal_mode is not None:  # main.py:226-227: reset, then mark_traj_start(state)
-            _lib.check(self._lib.qr_traj_start(C.byref(self._cenv), _ptr(m), None, self._stream()), "qr_traj_start")
+            with self._on_device():
+                _lib.check(self._lib.qr_traj_start(C.byref(self._cenv), _ptr(m), None, self._stream()), "qr_traj_start")
         return self.get_current_state().to(torch.float32)
 
     def get_norm_error_state(self, framework: Optional[str] = None):
@@ -450,7 +469,8 @@ class QuadVecEnv:
             raise RuntimeError("get_norm_error_state is defined for kind 'coupled'/'decoupled'")
         if framework is not None and framework != self.framework:
             raise ValueError(f"env kind {self.kind!r} produces {self.framework} observations, not {framework}")
-        rc = self._lib.qr_error_obs(C.byref(self._cenv), _ptr(self._obs0), _ptr(self._obs1), self._stream())
+        with self._on_device():
+            rc = self._lib.qr_error_obs(C.byref(self._cenv), _ptr(self._obs0), _ptr(self._obs1), self._stream())
         _lib.check(rc, "qr_error_obs")
         self._last_obs = self._obs()
         return [self._obs0] if self._obs1 is None else [self._obs0, self._obs1]
@@ -493,7 +513,8 @@ class QuadVecEnv:
                     3.0 * one if t_traj is None else torch.as_tensor(t_traj, dtype=torch.float32, device=self.device).expand(self.num_envs),
                     z if w_b1d is None else torch.as_tensor(w_b1d, dtype=torch.float32, device=self.device).expand(self.num_envs)]
             draws = torch.stack(cols).contiguous()
-        _lib.check(self._lib.qr_traj_start(C.byref(self._cenv), _ptr(m), _ptr(draws), self._stream()), "qr_traj_start")
+        with self._on_device():
+            _lib.check(self._lib.qr_traj_start(C.byref(self._cenv), _ptr(m), _ptr(draws), self._stream()), "qr_traj_start")
 
     def get_desired(self, store_goal: bool = False, mask: Optional[torch.Tensor] = None):
         """TrajectoryGenerator.get_desired(state, mode): (xd, vd, b1d, b1d_dot, Wd) as [N,3] views
@@ -506,14 +527,16 @@ class QuadVecEnv:
         if store_goal and self._goal is None:
             self._goal = self._soa(12, torch.float32)
             self._cenv.goal = self._goal.data_ptr()
-        _lib.check(self._lib.qr_get_desired(C.byref(self._cenv), _ptr(m), rows.data_ptr(), int(store_goal), self._stream()), "qr_get_desired")
+        with self._on_device():
+            _lib.check(self._lib.qr_get_desired(C.byref(self._cenv), _ptr(m), rows.data_ptr(), int(store_goal), self._stream()), "qr_get_desired")
         return rows[:, 0:3], rows[:, 3:6], rows[:, 6:9], rows[:, 9:12], rows[:, 12:15]
 
     def get_current_state(self) -> torch.Tensor:
         """quad.py:409-410: float64 [N,18] = (x, v, vec_F(R), W), rebuilt from the 13-word
         internal state (R = R(q)) by a small kernel; a fresh tensor each call."""
         rows = torch.empty(self.num_envs, 18, dtype=torch.float64, device=self.device)
-        _lib.check(self._lib.qr_get_state(C.byref(self._cenv), rows.data_ptr(), self._stream()), "qr_get_state")
+        with self._on_device():
+            _lib.check(self._lib.qr_get_state(C.byref(self._cenv), rows.data_ptr(), self._stream()), "qr_get_state")
         return rows
 
     def set_state(self, state, integ=None, params=None, mask=None):
@@ -528,7 +551,8 @@ class QuadVecEnv:
         if m is not None and tuple(m.shape) != (self.num_envs,):
             raise ValueError("mask must be a [num_envs] tensor")
         self._rejected.zero_()
-        _lib.check(self._lib.qr_set_state(C.byref(self._cenv), s.data_ptr(), _ptr(m), self._rejected.data_ptr(), self._stream()), "qr_set_state")
+        with self._on_device():
+            _lib.check(self._lib.qr_set_state(C.byref(self._cenv), s.data_ptr(), _ptr(m), self._rejected.data_ptr(), self._stream()), "qr_set_state")
         sel = None if m is None else m.bool()[None, :]
 
         def put(dst, rows):

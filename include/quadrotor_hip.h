@@ -19,12 +19,15 @@
  *     Caller-facing rows (actions in, observations/reward/done out) are AoS `[N][D]`
  *     row-major, i.e. what a policy network produces/consumes; the kernels transpose
  *     through LDS so that those rows are written with coalesced 16-byte stores.
- *   - INTERNAL STATE (13 words per env instead of the reference's 18): the step is
+ *   - INTERNAL STATE (12 words per env instead of the reference's 18): the step is
  *     HBM/fabric-bound, so the rotation is kept as a unit quaternion, which the kernel
  *     integrates directly (q' = q (0,W)/2 is the same flow as R' = R hat(W),
- *     quad.py:328):
+ *     quad.py:328) and stores as its THREE components of smaller magnitude ("smallest
+ *     three": the dropped one is made positive and rebuilt as sqrt(1 - sum of squares) >= 1/2;
+ *     its index rides in the two lowest mantissa bits of the first stored component):
  *         pos_vel  [6][N]  x(3), v(3)
- *         att_rate [7][N]  q = (w,x,y,z) with R = R(q), W(3)
+ *         att_rate [6][N]  k0, k1, k2 of q = (w,x,y,z) with R = R(q); W(3)
+ *     An all-zero att_rate is the identity attitude at rest.
  *     The reference's 18-vector (x, v, vec_F(R) column-major, W; quad.py:146,
  *     quad_utils.py:12-16) is produced / consumed by qr_get_state / qr_set_state.
  *   - precision (`layout`): QR_LAYOUT_MIXED (default) stores x,v as float32 and q,W as
@@ -121,7 +124,7 @@ typedef struct QrEnv {
                           reset_count of that tile, rank of the env among the tile's envs that reset in
                           that step) — see reset_count                                                */
   void*    pos_vel;    /* [6][N]  x, v                                         in/out      */
-  void*    att_rate;   /* [7][N]  q(w,x,y,z), W                                in/out      */
+  void*    att_rate;   /* [6][N]  q (smallest three), W                        in/out      */
   float*   integ;      /* [8][N]  eIx(3), g_x prev(3), eIb1, g_b prev (quad_utils.py:38-63); NULL for QUAD */
   float*   params;     /* [6][N]  m,d,J1(=J2),J3,c_tf,c_tw (quad.py:359-387); NULL = nominal */
   float*   goal;       /* [12][N] xd,vd,b1d,Wd (quad.py:413-418); NULL = hover default     */
