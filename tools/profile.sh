@@ -23,3 +23,6 @@ PY
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/calib_fetch" -- python3 /tmp/calib.py > "$OUT/calib_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/calib_write" -- python3 /tmp/calib.py > "$OUT/calib_write.log" 2>&1
 python3 "$ROOT/tools/summarize_profile.py" "$OUT" | tee "$OUT/summary.txt"
+# keep the per-kernel stats table, drop the raw per-dispatch traces (tens of MB per pass)
+f=$(find "$OUT/stats" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/kernel_stats.csv"
+rm -rf "$OUT/stats" "$OUT/fetch" "$OUT/write" "$OUT/calib_fetch" "$OUT/calib_write"
