@@ -29,10 +29,6 @@ struct Coeffs {
   float nom_f[6], g_f;
   // eight-shaped curve (trajectory_generator.py:98-110, 418-505)
   float e8_w1, e8_w2, e8_k, e8_A1, e8_A2, e8_wb, e8_alt, e8_tmax;
-  // in-launch reset pool (qr_rng.h): per role b = 0..4 of a slot, value_j = off_j + (zero-error ? scl_z_j : scl_j) * sym(word_j);
-  // rows [b][0..3] = off, [4..7] = scl, [8..11] = scl_z — for the reset mode of this call (train + UDM, train with nominal
-  // parameters, or eval: the host fills the table from the flags)
-  float role_tab[5][12];
 };
 
 struct ActorW {  // QrActor's tensors (torch.nn.Linear layout: weight [out][in])

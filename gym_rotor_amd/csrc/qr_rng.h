@@ -173,10 +173,10 @@ __device__ __forceinline__ void sample_reset(Work<T, X>& w, const Draws& d, bool
 // Philox block (4 words) AND turn it into its share of the episode start:
 //     b = 0: m, d, J1, J3      b = 1: c_tf, c_tw, x0, x1      b = 2: x2, v0, v1, v2
 //     b = 3: W0, W1, W2, zero-error branch      b = 4: yaw, roll, pitch -> unit quaternion; word 3 = goal-generator draws
-// so one pass is ~95 instructions of Philox + ~110 of sampling for up to 12 resets, issued right
-// after the wave's loads and run while they are in flight, when the SIMD has nothing else to do
-// (the per-lane scale / offset table of the roles is formed even before the tile counter has
-// arrived).  A lane that resets takes the slot given by its rank among the wave's resetting lanes
+// so one pass is ~95 instructions of Philox + ~110 of sampling for up to 12 resets, run by a wave
+// when one of its lanes resets (the per-lane scale / offset constants of the roles are formed at
+// the wave's start, under the latency of its loads).  A lane that resets takes the slot given by
+// its rank among the wave's resetting lanes
 // (ds_bpermute from lanes 5 * rank + b); ranks >= 12 (e.g. a time limit ending all 64 episodes at
 // once) draw further pools on demand (slots 12 p + s).  The tile's counter advances by one per
 // env-step, so no (tile, counter, slot) is ever used twice — also under hipGraph replay, because
@@ -187,16 +187,38 @@ struct PoolRole {  // per-lane constants of the lane's role: value_j = off_j + (
   float off[4], scl[4], scl_z[4];
 };
 
-// The role table is formed on the host (fill_pool_roles) and lives in the kernarg segment; a lane reads the
-// 12 constants of its role with three 16-byte loads, issued with the wave's first loads.
-__device__ __forceinline__ void pool_role(PoolRole& r, const float (*tab)[12]) {
+__device__ __forceinline__ float sel5(int b, float v0, float v1, float v2, float v3, float v4) {  // branch-free 5-way select
+  float v = v4;
+  v = b == 3 ? v3 : v;
+  v = b == 2 ? v2 : v;
+  v = b == 1 ? v1 : v;
+  v = b == 0 ? v0 : v;
+  return v;
+}
+
+// The lane's role constants, from scalar coefficients only (~60 selects and multiplies): formed at the wave's start,
+// between the arrival of the kernarg scalars (~0.45 us) and that of the working set (~0.85 us), when the SIMD has
+// nothing else to do.  (Measured alternatives: the table built on the host and read per lane from the kernarg segment
+// — host-visible memory, 1024 waves x 3 loads of it cost 0.4-0.9 us per launch wherever they sat in the load queue.)
+__device__ __forceinline__ void pool_role(PoolRole& r, bool randomise, bool eval, const Coeffs& c) {
   const int lane = (int)__lane_id();
   const int b = lane - 5 * (lane / 5);
-  float4 o, s, z;  // (the table is only 4-byte aligned in the kernarg segment: copies, not float4 dereferences)
-  __builtin_memcpy(&o, &tab[b][0], 16); __builtin_memcpy(&s, &tab[b][4], 16); __builtin_memcpy(&z, &tab[b][8], 16);
-  r.off[0] = o.x; r.off[1] = o.y; r.off[2] = o.z; r.off[3] = o.w;
-  r.scl[0] = s.x; r.scl[1] = s.y; r.scl[2] = s.z; r.scl[3] = s.w;
-  r.scl_z[0] = z.x; r.scl_z[1] = z.y; r.scl_z[2] = z.z; r.scl_z[3] = z.w;
+  // (all coefficient reads are unconditional scalar loads; the per-lane part is selects only)
+  const float n0 = c.nom_f[0], n1 = c.nom_f[1], n2 = c.nom_f[2], n3 = c.nom_f[3], n4 = c.nom_f[4], n5 = c.nom_f[5];
+  const float rv = c.reset_v, rW = c.reset_W;
+  const float p = randomise ? c.udm : 0.0f;
+  const float ix = eval ? 0.4f : 0.6f, iv = eval ? 0.0f : rv, iW = eval ? 0.0f : rW;
+  const float iR = eval ? 0.0f : (float)(50.0 * kPi / 180.0);
+  const float zx = eval ? ix : 0.0f;  // (the zero-error branch exists in 'train' only; with 'eval' it changes nothing)
+  const float pi = (float)kPi;
+  // role table: value_j = off_j + scl_j * sym_j, scl_z_j in the zero-error branch
+  //   b = 0: m, d, J1, J3   1: c_tf, c_tw, x0, x1   2: x2, v0, v1, v2   3: W0, W1, W2, branch   4: yaw, roll, pitch, raw
+  r.off[0] = sel5(b, n0, n4, 0.f, 0.f, 0.f); r.off[1] = sel5(b, n1, n5, 0.f, 0.f, 0.f);
+  r.off[2] = sel5(b, n2, 0.f, 0.f, 0.f, 0.f); r.off[3] = sel5(b, n3, 0.f, 0.f, 0.f, 0.f);
+  r.scl[0] = sel5(b, n0 * p, n4 * p, ix, iW, pi);            r.scl_z[0] = sel5(b, n0 * p, n4 * p, zx, 0.f, pi);
+  r.scl[1] = sel5(b, n1 * p, n5 * (0.5f * p), iv, iW, iR);   r.scl_z[1] = sel5(b, n1 * p, n5 * (0.5f * p), 0.f, 0.f, 0.f);
+  r.scl[2] = sel5(b, n2 * p, ix, iv, iW, iR);                r.scl_z[2] = sel5(b, n2 * p, zx, 0.f, 0.f, 0.f);
+  r.scl[3] = sel5(b, n3 * p, ix, iv, 0.f, 0.f);              r.scl_z[3] = sel5(b, n3 * p, zx, 0.f, 0.f, 0.f);
 }
 
 template <typename T>

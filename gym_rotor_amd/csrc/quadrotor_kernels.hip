@@ -161,10 +161,9 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       for (int j = 0; j < A; ++j) dst[j] = abase[ll * A + j];
     }
   };
-  // (first in the wave's load queue, so that waiting for them does not wait for the working set: vmcnt is in order)
   const bool auto_reset = reset_count != nullptr;  // passed only with QR_FLAG_AUTO_RESET: its presence IS the flag, known without a load
   PoolRole role;
-  if (auto_reset) pool_role(role, c.role_tab);
+  uint32_t rcount_s = 0;  // the tile's position in the in-launch reset stream
   load_state<XV, QW>(a, first, ll, w);
   w.nominal = a.params == nullptr;
   if (a.params) {
@@ -176,6 +175,10 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     for (int f = 0; f < 6; ++f) w.prm[f] = 0.0f;
   }
   if constexpr (!POLICY) load_action(0, act_next);
+  // The tile's position in the in-launch reset stream: a scalar load.  (Measured alternatives, bench.py at 65 536 envs:
+  // a vector load at the end of the wave's load queue 5.71 us, a load deferred until the working set has been consumed
+  // 6.12 us — against 5.42 us: both make hipcc wait for more than it has to somewhere else.)
+  if (auto_reset) rcount_s = (uint32_t)reset_count[blockIdx.x];
   if constexpr (KIND != QR_KIND_QUAD) {
     const SoA<float> integ(a.integ, 8, L);
 #pragma unroll
@@ -184,9 +187,6 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 #pragma unroll
     for (int f = 0; f < 8; ++f) w.integ[f] = 0.0f;
   }
-  // the tile's position in the in-launch reset stream: a scalar load behind the vector loads
-  uint32_t rcount = 0;
-  if (auto_reset) rcount = (uint32_t)reset_count[blockIdx.x];
   // ---- the rest of the arguments: one batch of scalar loads from the kernarg segment ----
   const uint32_t flags = ka.flags;
   const uint64_t seed = ka.seed;
@@ -196,6 +196,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   const int n_steps = SINGLE ? 1 : ka.n_steps;
   const bool eval_reset = (flags & QR_FLAG_EVAL_RESET) != 0;
   const bool randomise = !eval_reset && !(flags & QR_FLAG_NO_UDM) && a.params != nullptr;
+  if (auto_reset) pool_role(role, randomise, eval_reset, c);  // (scalars only: runs while the loads are in flight)
 #pragma unroll
   for (int f = 0; f < 12; ++f) w.goal[f] = f == 6 ? 1.0f : 0.0f;  // hover default (quad.py:98-101)
   if (!TRAJ && goal_ptr) {  // (with the fused generator the goal is formed in registers every step)
@@ -209,7 +210,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   bool have_pool = false;
 #if QR_ABLATE != 3 && QR_SPEC_GRID > 0
   if (auto_reset && gridDim.x <= QR_SPEC_GRID) {
-    make_pool<T>(pool, role, seed, gfirst, rcount, 0);
+    make_pool<T>(pool, role, seed, gfirst, rcount_s, 0);
     have_pool = true;
   }
 #endif
@@ -485,7 +486,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       const int total = __popcll(rmask);
       uint32_t r19 = 0;
       for (int pass = 0; 12 * pass < total; ++pass) {  // one pass unless more than 12 lanes reset at once
-        if (!(have_pool && pass == 0)) make_pool<T>(pool, role, seed, gfirst, rcount + (uint32_t)t, pass);
+        if (!(have_pool && pass == 0)) make_pool<T>(pool, role, seed, gfirst, rcount_s + (uint32_t)t, pass);
         const int slot = rank - 12 * pass;
 #if QR_ABLATE != 7
         take_from_pool<T, X, TRAJ>(pool, need_reset && slot >= 0 && slot < 12, slot, w, r19);
@@ -571,7 +572,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       for (int f = 0; f < 6; ++f) prm.store(f, ufirst, lane, w.prm[f]);
     }
   }
-  if (auto_reset && lane == 0) a.reset_count[blockIdx.x] = (int32_t)(rcount + (uint32_t)n_steps);  // never reuse a (tile, counter)
+  if (auto_reset && lane == 0) a.reset_count[blockIdx.x] = (int32_t)(rcount_s + (uint32_t)n_steps);  // never reuse a (tile, counter)
   QR_STAMP(6, tid);
 }
 
@@ -800,26 +801,6 @@ __global__ __launch_bounds__(64) void gae_kernel(const GaeArgs g) {
 // ------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------
-// Role table of the in-launch reset pool (qr_rng.h): what sample_start does, as (offset, scale, scale in the
-// zero-error branch) per word of the five roles of a slot.
-static void fill_pool_roles(Coeffs& o, bool eval, bool randomise) {
-  const float pi = (float)kPi, deg50 = (float)(50.0 * kPi / 180.0);
-  {
-    const float p = randomise ? o.udm : 0.0f;
-    const float ix = eval ? 0.4f : 0.6f, iv = eval ? 0.0f : o.reset_v, iW = eval ? 0.0f : o.reset_W, iR = eval ? 0.0f : deg50;
-    const float zx = eval ? ix : 0.0f;  // (the zero-error branch exists in 'train' only: quad.py:342-356)
-    const float* n = o.nom_f;
-    const float tab[5][12] = {
-        {n[0], n[1], n[2], n[3], n[0] * p, n[1] * p, n[2] * p, n[3] * p, n[0] * p, n[1] * p, n[2] * p, n[3] * p},   // m, d, J1, J3
-        {n[4], n[5], 0, 0, n[4] * p, n[5] * (0.5f * p), ix, ix, n[4] * p, n[5] * (0.5f * p), zx, zx},               // c_tf, c_tw, x0, x1
-        {0, 0, 0, 0, ix, iv, iv, iv, zx, 0, 0, 0},                                                                  // x2, v0, v1, v2
-        {0, 0, 0, 0, iW, iW, iW, 0, 0, 0, 0, 0},                                                                    // W0, W1, W2, branch
-        {0, 0, 0, 0, pi, iR, iR, 0, pi, 0, 0, 0}};                                                                  // yaw, roll, pitch, raw
-    for (int b = 0; b < 5; ++b)
-      for (int j = 0; j < 12; ++j) o.role_tab[b][j] = tab[b][j];
-  }
-}
-
 static float round_up_to_float(double v) {  // smallest float >= v
   float f = (float)v;
   if ((double)f < v) f = nextafterf(f, INFINITY);
@@ -872,8 +853,6 @@ static int fill_env(Args& a, const QrEnv* e) {
   a.env_offset = e->env_offset; a.seed = e->seed;
   a.max_episode_steps = e->max_episode_steps; a.flags = e->flags;
   fill_coeffs(a.c, e->coeffs);
-  const bool eval = (e->flags & QR_FLAG_EVAL_RESET) != 0;
-  fill_pool_roles(a.c, eval, !eval && !(e->flags & QR_FLAG_NO_UDM) && e->params != nullptr);
   return 0;
 }
 
