@@ -176,8 +176,9 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   }
   if constexpr (!POLICY) load_action(0, act_next);
   // The tile's position in the in-launch reset stream: a scalar load.  (Measured alternatives, bench.py at 65 536 envs:
-  // a vector load at the end of the wave's load queue 5.71 us, a load deferred until the working set has been consumed
-  // 6.12 us — against 5.42 us: both make hipcc wait for more than it has to somewhere else.)
+  // a vector load at the end of the wave's load queue 5.71 us, at its front 5.70 us, a load deferred until the working set
+  // has been consumed 6.12 us — against 5.42 us, although scalar loads return out of order and the first use of a kernarg
+  // coefficient therefore also waits for this one: the in-kernel timelines of those variants are shorter, their launches not.)
   if (auto_reset) rcount_s = (uint32_t)reset_count[blockIdx.x];
   if constexpr (KIND != QR_KIND_QUAD) {
     const SoA<float> integ(a.integ, 8, L);
