@@ -46,6 +46,20 @@ except AttributeError:  # pragma: no cover - older/newer torch without the priva
         return torch.cuda.current_device()
 
 
+def _pack_att_rate(old: torch.Tensor) -> torch.Tensor:
+    """[7, N] rows (q = w,x,y,z; W) -> the [6, N] storage form (quadrotor_hip.h: the three components of q of smaller
+    magnitude, the dropped one made positive, its index in the two lowest mantissa bits of the first kept one; W)."""
+    q, W = old[:4], old[4:]
+    idx = q.abs().argmax(0)                                             # ties: the lowest index, like pack_quat
+    sgn = torch.where(q.gather(0, idx[None])[0] < 0, -1.0, 1.0).to(q.dtype)
+    rows = torch.arange(3, device=old.device)[:, None]
+    keep = rows + (rows >= idx[None]).to(rows.dtype)                    # the three indices != idx, in order
+    k = q.gather(0, keep) * sgn[None]
+    ibits = torch.int64 if k.dtype == torch.float64 else torch.int32
+    k0 = (k[0].contiguous().view(ibits) & ~3) | idx.to(ibits)
+    return torch.cat([k0.view(k.dtype)[None], k[1:], W], 0)
+
+
 class _NullCtx:
     def __enter__(self):
         return None
@@ -75,7 +89,8 @@ class QuadVecEnv:
                     times the substeps.  Never active in regime (|W| < 2 pi), and with auto_reset it
                     cannot trigger (the plain kernel is launched); it keeps envs that are stepped on
                     far beyond termination inside the 1e-5 trajectory bar.  0 disables it.
-    layout          internal state precision (the state is 13 words: x, v, unit quaternion q, W):
+    layout          internal state precision (the state is 12 words: x, v, the unit quaternion q stored as its three
+                    smaller components, W):
                     'mixed' (default) x,v float32 + q,W float64; W integrated and q accumulated in
                     float64, RK4 stage quaternions / thrust direction in float32: 1000-step
                     trajectories within ~4e-6 of the reference (the float32 ulp of x, v);
@@ -609,6 +624,8 @@ class QuadVecEnv:
             cur = getattr(self, "_" + k)
             if v is None:
                 continue
+            if k == "att_rate" and v.shape[0] == 7:  # a checkpoint from before the smallest-three attitude storage: q(4), W(3)
+                v = _pack_att_rate(v.to(self.device))
             if cur is None:
                 cur = self._soa(v.shape[0], v.dtype) if v.dim() == 2 else torch.zeros_like(v, device=self.device)
                 setattr(self, "_" + k, cur)

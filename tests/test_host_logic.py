@@ -384,3 +384,26 @@ def test_learner_side_collectives_over_rccl(tmp_path):
     script.write_text(_NCCL_GATHER.format(root=ROOT, port=port))
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_checkpoint_attitude_conversion():
+    """A round-1 checkpoint stores att_rate as [7, N] (q, W); load_state_dict converts it to the smallest-three form the
+    kernels read (three smaller components, dropped one positive, its index in the two low mantissa bits of the first)."""
+    from gym_rotor_amd.vec_env import _pack_att_rate
+    g = torch.Generator().manual_seed(0)
+    for dt, ib, tol in ((torch.float64, torch.int64, 1e-15), (torch.float32, torch.int32, 5e-7)):
+        q = torch.randn(4, 500, generator=g, dtype=dt); q /= q.norm(dim=0)
+        q[:, 0] = torch.tensor([1, 0, 0, 0], dtype=dt); q[:, 1] = torch.tensor([0, 0, -1, 0], dtype=dt)
+        W = torch.randn(3, 500, generator=g, dtype=dt)
+        p = _pack_att_rate(torch.cat([q, W]))
+        assert p.shape == (6, 500) and torch.equal(p[3:], W)
+        bits = p[0].contiguous().view(ib)
+        idx = bits & 3
+        k = torch.stack([(bits & ~3).view(dt), p[1], p[2]])
+        w = torch.sqrt(1 - (k * k).sum(0))
+        assert (w >= 0.5 - 1e-6).all()                                  # the dropped component is the largest one
+        for n in range(500):
+            kk = list(k[:, n]); kk.insert(int(idx[n]), w[n])
+            dec = torch.stack(kk)
+            assert min((dec - q[:, n]).abs().max(), (dec + q[:, n]).abs().max()) <= tol   # q and -q are the same rotation
+        assert int(idx[0]) == 0 and int(idx[1]) == 2 and float(p[:3, 0].abs().max()) == 0.0
