@@ -75,6 +75,9 @@ __device__ unsigned long long* g_stamps = nullptr;
 #define QR_STAMP(k, dep) do { } while (0)
 #endif
 
+#ifndef QR_EARLY_STORE_GRID
+#define QR_EARLY_STORE_GRID 4096  // grids up to this many waves store a resetting wave's settled lanes before it samples
+#endif
 #ifndef QR_SPEC_GRID
 // Grids up to this many waves sample their reset pool SPECULATIVELY, right after issuing their loads.  Measured on
 // MI355X at 65 536 envs (profiles/r02/ab_reset_pool.json): the wave's loads are back ~0.7 us after its first
@@ -448,9 +451,12 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     }
     const unsigned long long rmask = __ballot(need_reset);
     if (rmask) {  // wave-uniform: skipped unless some lane of this wave starts a new episode
-      if constexpr (SINGLE) {
+      if (SINGLE && n_envs <= QR_EARLY_STORE_GRID * 64) {  // (n_envs: a preloaded SGPR — gridDim.x would be a scalar load here)
         // This wave is about to spend ~0.5 us sampling episode starts.  The state of its lanes that do NOT
-        // reset is final: hand it to the memory system first, so that those stores drain meanwhile.
+        // reset is final: hand it to the memory system first, so that those stores drain meanwhile.  Only for
+        // grids in the launch-latency regime: the resetting lanes' own stores then are partial-line writes, which
+        // cost more than the overlap gains once the launch is bound by bytes (measured, bench.py: 65 536 envs 5.43
+        // with / 5.49 us without; 1 M envs 39.4 with / 37.4 us without).
         if (active && !need_reset) {
           store_state<XV, QW>(a, first, lane, w, qp);
           if (KIND != QR_KIND_QUAD) {
@@ -459,7 +465,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
             for (int f = 0; f < 8; ++f) integ.store(f, ufirst, lane, w.integ[f]);
           }
         }
-        stored_early = !need_reset;
+        stored_early = active && !need_reset;
       }
       // the terminal observation of the episode that ends here (what a learner bootstraps from):
       // written for the resetting lanes only
