@@ -369,11 +369,25 @@ __device__ __forceinline__ void integrate(float (&x)[3], float (&v)[3], double (
 // LDS transposes between lane-per-env registers and AoS rows in global memory.
 // The workgroup's rows [first, first+rows) x D floats are contiguous in global memory.
 // ------------------------------------------------------------------------------------
+// The tile is one wavefront (B == 64): its LDS accesses execute in program order, so the exchange needs a
+// compiler-level ordering only — and must not be a workgroup barrier in the instantiation whose workgroup
+// carries a second (helper) wave that takes no part in it.
+template <int B>
+__device__ __forceinline__ void tile_sync() {
+  if constexpr (B == 64) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
+
 template <int B, int D>
 __device__ __forceinline__ void store_rows(float* __restrict__ gbase, const float (&vals)[D], float* smem, int tid, int rows) {
 #pragma unroll
   for (int j = 0; j < D; ++j) smem[tid * D + j] = vals[j];
-  __syncthreads();
+  tile_sync<B>();
   if (rows == B && (reinterpret_cast<uintptr_t>(gbase) & 15u) == 0) {
     constexpr int nvec = B * D / 4;  // B is a multiple of 4
     const float4* s4 = reinterpret_cast<const float4*>(smem);
@@ -384,7 +398,7 @@ __device__ __forceinline__ void store_rows(float* __restrict__ gbase, const floa
     const int total = rows * D;
     for (int idx = tid; idx < total; idx += B) gbase[idx] = smem[idx];
   }
-  __syncthreads();
+  tile_sync<B>();
 }
 
 template <int B, int D>
@@ -399,10 +413,10 @@ __device__ __forceinline__ void load_rows(const float* __restrict__ gbase, float
     const int total = rows * D;
     for (int idx = tid; idx < total; idx += B) smem[idx] = gbase[idx];
   }
-  __syncthreads();
+  tile_sync<B>();
 #pragma unroll
   for (int j = 0; j < D; ++j) vals[j] = tid < rows ? smem[tid * D + j] : 0.f;
-  __syncthreads();
+  tile_sync<B>();
 }
 
 template <int KIND> struct KindTraits;

@@ -281,4 +281,44 @@ __device__ __forceinline__ void take_from_pool(const ResetPool<T>& p, bool take,
   }
 }
 
+// The pool as the helper wave of a workgroup leaves it in LDS for the stepping wave (HELP instantiation of the step
+// kernel): 16 bytes of role values per lane, the quaternion of a slot from its role-4 lane.
+template <typename T>
+struct PoolLds {
+  float4 v[64];
+  T q[12][4];
+};
+
+template <typename T>
+__device__ __forceinline__ void pool_to_lds(PoolLds<T>& s, const ResetPool<T>& p) {
+  const int lane = (int)__lane_id();
+  const int k = lane / 5, b = lane - 5 * k;
+  s.v[lane] = make_float4(p.v[0], p.v[1], p.v[2], p.v[3]);
+  if (b == 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s.q[k][j] = p.q[j];
+  }
+}
+
+// take_from_pool with the pool in LDS: the same values into the same places.
+template <typename T, typename X, bool TRAJ>
+__device__ __forceinline__ void take_from_lds(const PoolLds<T>& s, bool take, int slot, Work<T, X>& w, uint32_t& r19) {
+  const int k = take ? slot : 0;
+  const float4 r0 = s.v[5 * k], r1 = s.v[5 * k + 1], r2 = s.v[5 * k + 2], r3 = s.v[5 * k + 3];
+  T q[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) q[j] = s.q[k][j];
+  float rb = 0.0f;
+  if constexpr (TRAJ) rb = s.v[5 * k + 4].w;
+  if (take) {
+    w.prm[0] = r0.x; w.prm[1] = r0.y; w.prm[2] = r0.z; w.prm[3] = r0.w; w.prm[4] = r1.x; w.prm[5] = r1.y;
+    w.x[0] = X(r1.z); w.x[1] = X(r1.w); w.x[2] = X(r2.x);
+    w.v[0] = X(r2.y); w.v[1] = X(r2.z); w.v[2] = X(r2.w);
+    w.W[0] = T(r3.x); w.W[1] = T(r3.y); w.W[2] = T(r3.z);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w.q[j] = q[j];
+    if constexpr (TRAJ) r19 = __builtin_bit_cast(uint32_t, rb);
+  }
+}
+
 }  // namespace qr

@@ -78,6 +78,9 @@ __device__ unsigned long long* g_stamps = nullptr;
 #ifndef QR_EARLY_STORE_GRID
 #define QR_EARLY_STORE_GRID 4096  // grids up to this many waves store a resetting wave's settled lanes before it samples
 #endif
+#ifndef QR_HELPER_GRID
+#define QR_HELPER_GRID 2048  // grids up to this many tiles run the one-step kernel with a helper wave per tile (HELP)
+#endif
 #ifndef QR_SPEC_GRID
 // Grids up to this many waves sample their reset pool SPECULATIVELY, right after issuing their loads.  Measured on
 // MI355X at 65 536 envs (profiles/r02/ab_reset_pool.json): the wave's loads are back ~0.7 us after its first
@@ -99,8 +102,13 @@ __device__ unsigned long long* g_stamps = nullptr;
 // (parameter log_std, tanh-of-mean rule); 2: any reference MLP actor (adds SAC's log_std head and rule).
 // SINGLE = exactly one env-step per launch (qr_step): no loop over steps, so nothing is hoisted out of it and kept
 // live across the whole kernel (fewer SGPRs to spill, a shorter prologue).
-template <int KIND, typename XV, typename QW, int B, bool TRAJ, bool ADAPT, int POLICY = 0, bool SINGLE = false>
-__global__ __launch_bounds__(B, ((TRAJ || POLICY) ? 1 : QR_WAVES_PER_SIMD))
+// HELP (with SINGLE, for grids in the launch-latency regime) = the workgroup carries a second wavefront that does
+// nothing but sample the tile's reset pool into LDS while the stepping wave waits for its loads and integrates:
+// a lone wave issues one VALU instruction per ~5.6 cycles, two waves on a SIMD one per ~2.9 (tools/valu_microbench.hip),
+// so the helper runs in issue slots that are otherwise empty, and the stepping wave's reset block shrinks from
+// ~230 instructions (Philox, role scaling, attitude, 24 cross-lane reads) to six LDS reads.
+template <int KIND, typename XV, typename QW, int B, bool TRAJ, bool ADAPT, int POLICY = 0, bool SINGLE = false, bool HELP = false>
+__global__ __launch_bounds__(B + (HELP ? 64 : 0), ((TRAJ || POLICY) ? 1 : QR_WAVES_PER_SIMD))
 void step_kernel(void* pos_vel, void* att_rate, const float* action, float* params, float* integ, int32_t* reset_count,
                  int32_t n_envs, int32_t ld_envs, const Args a_in) {
   // The leading scalar arguments duplicate the fields of Args that the wave's loads depend on: as
@@ -144,6 +152,24 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 #if QR_ABLATE == 1  // measurement build: launch floor only
   return;
 #endif
+  static_assert(!HELP || (SINGLE && !POLICY && B == 64), "the helper wave belongs to the one-step, one-wave-per-tile kernel");
+  __shared__ typename std::conditional<HELP, PoolLds<T>, char>::type pool_lds;  // (unused without HELP: dropped)
+  if constexpr (HELP) {
+    if (threadIdx.x >= B) {  // ---- the helper wavefront: pass 0 of the tile's reset pool -> LDS ----
+      const uint32_t rc = (uint32_t)reset_count[blockIdx.x];
+      const uint32_t hflags = ka.flags;
+      const uint64_t hseed = ka.seed;
+      const uint64_t hgfirst = (uint64_t)(ka.env_offset + first);
+      const bool heval = (hflags & QR_FLAG_EVAL_RESET) != 0;
+      PoolRole hrole;
+      pool_role(hrole, !heval && !(hflags & QR_FLAG_NO_UDM) && params != nullptr, heval, c);
+      ResetPool<T> hp;
+      make_pool<T>(hp, hrole, hseed, hgfirst, rc, 0);
+      pool_to_lds(pool_lds, hp);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      return;
+    }
+  }
   QR_STAMP(0, tid);
 
   // ---- issue the loads of the env's working set (SoA, lane-contiguous) and of its action row ----
@@ -164,7 +190,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       for (int j = 0; j < A; ++j) dst[j] = abase[ll * A + j];
     }
   };
-  const bool auto_reset = reset_count != nullptr;  // passed only with QR_FLAG_AUTO_RESET: its presence IS the flag, known without a load
+  const bool auto_reset = HELP || reset_count != nullptr;  // passed only with QR_FLAG_AUTO_RESET: its presence IS the flag, known without a load
   PoolRole role;
   uint32_t rcount_s = 0;  // the tile's position in the in-launch reset stream
   load_state<XV, QW>(a, first, ll, w);
@@ -182,7 +208,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   // a vector load at the end of the wave's load queue 5.71 us, at its front 5.70 us, a load deferred until the working set
   // has been consumed 6.12 us — against 5.42 us, although scalar loads return out of order and the first use of a kernarg
   // coefficient therefore also waits for this one: the in-kernel timelines of those variants are shorter, their launches not.)
-  if (auto_reset) rcount_s = (uint32_t)reset_count[blockIdx.x];
+  if (!HELP && auto_reset) rcount_s = (uint32_t)reset_count[blockIdx.x];
   if constexpr (KIND != QR_KIND_QUAD) {
     const SoA<float> integ(a.integ, 8, L);
 #pragma unroll
@@ -200,7 +226,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   const int n_steps = SINGLE ? 1 : ka.n_steps;
   const bool eval_reset = (flags & QR_FLAG_EVAL_RESET) != 0;
   const bool randomise = !eval_reset && !(flags & QR_FLAG_NO_UDM) && a.params != nullptr;
-  if (auto_reset) pool_role(role, randomise, eval_reset, c);  // (scalars only: runs while the loads are in flight)
+  if (!HELP && auto_reset) pool_role(role, randomise, eval_reset, c);  // (scalars only: runs while the loads are in flight)
 #pragma unroll
   for (int f = 0; f < 12; ++f) w.goal[f] = f == 6 ? 1.0f : 0.0f;  // hover default (quad.py:98-101)
   if (!TRAJ && goal_ptr) {  // (with the fused generator the goal is formed in registers every step)
@@ -231,6 +257,9 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   bool params_dirty = false;
   bool traj_dirty = false;  // this lane started a new episode: its generator state changed
   bool stored_early = false;  // (SINGLE) this lane's state went out before its wave sampled a reset pool
+  // (n_envs: a preloaded SGPR — gridDim.x would be a scalar load.  With a helper wave the reset block is six LDS reads:
+  // nothing to overlap.)
+  const bool early_store = SINGLE && !HELP && n_envs <= QR_EARLY_STORE_GRID * 64;
   QuatPack<T> qp;             // attitude in its storage form, formed once per env-step
   qp.k[0] = qp.k[1] = qp.k[2] = T(0);
 
@@ -351,7 +380,9 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       integrate(w.x, w.v, w.q, w.W, dyn, nsub, T(c.dt) * recip(T(nsub)));
     }
     renorm_quat(w.q);
-    pack_quat(w.q, qp);  // the attitude as it is stored (qr_traj.h: QuatPack)
+    // The attitude as it is stored (qr_traj.h: QuatPack) is formed once per env-step: here when this wave may store
+    // its settled lanes early (below), otherwise after the reset block, when every lane holds what it will store.
+    if (early_store) pack_quat(w.q, qp);
     QR_STAMP(3, (float)w.q[0] + (float)w.x[0] + (float)w.v[2] + (float)w.W[0]);
 #endif
 
@@ -449,9 +480,12 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       }
       if (ka.truncated) (ka.truncated + row0)[lane] = trunc ? 1 : 0;
     }
+    // (HELP) the helper wave's pool is in LDS: it got there while this wave waited for its loads.  A bare s_barrier:
+    // nothing of this wave's own (its reward / done stores in flight) has to be waited for.
+    if constexpr (HELP) asm volatile("s_barrier" ::: "memory");
     const unsigned long long rmask = __ballot(need_reset);
     if (rmask) {  // wave-uniform: skipped unless some lane of this wave starts a new episode
-      if (SINGLE && n_envs <= QR_EARLY_STORE_GRID * 64) {  // (n_envs: a preloaded SGPR — gridDim.x would be a scalar load here)
+      if (early_store) {
         // This wave is about to spend ~0.5 us sampling episode starts.  The state of its lanes that do NOT
         // reset is final: hand it to the memory system first, so that those stores drain meanwhile.  Only for
         // grids in the launch-latency regime: the resetting lanes' own stores then are partial-line writes, which
@@ -492,9 +526,18 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       const int rank = __popcll(rmask & ((1ull << lane) - 1ull));  // rank among the wave's resetting lanes
       const int total = __popcll(rmask);
       uint32_t r19 = 0;
-      for (int pass = 0; 12 * pass < total; ++pass) {  // one pass unless more than 12 lanes reset at once
-        if (!(have_pool && pass == 0)) make_pool<T>(pool, role, seed, gfirst, rcount_s + (uint32_t)t, pass);
+      int pass0 = 0;
+      if constexpr (HELP) {  // pass 0 comes from the helper wave
+        take_from_lds<T, X, TRAJ>(pool_lds, need_reset && rank < 12, rank, w, r19);
+        pass0 = 1;
+        if (total > 12) {  // more than 12 lanes reset at once (rare): this wave samples the further passes itself
+          pool_role(role, randomise, eval_reset, c);
+          rcount_s = (uint32_t)reset_count[blockIdx.x];
+        }
+      }
+      for (int pass = pass0; 12 * pass < total; ++pass) {  // one pass unless more than 12 lanes reset at once
         const int slot = rank - 12 * pass;
+        if (!(have_pool && pass == 0)) make_pool<T>(pool, role, seed, gfirst, rcount_s + (uint32_t)t, pass);
 #if QR_ABLATE != 7
         take_from_pool<T, X, TRAJ>(pool, need_reset && slot >= 0 && slot < 12, slot, w, r19);
 #endif
@@ -522,9 +565,10 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
           for (int f = 0; f < 8; ++f) w.integ[f] = 0.0f;
           error_obs<KIND, T, X>(w, R, c, o0, o1);  // first observation of the new episode (main.py:226-230)
         }
-        pack_quat(w.q, qp);
+        if (early_store) pack_quat(w.q, qp);
       }
     }
+    if (!early_store) pack_quat(w.q, qp);
     have_pool = false;  // the speculative pool belongs to step 0's counter value
     QR_STAMP(5, (float)w.q[0] + (float)w.x[0] + w.prm[0]);
 #ifdef QR_STAMPS
@@ -579,7 +623,11 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       for (int f = 0; f < 6; ++f) prm.store(f, ufirst, lane, w.prm[f]);
     }
   }
-  if (auto_reset && lane == 0) a.reset_count[blockIdx.x] = (int32_t)(rcount_s + (uint32_t)n_steps);  // never reuse a (tile, counter)
+  if constexpr (HELP) {  // (the helper wave read the counter; this wave only advances it)
+    if (lane == 0) __hip_atomic_fetch_add(a.reset_count + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (auto_reset && lane == 0) {
+    a.reset_count[blockIdx.x] = (int32_t)(rcount_s + (uint32_t)n_steps);  // never reuse a (tile, counter)
+  }
   QR_STAMP(6, tid);
 }
 
@@ -901,6 +949,8 @@ static void launch_kind(const Args& a, hipStream_t s) {
         if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
         else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, false, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
       } else if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+      else if ((a.flags & QR_FLAG_AUTO_RESET) && grid.x <= (unsigned)QR_HELPER_GRID)
+        hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 0, true, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
       else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
       return;
     }
