@@ -78,6 +78,9 @@ __device__ unsigned long long* g_stamps = nullptr;
 #ifndef QR_EARLY_STORE_GRID
 #define QR_EARLY_STORE_GRID 4096  // grids up to this many waves store a resetting wave's settled lanes before it samples
 #endif
+#ifndef QR_HELP_REWARD
+#define QR_HELP_REWARD 1
+#endif
 #ifndef QR_HELPER_GRID
 #define QR_HELPER_GRID 2048  // grids up to this many tiles run the one-step kernel with a helper wave per tile (HELP)
 #endif
@@ -89,6 +92,62 @@ __device__ unsigned long long* g_stamps = nullptr;
 // of the waves that hold a resetting lane ~0.45 us (5.18 us).  Default: on demand (0).
 #define QR_SPEC_GRID 0
 #endif
+
+// ------------------------------------------------------------------------------------
+// Quad-v0 reward and termination (quad.py:274-318) from the post-step state
+// ------------------------------------------------------------------------------------
+// reward_wrapper (quad.py:274-298), formed in float32 (its result is a float32 word)
+template <typename T, typename X>
+__device__ __forceinline__ float quad_reward_raw(const X (&x)[3], const X (&v)[3], const T (&q)[4], const T (&W)[3],
+                                                 const float (&goal)[12], const Coeffs& c) {
+  const T qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+  const T R00 = fma_1m2(fma_ss(qy, qy, qz, qz)), R10 = T(2) * fma_ss(qx, qy, qw, qz);  // b1 = first column of R(q)
+  float eX2 = 0.f, eV2 = 0.f, W2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float dx = (float)x[j] - goal[j], dv = (float)v[j] - goal[3 + j], wj = (float)W[j];
+    eX2 = fmaf(dx, dx, eX2); eV2 = fmaf(dv, dv, eV2); W2 = fmaf(wj, wj, W2);
+  }
+  // eb1 = signed angle from b1d to b1_proj ~ (R00, R10, 0) (quad_utils.py:97-101,157-177).
+  // acos(du.cu) with the sign of (du x cu)_z == atan2(|du x cu|, du.cu), which is invariant
+  // to the lengths of both vectors, so neither is normalised.
+  const float r00 = (float)R00, r10 = (float)R10;
+  const float g6 = goal[6], g7 = goal[7], g8 = goal[8];
+  const float dot = g6 * r00 + g7 * r10;
+  const float cz = g6 * r10 - g7 * r00;
+  const float hy2 = r00 * r00 + r10 * r10;
+  const float sabs = sqrtf(g8 * g8 * hy2 + cz * cz);
+  float ang = atan2_fast(sabs, dot);
+  if (cz < 0.0f) ang = -ang;
+  const float eb1 = ang * (float)(1.0 / kPi);
+  return -c.Cx * eX2 - c.Cb1 * fabsf(eb1) - c.Cv * eV2 - c.CW * W2;
+}
+
+// done_wrapper (quad.py:301-318): roll = atan2(R21,R22), pitch = -asin(R20); |angle| >= 85 deg
+// without inverse trig.  x, v: float32 numbers compared with the limit rounded UP to float32,
+// which decides exactly as the float64 comparison does.  (bitwise | on purpose: no branches)
+template <typename T, typename X>
+__device__ __forceinline__ bool quad_done(const X (&x)[3], const X (&v)[3], const T (&q)[4], const T (&W)[3], const Coeffs& c) {
+  const T qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+  const T R20 = T(2) * fma_sd(qx, qz, qw, qy), R21 = T(2) * fma_ss(qy, qz, qw, qx), R22 = fma_1m2(fma_ss(qx, qx, qy, qy));
+  X xl, vl;
+  if constexpr (std::is_same<X, float>::value) { xl = c.x_lim_up; vl = c.v_lim_up; } else { xl = X(c.x_lim); vl = X(c.v_lim); }
+  bool d = false;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+    d = d | !(fabs(x[j]) < xl) | !(fabs(v[j]) < vl) | !(fabs(W[j]) < T(c.W_lim));
+  d = d | !(fabs(R20) < T(c.sin_euler_lim));          // |pitch| >= lim
+  d = d | !(fabs(R21) < T(c.tan_euler_lim) * R22);    // |atan2(R21,R22)| >= lim
+  return d;
+}
+
+// The post-step state of a tile as its stepping wave leaves it in LDS for the helper wave (HELP, Quad-v0), which
+// forms and stores the reward from it.
+template <typename T, typename X>
+struct PostLds {
+  X x[3][64], v[3][64];
+  T q[4][64], W[3][64];
+};
 
 // ------------------------------------------------------------------------------------
 // The fused step / rollout kernel
@@ -154,8 +213,22 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 #endif
   static_assert(!HELP || (SINGLE && !POLICY && B == 64), "the helper wave belongs to the one-step, one-wave-per-tile kernel");
   __shared__ typename std::conditional<HELP, PoolLds<T>, char>::type pool_lds;  // (unused without HELP: dropped)
+  // Quad-v0's reward (an atan2, a sqrt: ~90 instructions) is formed by the helper wave as well
+  constexpr bool kHelpReward = HELP && KIND == QR_KIND_QUAD && QR_HELP_REWARD;
+  __shared__ typename std::conditional<kHelpReward, PostLds<T, X>, char>::type post_lds;
   if constexpr (HELP) {
     if (threadIdx.x >= B) {  // ---- the helper wavefront: pass 0 of the tile's reset pool -> LDS ----
+      float hgoal[12];
+#pragma unroll
+      for (int f = 0; f < 12; ++f) hgoal[f] = f == 6 ? 1.0f : 0.0f;  // hover default (quad.py:98-101)
+      if constexpr (kHelpReward) {
+        if (float* const gp = ka.goal) {
+          const SoA<float> goal(gp, 12, ld_envs);
+          const unsigned hll = min(threadIdx.x - B, (unsigned)(rows - 1));
+#pragma unroll
+          for (int f = 0; f < 9; ++f) hgoal[f] = goal.load(f, ufirst, hll);
+        }
+      }
       const uint32_t rc = (uint32_t)reset_count[blockIdx.x];
       const uint32_t hflags = ka.flags;
       const uint64_t hseed = ka.seed;
@@ -167,6 +240,21 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       make_pool<T>(hp, hrole, hseed, hgfirst, rc, 0);
       pool_to_lds(pool_lds, hp);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if constexpr (kHelpReward) {  // ---- then the reward of the step, from the post-step state the stepping wave left in LDS ----
+        const unsigned hl = threadIdx.x - B;
+        X hx[3], hv[3];
+        T hq[4], hW[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { hx[j] = post_lds.x[j][hl]; hv[j] = post_lds.v[j][hl]; hW[j] = post_lds.W[j][hl]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hq[j] = post_lds.q[j][hl];
+        const float r = quad_reward_raw<T, X>(hx, hv, hq, hW, hgoal, c);
+        const bool d = quad_done<T, X>(hx, hv, hq, hW, c);
+        if ((int)hl < rows) {
+          (ka.reward + first)[hl] = d ? -1.0f : interp01(r, c.rmin_mono, c.inv_nrmin_mono);  // crash override (quad.py:162-166)
+          if (ka.reward_raw) (ka.reward_raw + first)[hl] = r;
+        }
+      }
       return;
     }
   }
@@ -393,43 +481,20 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     float rraw[NAG], rwd[NAG];
     bool dn[NAG];
     if constexpr (KIND == QR_KIND_QUAD) {
-      const T qw = w.q[0], qx = w.q[1], qy = w.q[2], qz = w.q[3];
-      const T R00 = fma_1m2(fma_ss(qy, qy, qz, qz)), R10 = T(2) * fma_ss(qx, qy, qw, qz);  // b1 = first column of R(q)
-      const T R20 = T(2) * fma_sd(qx, qz, qw, qy), R21 = T(2) * fma_ss(qy, qz, qw, qx), R22 = fma_1m2(fma_ss(qx, qx, qy, qy));
-      // reward_wrapper (quad.py:274-298), formed in float32 (its result is a float32 word)
-      float eX2 = 0.f, eV2 = 0.f, W2 = 0.f;
+      if constexpr (kHelpReward) {
+        // the helper wave forms and stores the reward (below, after the barrier): hand it the post-step state
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const float dx = (float)w.x[j] - w.goal[j], dv = (float)w.v[j] - w.goal[3 + j], wj = (float)w.W[j];
-        eX2 = fmaf(dx, dx, eX2); eV2 = fmaf(dv, dv, eV2); W2 = fmaf(wj, wj, W2);
+        for (int j = 0; j < 3; ++j) { post_lds.x[j][lane] = w.x[j]; post_lds.v[j][lane] = w.v[j]; post_lds.W[j][lane] = w.W[j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) post_lds.q[j][lane] = w.q[j];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        rraw[0] = rwd[0] = 0.0f;
+      } else {
+        const float r = quad_reward_raw<T, X>(w.x, w.v, w.q, w.W, w.goal, c);
+        rraw[0] = r;
+        rwd[0] = interp01(r, c.rmin_mono, c.inv_nrmin_mono);
       }
-      // eb1 = signed angle from b1d to b1_proj ~ (R00, R10, 0) (quad_utils.py:97-101,157-177).
-      // acos(du.cu) with the sign of (du x cu)_z == atan2(|du x cu|, du.cu), which is invariant
-      // to the lengths of both vectors, so neither is normalised.
-      const float r00 = (float)R00, r10 = (float)R10;
-      const float g6 = w.goal[6], g7 = w.goal[7], g8 = w.goal[8];
-      const float dot = g6 * r00 + g7 * r10;
-      const float cz = g6 * r10 - g7 * r00;
-      const float hy2 = r00 * r00 + r10 * r10;
-      const float sabs = sqrtf(g8 * g8 * hy2 + cz * cz);
-      float ang = atan2_fast(sabs, dot);
-      if (cz < 0.0f) ang = -ang;
-      const float eb1 = ang * (float)(1.0 / kPi);
-      const float r = -c.Cx * eX2 - c.Cb1 * fabsf(eb1) - c.Cv * eV2 - c.CW * W2;
-      rraw[0] = r;
-      rwd[0] = interp01(r, c.rmin_mono, c.inv_nrmin_mono);
-      // done_wrapper (quad.py:301-318): roll = atan2(R21,R22), pitch = -asin(R20); |angle| >= 85 deg
-      // without inverse trig.  x, v: float32 numbers compared with the limit rounded UP to float32,
-      // which decides exactly as the float64 comparison does.  (bitwise | on purpose: no branches)
-      X xl, vl;
-      if constexpr (std::is_same<X, float>::value) { xl = c.x_lim_up; vl = c.v_lim_up; } else { xl = X(c.x_lim); vl = X(c.v_lim); }
-      bool d = false;
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-        d = d | !(fabs(w.x[j]) < xl) | !(fabs(w.v[j]) < vl) | !(fabs(w.W[j]) < T(c.W_lim));
-      d = d | !(fabs(R20) < T(c.sin_euler_lim));          // |pitch| >= lim
-      d = d | !(fabs(R21) < T(c.tan_euler_lim) * R22);    // |atan2(R21,R22)| >= lim
-      dn[0] = d;
+      dn[0] = quad_done<T, X>(w.x, w.v, w.q, w.W, c);
     } else {
       quat_to_R(w.q, R);
       error_obs<KIND, T, X>(w, R, c, o0, o1);
@@ -470,8 +535,10 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     // ---- reward / done of step t (they belong to the step that just ended, whatever the reset does next) ----
     if (active) {
       if constexpr (NAG == 1) {
-        (ka.reward + row0)[lane] = rwd[0];
-        if (ka.reward_raw) (ka.reward_raw + row0)[lane] = rraw[0];
+        if constexpr (!kHelpReward) {
+          (ka.reward + row0)[lane] = rwd[0];
+          if (ka.reward_raw) (ka.reward_raw + row0)[lane] = rraw[0];
+        }
         (ka.done + row0)[lane] = dn[0] ? 1 : 0;
       } else {
         (reinterpret_cast<float2*>(ka.reward) + row0)[lane] = make_float2(rwd[0], rwd[NAG - 1]);
@@ -482,7 +549,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     }
     // (HELP) the helper wave's pool is in LDS: it got there while this wave waited for its loads.  A bare s_barrier:
     // nothing of this wave's own (its reward / done stores in flight) has to be waited for.
-    if constexpr (HELP) asm volatile("s_barrier" ::: "memory");
+    if constexpr (HELP && !kHelpReward) asm volatile("s_barrier" ::: "memory");
     const unsigned long long rmask = __ballot(need_reset);
     if (rmask) {  // wave-uniform: skipped unless some lane of this wave starts a new episode
       if (early_store) {
