@@ -82,7 +82,14 @@ __device__ unsigned long long* g_stamps = nullptr;
 #define QR_HELP_REWARD 1
 #endif
 #ifndef QR_HELPER_GRID
-#define QR_HELPER_GRID 2048  // grids up to this many tiles run the one-step kernel with a helper wave per tile (HELP)
+// Grids up to this many tiles run the one-step kernel with a helper wave per tile (HELP): while every wave of the
+// grid — stepping and helper — is resident at once.  Measured (bench.py, HELP / plain, us per launch): Quad-v0 65 536 envs
+// 4.55 / 5.46, 98 304 5.65 / 6.42, 131 072 6.13 / 6.81, 196 608 9.23 / 8.40; Coupled 65 536 6.71 / 7.72, 98 304 7.78 / 8.63,
+// 131 072 9.64 / 9.06; Decoupled 32 768 5.86 / 6.51, 98 304 7.83 / 8.63, 131 072 9.66 / 8.98.
+#define QR_HELPER_GRID 2048       // Quad-v0 (128 VGPRs: four waves per SIMD)
+#endif
+#ifndef QR_HELPER_GRID_WRAP
+#define QR_HELPER_GRID_WRAP (QR_HELPER_GRID < 1536 ? QR_HELPER_GRID : 1536)  // the wrappers (three waves per SIMD)
 #endif
 #ifndef QR_SPEC_GRID
 // Grids up to this many waves sample their reset pool SPECULATIVELY, right after issuing their loads.  Measured on
@@ -217,7 +224,9 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   constexpr bool kHelpReward = HELP && KIND == QR_KIND_QUAD && QR_HELP_REWARD;
   __shared__ typename std::conditional<kHelpReward, PostLds<T, X>, char>::type post_lds;
   if constexpr (HELP) {
-    if (threadIdx.x >= B) {  // ---- the helper wavefront: pass 0 of the tile's reset pool -> LDS ----
+    // (the wave's first lane decides: a wave-uniform branch in the compiler's eyes too — on threadIdx.x itself everything
+    // after it counts as divergent control flow, and scalar offsets of the loads below were re-derived per lane)
+    if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= B) {  // ---- the helper wavefront: pass 0 of the tile's reset pool -> LDS ----
       float hgoal[12];
 #pragma unroll
       for (int f = 0; f < 12; ++f) hgoal[f] = f == 6 ? 1.0f : 0.0f;  // hover default (quad.py:98-101)
@@ -283,13 +292,10 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   uint32_t rcount_s = 0;  // the tile's position in the in-launch reset stream
   load_state<XV, QW>(a, first, ll, w);
   w.nominal = a.params == nullptr;
-  if (a.params) {
+  {  // (without a params buffer: a descriptor without records, the loads return 0 — no branch between the load batches)
     const SoA<float> prm(a.params, 6, L);
 #pragma unroll
     for (int f = 0; f < 6; ++f) w.prm[f] = prm.load(f, ufirst, ll);
-  } else {
-#pragma unroll
-    for (int f = 0; f < 6; ++f) w.prm[f] = 0.0f;
   }
   if constexpr (!POLICY) load_action(0, act_next);
   // The tile's position in the in-launch reset stream: a scalar load.  (Measured alternatives, bench.py at 65 536 envs:
@@ -1016,7 +1022,7 @@ static void launch_kind(const Args& a, hipStream_t s) {
         if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
         else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, false, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
       } else if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-      else if ((a.flags & QR_FLAG_AUTO_RESET) && grid.x <= (unsigned)QR_HELPER_GRID)
+      else if ((a.flags & QR_FLAG_AUTO_RESET) && grid.x <= (unsigned)(KIND == QR_KIND_QUAD ? QR_HELPER_GRID : QR_HELPER_GRID_WRAP))
         hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 0, true, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
       else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
       return;
