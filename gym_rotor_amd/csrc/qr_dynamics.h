@@ -383,11 +383,16 @@ __device__ __forceinline__ void tile_sync() {
   }
 }
 
-template <int B, int D>
-__device__ __forceinline__ void store_rows(float* __restrict__ gbase, const float (&vals)[D], float* smem, int tid, int rows) {
+// Half one: this thread's row into the LDS tile.  Half two: the tile, as it lies, to global memory with 16-byte stores.
+// (The two halves may run in different wavefronts of a workgroup, with a barrier between them.)
+template <int D>
+__device__ __forceinline__ void rows_to_lds(const float (&vals)[D], float* smem, int tid) {
 #pragma unroll
   for (int j = 0; j < D; ++j) smem[tid * D + j] = vals[j];
-  tile_sync<B>();
+}
+
+template <int B, int D>
+__device__ __forceinline__ void lds_to_rows(float* __restrict__ gbase, const float* smem, int tid, int rows) {
   if (rows == B && (reinterpret_cast<uintptr_t>(gbase) & 15u) == 0) {
     constexpr int nvec = B * D / 4;  // B is a multiple of 4
     const float4* s4 = reinterpret_cast<const float4*>(smem);
@@ -398,6 +403,13 @@ __device__ __forceinline__ void store_rows(float* __restrict__ gbase, const floa
     const int total = rows * D;
     for (int idx = tid; idx < total; idx += B) gbase[idx] = smem[idx];
   }
+}
+
+template <int B, int D>
+__device__ __forceinline__ void store_rows(float* __restrict__ gbase, const float (&vals)[D], float* smem, int tid, int rows) {
+  rows_to_lds<D>(vals, smem, tid);
+  tile_sync<B>();
+  lds_to_rows<B, D>(gbase, smem, tid, rows);
   tile_sync<B>();
 }
 

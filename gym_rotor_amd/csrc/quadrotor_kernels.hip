@@ -78,6 +78,9 @@ __device__ unsigned long long* g_stamps = nullptr;
 #ifndef QR_EARLY_STORE_GRID
 #define QR_EARLY_STORE_GRID 4096  // grids up to this many waves store a resetting wave's settled lanes before it samples
 #endif
+#ifndef QR_HELP_ROWS
+#define QR_HELP_ROWS 1
+#endif
 #ifndef QR_HELP_REWARD
 #define QR_HELP_REWARD 1
 #endif
@@ -223,6 +226,8 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   // Quad-v0's reward (an atan2, a sqrt: ~90 instructions) is formed by the helper wave as well
   constexpr bool kHelpReward = HELP && KIND == QR_KIND_QUAD && QR_HELP_REWARD;
   __shared__ typename std::conditional<kHelpReward, PostLds<T, X>, char>::type post_lds;
+  constexpr bool kHelpRows = HELP && QR_HELP_ROWS;
+  __shared__ __attribute__((aligned(16))) float smem1[kHelpRows && KT::D1 > 0 ? B * D1 : 4];  // (Decoupled: both tiles at once)
   if constexpr (HELP) {
     // (the wave's first lane decides: a wave-uniform branch in the compiler's eyes too — on threadIdx.x itself everything
     // after it counts as divergent control flow, and scalar offsets of the loads below were re-derived per lane)
@@ -262,6 +267,15 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         if ((int)hl < rows) {
           (ka.reward + first)[hl] = d ? -1.0f : interp01(r, c.rmin_mono, c.inv_nrmin_mono);  // crash override (quad.py:162-166)
           if (ka.reward_raw) (ka.reward_raw + first)[hl] = r;
+        }
+      }
+      if constexpr (kHelpRows) {  // ---- and the observation rows: the stepping wave leaves the tile in LDS, this wave carries it out ----
+        float* const ob0 = ka.obs0;
+        if (KIND != QR_KIND_QUAD || ob0 != nullptr) {
+          asm volatile("s_barrier" ::: "memory");
+          const int hl = (int)threadIdx.x - B;
+          lds_to_rows<B, D0>(ob0 + first * D0, smem, hl, rows);
+          if constexpr (KT::D1 > 0) lds_to_rows<B, D1>(ka.obs1 + first * D1, smem1, hl, rows);
         }
       }
       return;
@@ -649,6 +663,20 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 #endif
 
     // ---- outputs of step t ----
+    if constexpr (kHelpRows) {  // rows -> LDS tile(s); the helper wave stores them
+      if (KIND != QR_KIND_QUAD || ka.obs0 != nullptr) {
+        if constexpr (KIND == QR_KIND_QUAD) {  // next state in the reference's order (x, v, vec_F(R), W)
+          quat_to_R(w.q, R);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) { o0[j] = (float)w.x[j]; o0[3 + j] = (float)w.v[j]; o0[15 + j] = (float)w.W[j]; }
+#pragma unroll
+          for (int j = 0; j < 9; ++j) o0[6 + j] = (float)R[j];
+        }
+        rows_to_lds<D0>(o0, smem, tid);
+        if constexpr (KT::D1 > 0) rows_to_lds<D1>(o1, smem1, tid);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+    } else {
     if constexpr (KIND == QR_KIND_QUAD) {
       if (ka.obs0 != nullptr) {  // next state in the reference's order (x, v, vec_F(R), W)
         quat_to_R(w.q, R);
@@ -662,6 +690,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       store_rows<B, D0>(ka.obs0 + row0 * D0, o0, smem, tid, rows);
     }
     if constexpr (KT::D1 > 0) store_rows<B, D1>(ka.obs1 + row0 * D1, o1, smem, tid, rows);
+    }
     if constexpr (POLICY) {
 #pragma unroll
       for (int j = 0; j < D0; ++j) po0[j] = o0[j];

@@ -27,7 +27,8 @@ b coupled1M --kind coupled --envs 1048576 --action-batches 16 --steps 100 ; b de
 python3 bench.py --cpu-seconds 12 > "$OUT/bench_full_line.json" 2>> "$OUT/bench.err"
 # (3) build-time ablations (A/B of libraries), run-time A/B, timelines, instruction issue costs
 L=gym_rotor_amd
-QR_AB_JSON=$OUT/ab_quad_builds.json QR_AB_KINDS=quad QR_AB_SIZES=65536,1048576 python3 tools/ab_libs.py $L/libquadrotor_hip_q.so $L/libquadrotor_hip_q_floor.so $L/libquadrotor_hip_q_copy.so $L/libquadrotor_hip_q_spec.so $L/libquadrotor_hip_q_spec_noreset.so $L/libquadrotor_hip_q_pk.so $L/libquadrotor_hip_q_w4.so > "$OUT/ab_quad_builds.txt" 2>&1
+QR_AB_JSON=$OUT/ab_quad_builds.json QR_AB_KINDS=quad QR_AB_SIZES=65536,1048576 python3 tools/ab_libs.py $L/libquadrotor_hip_q.so $L/libquadrotor_hip_q_norew.so $L/libquadrotor_hip_q_nohelp.so $L/libquadrotor_hip_q_floor.so $L/libquadrotor_hip_q_copy.so $L/libquadrotor_hip_q_spec.so $L/libquadrotor_hip_q_spec_noreset.so $L/libquadrotor_hip_q_pk.so $L/libquadrotor_hip_q_w4.so > "$OUT/ab_quad_builds.txt" 2>&1
+tools/sweep_kinds.sh "$L/libquadrotor_hip_nohelp.so $L/libquadrotor_hip.so" "quad:65536 quad:98304 quad:131072 quad:196608 coupled:65536 coupled:98304 coupled:131072 decoupled:32768 decoupled:65536 decoupled:98304 decoupled:131072" > "$OUT/ab_helper_wave.txt" 2>&1
 python3 tools/evidence.py > "$OUT/runtime_ab.json" 2> "$OUT/runtime_ab.err"
 for ar in 1 0; do QR_LIB=$L/libquadrotor_hip_q_stamps.so python3 tools/stamp_timeline.py --auto-reset $ar --json "$OUT/stamps_quad65536_ar$ar.json" > "$OUT/stamps_quad65536_ar$ar.txt" 2>&1; done
 QR_LIB=$L/libquadrotor_hip_q_stamps.so python3 tools/stamp_timeline.py --auto-reset 1 --envs 1048576 --json "$OUT/stamps_quad1M_ar1.json" > "$OUT/stamps_quad1M_ar1.txt" 2>&1
