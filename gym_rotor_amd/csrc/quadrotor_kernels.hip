@@ -221,12 +221,13 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 #if QR_ABLATE == 1  // measurement build: launch floor only
   return;
 #endif
-  static_assert(!HELP || (SINGLE && !POLICY && B == 64), "the helper wave belongs to the one-step, one-wave-per-tile kernel");
-  __shared__ typename std::conditional<HELP, PoolLds<T>, char>::type pool_lds;  // (unused without HELP: dropped)
+  static_assert(!HELP || (!POLICY && B == 64), "the helper wave belongs to the one-wave-per-tile kernels");
+  // (a rollout alternates between two pools: the helper samples step t+1's while the stepping wave takes from step t's)
+  __shared__ typename std::conditional<HELP, PoolLds<T>, char>::type pool_lds[SINGLE ? 1 : 2];  // (unused without HELP: dropped)
   // Quad-v0's reward (an atan2, a sqrt: ~90 instructions) is formed by the helper wave as well
-  constexpr bool kHelpReward = HELP && KIND == QR_KIND_QUAD && QR_HELP_REWARD;
+  constexpr bool kHelpReward = HELP && SINGLE && KIND == QR_KIND_QUAD && QR_HELP_REWARD;
   __shared__ typename std::conditional<kHelpReward, PostLds<T, X>, char>::type post_lds;
-  constexpr bool kHelpRows = HELP && QR_HELP_ROWS;
+  constexpr bool kHelpRows = HELP && SINGLE && QR_HELP_ROWS;
   __shared__ __attribute__((aligned(16))) float smem1[kHelpRows && KT::D1 > 0 ? B * D1 : 4];  // (Decoupled: both tiles at once)
   if constexpr (HELP) {
     // (the wave's first lane decides: a wave-uniform branch in the compiler's eyes too — on threadIdx.x itself everything
@@ -251,8 +252,17 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       PoolRole hrole;
       pool_role(hrole, !heval && !(hflags & QR_FLAG_NO_UDM) && params != nullptr, heval, c);
       ResetPool<T> hp;
+      if constexpr (!SINGLE) {  // a rollout: one pool per env-step, each handed over at that step's barrier
+        const int hsteps = ka.n_steps;
+        for (int t = 0; t < hsteps; ++t) {
+          make_pool<T>(hp, hrole, hseed, hgfirst, rc + (uint32_t)t, 0);
+          pool_to_lds(pool_lds[t & 1], hp);
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        return;
+      }
       make_pool<T>(hp, hrole, hseed, hgfirst, rc, 0);
-      pool_to_lds(pool_lds, hp);
+      pool_to_lds(pool_lds[0], hp);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if constexpr (kHelpReward) {  // ---- then the reward of the step, from the post-step state the stepping wave left in LDS ----
         const unsigned hl = threadIdx.x - B;
@@ -615,11 +625,11 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       uint32_t r19 = 0;
       int pass0 = 0;
       if constexpr (HELP) {  // pass 0 comes from the helper wave
-        take_from_lds<T, X, TRAJ>(pool_lds, need_reset && rank < 12, rank, w, r19);
+        take_from_lds<T, X, TRAJ>(pool_lds[SINGLE ? 0 : (t & 1)], need_reset && rank < 12, rank, w, r19);
         pass0 = 1;
         if (total > 12) {  // more than 12 lanes reset at once (rare): this wave samples the further passes itself
           pool_role(role, randomise, eval_reset, c);
-          rcount_s = (uint32_t)reset_count[blockIdx.x];
+          rcount_s = (uint32_t)reset_count[blockIdx.x];  // (still this launch's base: advanced only at the end)
         }
       }
       for (int pass = pass0; 12 * pass < total; ++pass) {  // one pass unless more than 12 lanes reset at once
@@ -726,7 +736,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     }
   }
   if constexpr (HELP) {  // (the helper wave read the counter; this wave only advances it)
-    if (lane == 0) __hip_atomic_fetch_add(a.reset_count + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_fetch_add(a.reset_count + blockIdx.x, n_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else if (auto_reset && lane == 0) {
     a.reset_count[blockIdx.x] = (int32_t)(rcount_s + (uint32_t)n_steps);  // never reuse a (tile, counter)
   }
@@ -1045,13 +1055,14 @@ static void launch_kind(const Args& a, hipStream_t s) {
   }
   // qr_step in the default layout: the instantiation without the loop over env-steps
   constexpr bool kHasSingle = std::is_same<XV, float>::value && std::is_same<QW, double>::value;
+  const bool help = (a.flags & QR_FLAG_AUTO_RESET) && grid.x <= (unsigned)(KIND == QR_KIND_QUAD ? QR_HELPER_GRID : QR_HELPER_GRID_WRAP);
   if constexpr (kHasSingle) {
     if (a.n_steps == 1) {
       if (a.goal_mode != QR_GOAL_EXTERNAL) {
         if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
         else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, false, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
       } else if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-      else if ((a.flags & QR_FLAG_AUTO_RESET) && grid.x <= (unsigned)(KIND == QR_KIND_QUAD ? QR_HELPER_GRID : QR_HELPER_GRID_WRAP))
+      else if (help)
         hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 0, true, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
       else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
       return;
@@ -1061,7 +1072,15 @@ static void launch_kind(const Args& a, hipStream_t s) {
     if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
     else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, false>), grid, dim3(64), 0, s, QR_STEP_ARGS);
   } else if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-  else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+  else {
+    if constexpr (kHasSingle) {  // rollouts in the default layout: a helper wave per tile for grids it pays on
+      if (help) {
+        hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 0, false, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
+        return;
+      }
+    }
+    hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+  }
 #undef QR_STEP_ARGS
 }
 
