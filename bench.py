@@ -366,7 +366,8 @@ def main():
                          "achieved_layout_GBs": layout * N / (launch_us * 1e-6) / 1e9,
                          "note": "algorithmic bytes = SURVEY.md 8(d) (165 B + 24 B per-env params for Quad-v0); "
                                  "avg_launch_us = ms_per_step: launch-to-launch time of back-to-back launches (includes the "
-                                 "~1.8 us boundary between dependent kernels)"},
+                                 "~1.8 us boundary between dependent kernels); block 128 = a 64-lane stepping wavefront plus a "
+                                 "64-lane helper wavefront per 64-env tile (reset pool, Quad-v0 reward, observation rows)"},
         }
         if n_gpus == 1 and a.extras:
             # secondary figure: the other reset mode (no reset inside step = the reference's own semantics)

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("QR_LIB", os.path.join(_HERE, "libquadrotor_hip.so"))
 KIND_QUAD, KIND_COUPLED, KIND_DECOUPLED = 0, 1, 2
 KIND_ID = {"quad": KIND_QUAD, "coupled": KIND_COUPLED, "decoupled": KIND_DECOUPLED}
 FLAG_AUTO_RESET, FLAG_EVAL_RESET, FLAG_NO_UDM = 1, 2, 4
-ABI_VERSION = 10
+ABI_VERSION = 11
 GOAL_EXTERNAL, GOAL_MODE0, GOAL_MODE1, GOAL_MODE6 = 0, 1, 2, 3
 GOAL_ID = {None: 0, 0: 1, 1: 2, 6: 3}  # TrajectoryGenerator mode -> QR_GOAL_*
 LAYOUT_ID = {"mixed": 0, "f64": 1, "f32": 2}
@@ -117,7 +117,7 @@ def load():
     lib.qr_gae.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_float,
                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.qr_step_kernel_info.restype = C.c_char_p
-    lib.qr_step_kernel_info.argtypes = [C.c_int32, C.c_int32, C.c_int64, P(C.c_int32), P(C.c_int32)]
+    lib.qr_step_kernel_info.argtypes = [P(QrEnv), C.c_int32, P(C.c_int32), P(C.c_int32)]
     if lib.qr_abi_version() != ABI_VERSION:
         raise QuadrotorLibError(f"ABI mismatch: library {lib.qr_abi_version()} vs binding {ABI_VERSION}")
     _lib = lib

@@ -1030,6 +1030,16 @@ static int fill_env(Args& a, const QrEnv* e) {
 // what a bandwidth-bound launch needs, and barriers of 4-wave groups at 1-2 waves/SIMD stall.
 static inline int pick_block(int64_t) { return 64; }
 
+// Which instantiation a launch gets (shared by launch_kind and qr_step_kernel_info).
+static inline bool wants_adapt(const Args& a) {
+  return a.c.inv_w_adapt > 0 && (!(a.flags & QR_FLAG_AUTO_RESET) || a.c.inv_w_adapt * a.c.W_lim * 2.5 > 1.0);
+}
+static inline bool wants_helper(const Args& a, int kind, int layout) {  // a helper wave per tile (HELP)
+  const unsigned tiles = (unsigned)((a.n + 63) / 64);
+  return layout == QR_LAYOUT_MIXED && a.act_out == nullptr && a.goal_mode == QR_GOAL_EXTERNAL && !wants_adapt(a) &&
+         (a.flags & QR_FLAG_AUTO_RESET) && tiles <= (unsigned)(kind == QR_KIND_QUAD ? QR_HELPER_GRID : QR_HELPER_GRID_WRAP);
+}
+
 template <int KIND, typename XV, typename QW>
 static void launch_kind(const Args& a, hipStream_t s) {
   const dim3 grid((unsigned)((a.n + 63) / 64));
@@ -1038,8 +1048,7 @@ static void launch_kind(const Args& a, hipStream_t s) {
   // that took it there (done): Quad-v0 |W_i| < W_lim, Coupled |W_i - Wd_i| < W_lim, Decoupled
   // |W - Wd| < 2 W_lim (|ew12_i| < W_lim and |eW3| < W_lim).  For goal rates |Wd| <= W_lim / 2
   // and w_adapt >= 2.5 W_lim (the default 16 rad/s is) the plain kernel computes the same bits.
-  const bool adapt = a.c.inv_w_adapt > 0 &&
-                     (!(a.flags & QR_FLAG_AUTO_RESET) || a.c.inv_w_adapt * a.c.W_lim * 2.5 > 1.0);
+  const bool adapt = wants_adapt(a);
 #define QR_STEP_ARGS a.pos_vel, a.att_rate, a.action, a.params, a.integ, ((a.flags & QR_FLAG_AUTO_RESET) ? a.reset_count : nullptr), (int32_t)a.n, (int32_t)a.ld, a
   if constexpr (KIND != QR_KIND_QUAD) {
     if (a.act_out != nullptr) {  // qr_rollout_actor
@@ -1055,7 +1064,7 @@ static void launch_kind(const Args& a, hipStream_t s) {
   }
   // qr_step in the default layout: the instantiation without the loop over env-steps
   constexpr bool kHasSingle = std::is_same<XV, float>::value && std::is_same<QW, double>::value;
-  const bool help = (a.flags & QR_FLAG_AUTO_RESET) && grid.x <= (unsigned)(KIND == QR_KIND_QUAD ? QR_HELPER_GRID : QR_HELPER_GRID_WRAP);
+  const bool help = kHasSingle && wants_helper(a, KIND, QR_LAYOUT_MIXED);
   if constexpr (kHasSingle) {
     if (a.n_steps == 1) {
       if (a.goal_mode != QR_GOAL_EXTERNAL) {
@@ -1318,12 +1327,13 @@ int qr_gae(const float* reward, const uint8_t* done, const float* value, const f
   return (int)hipGetLastError();
 }
 
-const char* qr_step_kernel_info(int32_t kind, int32_t layout, int64_t num_envs, int32_t* grid, int32_t* block) {
-  const int b = qr::pick_block(num_envs);
-  if (grid) *grid = (int32_t)((num_envs + b - 1) / b);
-  if (block) *block = b;
-  (void)layout;
-  switch (kind) {
+const char* qr_step_kernel_info(const QrEnv* env, int32_t n_steps, int32_t* grid, int32_t* block) {
+  qr::Args a{};
+  if (qr::fill_env(a, env) != 0) return "";
+  a.n_steps = n_steps;
+  if (grid) *grid = (int32_t)((a.n + 63) / 64);
+  if (block) *block = qr::wants_helper(a, env->kind, env->layout) ? 128 : 64;
+  switch (env->kind) {
     case QR_KIND_QUAD: return "qr::step_kernel<0,...>";
     case QR_KIND_COUPLED: return "qr::step_kernel<1,...>";
     case QR_KIND_DECOUPLED: return "qr::step_kernel<2,...>";

@@ -645,10 +645,10 @@ class QuadVecEnv:
     def episode_steps(self):
         return self._steps
 
-    def kernel_info(self):
+    def kernel_info(self, n_steps=1):
+        """(kernel family, workgroups, threads per workgroup) of the launch `step` (n_steps=1) / `rollout` uses."""
         g, b = C.c_int32(), C.c_int32()
-        name = self._lib.qr_step_kernel_info(_lib.KIND_ID[self.kind], _lib.LAYOUT_ID[self.layout],
-                                             self.num_envs, C.byref(g), C.byref(b))
+        name = self._lib.qr_step_kernel_info(C.byref(self._cenv), n_steps, C.byref(g), C.byref(b))
         return name.decode(), g.value, b.value
 
     def render(self, *a, **k):

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define QR_ABI_VERSION 10
+#define QR_ABI_VERSION 11
 
 /* env kinds */
 #define QR_KIND_QUAD      0 /* QuadEnv            gym_rotor/envs/quad.py:19            */
@@ -296,8 +296,11 @@ int qr_gae(const float* reward, const uint8_t* done, const float* value, const f
 /* Host-side helpers (no device work). */
 void qr_default_coeffs(QrCoeffs* c);
 int  qr_abi_version(void);
-/* Kernel family name + launch geometry used for `num_envs` envs (for profiling tools). */
-const char* qr_step_kernel_info(int32_t kind, int32_t layout, int64_t num_envs, int32_t* grid, int32_t* block);
+/* Kernel family name + launch geometry qr_step (n_steps = 1) / qr_rollout would use for this env (for profiling
+ * tools): `grid` workgroups of `block` threads — 64 (one wavefront per 64-env tile), or 128 where the launcher adds a
+ * helper wavefront per tile (QR_FLAG_AUTO_RESET, default layout, grids in the launch-latency regime).  "" if the env
+ * descriptor is invalid. */
+const char* qr_step_kernel_info(const QrEnv* env, int32_t n_steps, int32_t* grid, int32_t* block);
 
 #ifdef __cplusplus
 }

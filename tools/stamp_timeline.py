@@ -4,8 +4,8 @@
     hipcc ... -DQR_ONLY_KIND=0 -DQR_ONLY_LAYOUT=0 -DQR_STAMPS -o gym_rotor_amd/libquadrotor_hip_q_stamps.so ...
     QR_LIB=gym_rotor_amd/libquadrotor_hip_q_stamps.so python tools/stamp_timeline.py [--envs 65536] [--auto-reset 1]
 
-Every wave records s_memrealtime (100 MHz, chip-wide) at: 0 entry, 1 reset pool sampled (speculative
-part done), 2 loads arrived (first use of the working set), 3 integrated, 4 reward/done formed,
+Every wave records s_memrealtime (100 MHz, chip-wide) at: 0 entry, 1 kernarg scalars read (in
+speculative builds: and the pool sampled), 2 loads arrived (first use of the working set), 3 integrated, 4 reward/done formed,
 5 reset block done, 6 stores issued.  The kernel is replayed from a hipGraph of K launches; the
 stamps of the LAST launch are read back.  Output: per-stamp distribution over waves relative to the
 earliest wave's entry, for waves with and without a resetting lane — where a launch's time goes.
@@ -64,7 +64,7 @@ st = stamps.cpu().numpy()
 t = (st[:, :7] - st[:, 0].min()) * 0.01  # us since the first wave's entry (last launch of the replay)
 has_reset = st[:, 7] != 0
 out = {"envs": a.envs, "kind": a.kind, "auto_reset": a.auto_reset, "waves": nw, "us_per_launch_with_stamps": us_per_launch,
-       "frac_waves_with_reset": float(has_reset.mean()), "names": ["entry", "pool sampled", "loads arrived", "integrated",
+       "frac_waves_with_reset": float(has_reset.mean()), "names": ["entry", "arguments read", "loads arrived", "integrated",
                                                                     "reward/done", "reset block done", "stores issued"]}
 print(f"{a.kind} {a.envs} envs, auto_reset={a.auto_reset}: {us_per_launch:.2f} us/launch (stamped build), "
       f"{100 * has_reset.mean():.0f} % of the waves had a resetting lane; kernel span {t[:, 6].max():.2f} us")

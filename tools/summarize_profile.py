@@ -20,11 +20,29 @@ f = find("stats", "*kernel_trace.csv")
 if f:
     rows = [r for r in csv.DictReader(open(f)) if "step_kernel" in r["Kernel_Name"]]
     if rows:
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
         last = rows[-1]
-        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+        st = [int(r["Start_Timestamp"]) for r in rows]
+        en = [int(r["End_Timestamp"]) for r in rows]
+        d = sorted(e - b for b, e in zip(st, en))
+        per = sorted(b1 - b0 for b0, b1 in zip(st[:-1], st[1:]))
+        gap = sorted(b1 - e0 for e0, b1 in zip(en[:-1], st[1:]))
+        pc = lambda a, q: a[min(len(a) - 1, int(q * len(a)))]
         print(f"step_kernel dispatches {len(d)}: mean {statistics.mean(d):.0f} ns median {statistics.median(d):.0f} ns; "
               f"grid {last['Grid_Size_X']} wg {last['Workgroup_Size_X']} VGPR {last['VGPR_Count']} AGPR {last['Accum_VGPR_Count']} "
               f"SGPR {last['SGPR_Count']} LDS {last['LDS_Block_Size']} scratch {last['Scratch_Size']}")
+        # Consecutive dispatches of the graph: start(i+1) == end(i) when the GPU is the bottleneck (the duration then IS the
+        # launch-to-launch period).  Gaps mean the tool could not keep up with the dispatch rate: its per-dispatch cost
+        # (~6 us here) then bounds the run and inflates the durations of kernels shorter than that.
+        print(f"  duration ns p10/p50/p90: {pc(d, .1)} / {pc(d, .5)} / {pc(d, .9)};  start-to-start period p10/p50/p90: "
+              f"{pc(per, .1)} / {pc(per, .5)} / {pc(per, .9)};  idle gap before a dispatch p50/p90: {pc(gap, .5)} / {pc(gap, .9)}")
+f = os.path.join(out, "stats.log")
+if os.path.exists(f):
+    import json, re
+    for line in open(f, errors="replace"):
+        if line.startswith("{") and "ms_per_step" in line:
+            j = json.loads(line)
+            print(f"  bench.py UNDER the profiler: {j['ms_per_step'] * 1e3:.3f} us per step (its un-profiled figure is in bench_*.json)")
 
 
 def pmc(sub, counter, match):
