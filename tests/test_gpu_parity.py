@@ -533,6 +533,48 @@ def test_one_million_envs_ten_substeps_and_shard_equivalence():
     assert (r[d] == -1.0).all() and ((r[~d] >= 0) & (r[~d] <= 1)).all()
 
 
+@pytest.mark.parametrize("kind", KINDS)
+def test_helper_wave_launch_equals_the_plain_one(kind):
+    """Small grids run the one-step kernel with a helper wavefront per tile (reset pool, Quad-v0 reward, observation
+    rows formed / carried out by the second wave of the workgroup), large ones without.  The same envs stepped as a
+    shard small enough for the helper launch and inside a batch too large for it give the same bits — state,
+    observation rows, rewards (also the raw ones), dones, terminal observations, episode counters — and so does a
+    rollout, whose helper wave hands over one pool per env-step."""
+    n, shard, rank, T = 196608, 32768, 3, 160
+    adim = 5 if kind == "decoupled" else 4
+    g = torch.Generator(device="cuda"); g.manual_seed(17)
+    acts = torch.rand(T, n, adim, device="cuda", generator=g) * 2 - 1
+    big = _env(kind, n, seed=21, auto_reset=True, obs_rows=True, final_obs=True)
+    part = _env(kind, shard, seed=21, auto_reset=True, obs_rows=True, final_obs=True, env_offset=rank * shard)
+    assert big.kernel_info()[2] == 64 and part.kernel_info()[2] == 128      # threads per workgroup: plain / with helper
+    lo, hi = rank * shard, (rank + 1) * shard
+    for e in (big, part):
+        e.reset("train")
+        if kind != "quad":
+            e.get_norm_error_state()
+    dones = 0
+    for t in range(T // 2):
+        o, r, d, _, info = big.step(acts[t])
+        o2, r2, d2, _, info2 = part.step(acts[t, lo:hi].contiguous())
+        for a_, b_ in zip(_obs_list(o), _obs_list(o2)):
+            assert torch.equal(a_[lo:hi], b_)
+        assert torch.equal(r[lo:hi], r2) and torch.equal(d[lo:hi], d2)
+        fo, fo2 = big.final_observation(), part.final_observation()
+        reset_rows = d2.reshape(shard, -1).any(dim=1)
+        for a_, b_ in zip(_obs_list(fo), _obs_list(fo2)):
+            assert torch.equal(a_[lo:hi][reset_rows], b_[reset_rows])
+        dones += int(reset_rows.sum())
+    assert dones > 1000
+    assert torch.equal(big.get_current_state()[lo:hi], part.get_current_state())
+    assert torch.equal(big._episode[lo:hi], part._episode)
+    # the second half as ONE rollout launch on the shard (helper wave, a pool per step) against steps on the batch
+    ro = part.rollout(acts[T // 2:, lo:hi].contiguous())
+    for t in range(T // 2, T):
+        o, r, d, _, _ = big.step(acts[t])
+        assert torch.equal(r[lo:hi], ro["reward"][t - T // 2]) and torch.equal(d[lo:hi], ro["terminated"][t - T // 2])
+    assert torch.equal(big.get_current_state()[lo:hi], part.get_current_state())
+
+
 def _kill(env, kill):
     """Make the envs in `kill` terminate in the next step: x far outside the arena."""
     st = _np(env.get_current_state())
