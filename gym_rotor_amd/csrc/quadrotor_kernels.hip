@@ -78,6 +78,12 @@ __device__ unsigned long long* g_stamps = nullptr;
 #ifndef QR_EARLY_STORE_GRID
 #define QR_EARLY_STORE_GRID 4096  // grids up to this many waves store a resetting wave's settled lanes before it samples
 #endif
+#ifndef QR_LAZY_ROLE
+#define QR_LAZY_ROLE 1
+#endif
+#ifndef QR_TAKE_VIA_LDS
+#define QR_TAKE_VIA_LDS 1
+#endif
 #ifndef QR_HELP_ROWS
 #define QR_HELP_ROWS 1
 #endif
@@ -225,8 +231,9 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   // (a rollout alternates between two pools: the helper samples step t+1's while the stepping wave takes from step t's)
   __shared__ typename std::conditional<HELP, PoolLds<T>, char>::type pool_lds[SINGLE ? 1 : 2];  // (unused without HELP: dropped)
   // Quad-v0's reward (an atan2, a sqrt: ~90 instructions) is formed by the helper wave as well
-  constexpr bool kHelpReward = HELP && SINGLE && KIND == QR_KIND_QUAD && QR_HELP_REWARD;
+  constexpr bool kHelpReward = HELP && SINGLE && !TRAJ && KIND == QR_KIND_QUAD && QR_HELP_REWARD;  // (TRAJ: the goal lives in the stepping wave's registers)
   __shared__ typename std::conditional<kHelpReward, PostLds<T, X>, char>::type post_lds;
+  __shared__ PoolLds<T> own_pool;  // pools this wave samples itself (no helper; or a tile's 13th.. resetting lane)
   constexpr bool kHelpRows = HELP && SINGLE && QR_HELP_ROWS;
   __shared__ __attribute__((aligned(16))) float smem1[kHelpRows && KT::D1 > 0 ? B * D1 : 4];  // (Decoupled: both tiles at once)
   if constexpr (HELP) {
@@ -344,7 +351,9 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   const int n_steps = SINGLE ? 1 : ka.n_steps;
   const bool eval_reset = (flags & QR_FLAG_EVAL_RESET) != 0;
   const bool randomise = !eval_reset && !(flags & QR_FLAG_NO_UDM) && a.params != nullptr;
+#if !QR_LAZY_ROLE
   if (!HELP && auto_reset) pool_role(role, randomise, eval_reset, c);  // (scalars only: runs while the loads are in flight)
+#endif
 #pragma unroll
   for (int f = 0; f < 12; ++f) w.goal[f] = f == 6 ? 1.0f : 0.0f;  // hover default (quad.py:98-101)
   if (!TRAJ && goal_ptr) {  // (with the fused generator the goal is formed in registers every step)
@@ -632,11 +641,26 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
           rcount_s = (uint32_t)reset_count[blockIdx.x];  // (still this launch's base: advanced only at the end)
         }
       }
+#if QR_LAZY_ROLE
+      // The lane's role constants are formed HERE, not while the loads are in flight: twelve values held across the whole
+      // step cost the plain kernel its fourth wave per SIMD (142 -> 128 VGPRs), and the grids that run it are either large
+      // (other waves cover this) or take the helper-wave instantiation.
+      if (!HELP) pool_role(role, randomise, eval_reset, c);
+#endif
       for (int pass = pass0; 12 * pass < total; ++pass) {  // one pass unless more than 12 lanes reset at once
         const int slot = rank - 12 * pass;
         if (!(have_pool && pass == 0)) make_pool<T>(pool, role, seed, gfirst, rcount_s + (uint32_t)t, pass);
 #if QR_ABLATE != 7
+#if QR_TAKE_VIA_LDS
+        // through LDS (six 16-byte reads per taking lane) rather than 23 ds_bpermute with all their results in flight at
+        // once: 128 instead of 142 VGPRs for the plain Quad-v0 kernel, i.e. four waves per SIMD instead of three
+        pool_to_lds(own_pool, pool);
+        tile_sync<B>();
+        take_from_lds<T, X, TRAJ>(own_pool, need_reset && slot >= 0 && slot < 12, slot, w, r19);
+        tile_sync<B>();
+#else
         take_from_pool<T, X, TRAJ>(pool, need_reset && slot >= 0 && slot < 12, slot, w, r19);
+#endif
 #endif
       }
       if (need_reset) {
@@ -1040,6 +1064,12 @@ static inline bool wants_helper(const Args& a, int kind, int layout) {  // a hel
          (a.flags & QR_FLAG_AUTO_RESET) && tiles <= (unsigned)(kind == QR_KIND_QUAD ? QR_HELPER_GRID : QR_HELPER_GRID_WRAP);
 }
 
+static inline bool wants_helper_traj(const Args& a, int kind) {  // the same with the fused goal generator (one-step launches)
+  const unsigned tiles = (unsigned)((a.n + 63) / 64);
+  return a.act_out == nullptr && a.goal_mode != QR_GOAL_EXTERNAL && !wants_adapt(a) && (a.flags & QR_FLAG_AUTO_RESET) &&
+         tiles <= (unsigned)(kind == QR_KIND_QUAD ? QR_HELPER_GRID : QR_HELPER_GRID_WRAP);
+}
+
 template <int KIND, typename XV, typename QW>
 static void launch_kind(const Args& a, hipStream_t s) {
   const dim3 grid((unsigned)((a.n + 63) / 64));
@@ -1065,10 +1095,12 @@ static void launch_kind(const Args& a, hipStream_t s) {
   // qr_step in the default layout: the instantiation without the loop over env-steps
   constexpr bool kHasSingle = std::is_same<XV, float>::value && std::is_same<QW, double>::value;
   const bool help = kHasSingle && wants_helper(a, KIND, QR_LAYOUT_MIXED);
+  const bool help_traj = kHasSingle && a.n_steps == 1 && wants_helper_traj(a, KIND);  // (fused goal generator: one-step launches only)
   if constexpr (kHasSingle) {
     if (a.n_steps == 1) {
       if (a.goal_mode != QR_GOAL_EXTERNAL) {
         if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+        else if (help_traj) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, false, 0, true, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
         else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, false, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
       } else if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
       else if (help)
@@ -1332,7 +1364,9 @@ const char* qr_step_kernel_info(const QrEnv* env, int32_t n_steps, int32_t* grid
   if (qr::fill_env(a, env) != 0) return "";
   a.n_steps = n_steps;
   if (grid) *grid = (int32_t)((a.n + 63) / 64);
-  if (block) *block = qr::wants_helper(a, env->kind, env->layout) ? 128 : 64;
+  const bool helper = qr::wants_helper(a, env->kind, env->layout) ||
+                      (env->layout == QR_LAYOUT_MIXED && n_steps == 1 && qr::wants_helper_traj(a, env->kind));
+  if (block) *block = helper ? 128 : 64;
   switch (env->kind) {
     case QR_KIND_QUAD: return "qr::step_kernel<0,...>";
     case QR_KIND_COUPLED: return "qr::step_kernel<1,...>";

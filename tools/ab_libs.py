@@ -22,7 +22,9 @@ out = {}
 for n in [int(x) for x in os.environ.get('QR_AB_SIZES', '65536,1048576').split(',')]:
     for kind in os.environ.get('QR_AB_KINDS', 'quad,coupled,decoupled').split(','):
         for ar in [int(x) for x in os.environ.get('QR_AB_AR', '1,0').split(',')]:
-            env = QuadVecEnv(kind, n, device=dev, auto_reset=bool(ar), obs_rows=(kind != "quad"), substeps=int(os.environ.get('QR_AB_SUBSTEPS', '1')))
+            gm = os.environ.get('QR_AB_GOAL_MODE')  # fused goal generator (trajectory_generator.py mode) instead of external goals
+            env = QuadVecEnv(kind, n, device=dev, auto_reset=bool(ar), obs_rows=(kind != "quad"), substeps=int(os.environ.get('QR_AB_SUBSTEPS', '1')),
+                             **({"goal_mode": int(gm)} if gm else {}))
             env.reset("train")
             acts = [torch.rand(n, env.action_dim, device=dev) * 2 - 1 for _ in range(8)]
             s = torch.cuda.Stream()
