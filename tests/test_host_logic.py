@@ -182,6 +182,43 @@ def test_abi_argument_errors_without_gpu():
     assert lib.qr_step(C.byref(e4), 0x6000, 1, C.byref(o4), None) == -1      # reset_count missing
 
 
+def test_launch_geometry_rule_without_gpu():
+    """qr_step_kernel_info (host-only) reports the launch the step launcher would use: one 64-lane wavefront per 64-env
+    tile, plus a helper wavefront (128 threads per workgroup) exactly for: in-launch auto-reset, default layout, no rate
+    adaptivity in reach, and grids of <= 2048 tiles (Quad-v0) / <= 1536 (wrappers); with the fused goal generator only
+    for one-step launches."""
+    L = _lib()
+    lib = L.load()
+
+    def info(kind, n, flags, layout=0, n_steps=1, goal_mode=None, w_adapt=None):
+        e = L.QrEnv()
+        lib.qr_default_coeffs(C.byref(e.coeffs))
+        e.kind, e.layout, e.num_envs, e.pos_vel, e.att_rate, e.flags = kind, layout, n, 0x1000, 0x2000, flags
+        if goal_mode is not None:
+            e.goal_mode, e.traj = goal_mode, 0x7000
+        if w_adapt is not None:
+            e.coeffs.w_adapt = w_adapt
+        g, b = C.c_int32(), C.c_int32()
+        name = lib.qr_step_kernel_info(C.byref(e), n_steps, C.byref(g), C.byref(b))
+        return name.decode(), g.value, b.value
+
+    hdr = open(os.path.join(ROOT, "include", "quadrotor_hip.h")).read()
+    AR = int(re.search(r"#define QR_FLAG_AUTO_RESET\s+(\S+)", hdr).group(1).rstrip("u"), 0)
+    GOAL_EXTERNAL = int(re.search(r"#define QR_GOAL_EXTERNAL\s+(\d+)", hdr).group(1))
+    assert info(0, 65536, AR) == ("qr::step_kernel<0,...>", 1024, 128)
+    assert info(0, 65536 + 1, AR)[1:] == (1025, 128)                      # ragged tail: one more tile
+    assert info(0, 131072, AR)[2] == 128 and info(0, 131072 + 64, AR)[2] == 64
+    assert info(1, 98304, AR)[2] == 128 and info(1, 98304 + 64, AR)[2] == 64
+    assert info(2, 32768, AR)[2] == 128 and info(2, 131072, AR)[2] == 64
+    assert info(0, 65536, 0)[2] == 64                                      # no in-launch reset: nothing for a helper to sample
+    assert info(0, 65536, AR, layout=1)[2] == 64 and info(0, 65536, AR, layout=2)[2] == 64
+    assert info(0, 65536, AR, w_adapt=3.0)[2] == 64                        # rate adaptivity within reach of |W| < W_lim: the adaptive kernel
+    assert info(0, 65536, AR, n_steps=100)[2] == 128                       # rollouts too
+    gm = int(re.search(r"#define QR_GOAL_MODE0\s+(\d+)", hdr).group(1))
+    assert GOAL_EXTERNAL == 0 and info(1, 65536, AR, goal_mode=gm)[2] == 128 and info(1, 65536, AR, goal_mode=gm, n_steps=8)[2] == 64
+    assert info(0, -5, AR)[0] == ""                                        # invalid descriptor
+
+
 def test_no_cpu_fallback():
     """Without a GPU the env refuses to exist; without the library the import of the binding raises."""
     _lib()
