@@ -78,6 +78,9 @@ __device__ unsigned long long* g_stamps = nullptr;
 #ifndef QR_EARLY_STORE_GRID
 #define QR_EARLY_STORE_GRID 4096  // grids up to this many waves store a resetting wave's settled lanes before it samples
 #endif
+#ifndef QR_HELP_POLICY
+#define QR_HELP_POLICY 1  // 0: no helper wave in qr_rollout_actor
+#endif
 #ifndef QR_LAZY_ROLE
 #define QR_LAZY_ROLE 1
 #endif
@@ -183,7 +186,7 @@ struct PostLds {
 // so the helper runs in issue slots that are otherwise empty, and the stepping wave's reset block shrinks from
 // ~230 instructions (Philox, role scaling, attitude, 24 cross-lane reads) to six LDS reads.
 template <int KIND, typename XV, typename QW, int B, bool TRAJ, bool ADAPT, int POLICY = 0, bool SINGLE = false, bool HELP = false>
-__global__ __launch_bounds__(B + (HELP ? 64 : 0), ((TRAJ || POLICY) ? 1 : QR_WAVES_PER_SIMD))
+__global__ __launch_bounds__(B + (HELP ? 64 : 0), ((HELP && POLICY) ? 2 : (TRAJ || POLICY) ? 1 : QR_WAVES_PER_SIMD))  // (HELP: both waves of every tile resident)
 void step_kernel(void* pos_vel, void* att_rate, const float* action, float* params, float* integ, int32_t* reset_count,
                  int32_t n_envs, int32_t ld_envs, const Args a_in) {
   // The leading scalar arguments duplicate the fields of Args that the wave's loads depend on: as
@@ -227,15 +230,17 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 #if QR_ABLATE == 1  // measurement build: launch floor only
   return;
 #endif
-  static_assert(!HELP || (!POLICY && B == 64), "the helper wave belongs to the one-wave-per-tile kernels");
+  static_assert(!HELP || B == 64, "the helper wave belongs to the one-wave-per-tile kernels");
   // (a rollout alternates between two pools: the helper samples step t+1's while the stepping wave takes from step t's)
-  __shared__ typename std::conditional<HELP, PoolLds<T>, char>::type pool_lds[SINGLE ? 1 : 2];  // (unused without HELP: dropped)
+  __shared__ typename std::conditional<HELP, PoolLds<T>, char>::type pool_lds[(SINGLE || POLICY) ? 1 : 2];  // (unused without HELP: dropped)
+  // (POLICY with a helper wave) the step's exploration noise, sampled a step ahead by the helper: [t & 1][lane][8]
+  __shared__ __attribute__((aligned(16))) float eps_lds[HELP && POLICY ? 2 * 64 * 8 : 4];
   // Quad-v0's reward (an atan2, a sqrt: ~90 instructions) is formed by the helper wave as well
   constexpr bool kHelpReward = HELP && SINGLE && !TRAJ && KIND == QR_KIND_QUAD && QR_HELP_REWARD;  // (TRAJ: the goal lives in the stepping wave's registers)
   __shared__ typename std::conditional<kHelpReward, PostLds<T, X>, char>::type post_lds;
   __shared__ PoolLds<T> own_pool;  // pools this wave samples itself (no helper; or a tile's 13th.. resetting lane)
   constexpr bool kHelpRows = HELP && SINGLE && QR_HELP_ROWS;
-  __shared__ __attribute__((aligned(16))) float smem1[kHelpRows && KT::D1 > 0 ? B * D1 : 4];  // (Decoupled: both tiles at once)
+  __shared__ __attribute__((aligned(16))) float smem1[(kHelpRows || (HELP && POLICY)) && KT::D1 > 0 ? B * D1 : 4];  // (Decoupled: both tiles at once)
   if constexpr (HELP) {
     // (the wave's first lane decides: a wave-uniform branch in the compiler's eyes too — on threadIdx.x itself everything
     // after it counts as divergent control flow, and scalar offsets of the loads below were re-derived per lane)
@@ -259,6 +264,44 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       PoolRole hrole;
       pool_role(hrole, !heval && !(hflags & QR_FLAG_NO_UDM) && params != nullptr, heval, c);
       ResetPool<T> hp;
+      if constexpr (POLICY != 0) {
+        // qr_rollout_actor.  Per env-step t the helper meets the stepping wave twice: B1(t), when the step's noise is in
+        // LDS and the tile holds the observation rows of step t-1 (which this wave then carries out), and B2(t), when the
+        // step's reset pool and the NEXT step's noise are in LDS.
+        const int hsteps = ka.n_steps;
+        const int hl = (int)threadIdx.x - B;
+        const bool own_noise = !ka.deterministic && ka.noise == nullptr;
+        const uint64_t nseed = ka.noise_seed, sbase = ka.step_base, hgid = (uint64_t)(ka.env_offset + first + hl);
+        float* const ob0 = ka.obs0;
+        float* const ob1 = KT::D1 > 0 ? ka.obs1 : nullptr;
+        auto make_eps = [&](int t) {
+          if (!own_noise) return;
+          float z[4];
+          normal4(z, nseed, hgid, sbase + (uint64_t)t, 0u);
+          float* e = eps_lds + ((t & 1) * 64 + hl) * 8;
+          *reinterpret_cast<float4*>(e) = make_float4(z[0], z[1], z[2], z[3]);
+          if constexpr (A > 4) {
+            normal4(z, nseed, hgid, sbase + (uint64_t)t, 1u);
+            e[4] = z[0];
+          }
+        };
+        make_eps(0);
+        for (int t = 0; t < hsteps; ++t) {
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B1(t)
+          if (t > 0) {
+            lds_to_rows<B, D0>(ob0 + ((int64_t)(t - 1) * n_envs + first) * D0, smem, hl, rows);
+            if constexpr (KT::D1 > 0) lds_to_rows<B, D1>(ob1 + ((int64_t)(t - 1) * n_envs + first) * D1, smem1, hl, rows);
+          }
+          make_pool<T>(hp, hrole, hseed, hgfirst, rc + (uint32_t)t, 0);
+          pool_to_lds(pool_lds[0], hp);
+          if (t + 1 < hsteps) make_eps(t + 1);
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B2(t)
+        }
+        asm volatile("s_barrier" ::: "memory");  // the tile of the last step
+        lds_to_rows<B, D0>(ob0 + ((int64_t)(hsteps - 1) * n_envs + first) * D0, smem, hl, rows);
+        if constexpr (KT::D1 > 0) lds_to_rows<B, D1>(ob1 + ((int64_t)(hsteps - 1) * n_envs + first) * D1, smem1, hl, rows);
+        return;
+      }
       if constexpr (!SINGLE) {  // a rollout: one pool per env-step, each handed over at that step's barrier
         const int hsteps = ka.n_steps;
         for (int t = 0; t < hsteps; ++t) {
@@ -404,7 +447,10 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     if constexpr (KT::D1 > 0) load_rows<B, D1>(ka.obs1_in + first * D1, po1, smem, tid, rows);
     actor0.load(ka.actor[0], tid);
     if constexpr (KT::D1 > 0) Actor1::fill(wsm, ka.actor[1], tid);
-    __syncthreads();
+    // (HELP) the tile always holds the current observation rows: written here and at the end of every step, read by the
+    // first layer's MFMAs and — as the rows of the step that produced them — carried out by the helper wave
+    if constexpr (HELP) rows_to_lds<D0>(po0, smem, tid);
+    tile_sync<B>();
   }
 
   for (int t = 0; t < n_steps; ++t) {
@@ -412,9 +458,11 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     if constexpr (POLICY) {
       float pre[A], ls[A], eps[A], logp[A];
       // the wave's observation rows -> LDS tile [lane][D0] (B operands of the first layer)
+      if constexpr (!HELP) {
 #pragma unroll
-      for (int j = 0; j < D0; ++j) smem[tid * D0 + j] = po0[j];
-      __syncthreads();
+        for (int j = 0; j < D0; ++j) smem[tid * D0 + j] = po0[j];
+        tile_sync<B>();
+      }
       {
         float p0[4], l0[4];
         actor0.heads(smem, tid, p0, l0);
@@ -428,6 +476,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       }
 #pragma unroll
       for (int j = 0; j < A; ++j) eps[j] = 0.0f;
+      if constexpr (HELP) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B1(t): see the helper wave
       if (!ka.deterministic) {
         if (ka.noise != nullptr) {  // injected draws [T][N][A]
           if (active) {
@@ -435,6 +484,11 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 #pragma unroll
             for (int j = 0; j < A; ++j) eps[j] = nbase[lane * A + j];
           }
+        } else if constexpr (HELP) {  // sampled by the helper wave, one step ahead
+          const float* e = eps_lds + ((t & 1) * 64 + tid) * 8;
+          const float4 z4 = *reinterpret_cast<const float4*>(e);
+          eps[0] = z4.x; eps[1] = z4.y; eps[2] = z4.z; eps[3] = z4.w;
+          if constexpr (A > 4) eps[A - 1] = e[4];
         } else {
           float z[4];
           normal4(z, ka.noise_seed, (uint64_t)(ka.env_offset + i), ka.step_base + (uint64_t)t, 0u);
@@ -446,7 +500,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
           }
         }
       }
-      __syncthreads();  // the tile is reused by the row stores below
+      if constexpr (!HELP) tile_sync<B>();  // the tile is reused by the row stores below
       actor_sample<4, GENERAL>(ka.actor[0].squash, actor0.ls_head, &pre[0], &ls[0], &eps[0], ka.deterministic != 0, ka.max_action, &act[0], &logp[0]);
       if constexpr (A > 4)
         actor_sample<1, GENERAL>(ka.actor[1].squash, ka.actor[1].ls_w != nullptr, &pre[A - 1], &ls[A - 1], &eps[A - 1], ka.deterministic != 0,
@@ -634,7 +688,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       uint32_t r19 = 0;
       int pass0 = 0;
       if constexpr (HELP) {  // pass 0 comes from the helper wave
-        take_from_lds<T, X, TRAJ>(pool_lds[SINGLE ? 0 : (t & 1)], need_reset && rank < 12, rank, w, r19);
+        take_from_lds<T, X, TRAJ>(pool_lds[(SINGLE || POLICY) ? 0 : (t & 1)], need_reset && rank < 12, rank, w, r19);
         pass0 = 1;
         if (total > 12) {  // more than 12 lanes reset at once (rare): this wave samples the further passes itself
           pool_role(role, randomise, eval_reset, c);
@@ -710,6 +764,10 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         if constexpr (KT::D1 > 0) rows_to_lds<D1>(o1, smem1, tid);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       }
+    } else if constexpr (HELP && POLICY != 0) {  // the tile is next step's MFMA operand AND this step's rows (helper wave)
+      rows_to_lds<D0>(o0, smem, tid);
+      if constexpr (KT::D1 > 0) rows_to_lds<D1>(o1, smem1, tid);
+      tile_sync<B>();
     } else {
     if constexpr (KIND == QR_KIND_QUAD) {
       if (ka.obs0 != nullptr) {  // next state in the reference's order (x, v, vec_F(R), W)
@@ -734,6 +792,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     if constexpr (!SINGLE) unpack_quat(qp, w.q);  // the next env-step starts from what a single-step launch would have re-loaded
   }
 
+  if constexpr (HELP && POLICY != 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the last step's tile: see the helper wave
   // ---- write the working set back ----
   if (active) {
     if (!(SINGLE && stored_early)) {
@@ -1085,6 +1144,16 @@ static void launch_kind(const Args& a, hipStream_t s) {
       const bool general = a.actor[0].ls_w || a.actor[0].squash != QR_ACTOR_TANH_MEAN ||
                            (KIND == QR_KIND_DECOUPLED && (a.actor[1].ls_w || a.actor[1].squash != QR_ACTOR_TANH_MEAN));
       const bool traj = a.goal_mode != QR_GOAL_EXTERNAL;
+      if constexpr (std::is_same<XV, float>::value && std::is_same<QW, double>::value) {
+        // PPO / TD3 actors with in-launch resets and external goals, on grids where every wave is resident: a helper wave
+        // per tile (noise, reset pool, observation rows).  Measured, Coupled 65 536 envs, T = 32: 5.37 -> 4.51 us per step;
+        // with the fused goal generator the same split measured SLOWER (5.65 -> 6.25 us per step, tools/ppo_rollout_bench.py;
+        // both waves of a tile must be resident, which caps the kernel at 256 registers) and is not instantiated.
+        if (QR_HELP_POLICY && !general && !traj && (a.flags & QR_FLAG_AUTO_RESET) && grid.x <= (unsigned)QR_HELPER_GRID_WRAP) {
+          hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 1, false, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
+          return;
+        }
+      }
       if (traj && general) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true, 2>), grid, dim3(64), 0, s, QR_STEP_ARGS);
       else if (traj) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true, 1>), grid, dim3(64), 0, s, QR_STEP_ARGS);
       else if (general) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 2>), grid, dim3(64), 0, s, QR_STEP_ARGS);
