@@ -125,8 +125,8 @@ def test_in_kernel_noise_statistics_and_streams():
     for a in actors:
         a.mean_w.zero_(); a.mean_b.zero_()       # mean = 0, std = 1: the unclamped action IS the noise
 
-    def run(n_envs, offset=0, splits=(T,), seed=3):
-        env = _env("decoupled", n_envs, seed=seed, env_offset=offset)
+    def run(n_envs, offset=0, splits=(T,), seed=3, **kw):
+        env = _env("decoupled", n_envs, seed=seed, env_offset=offset, **kw)
         env.reset("train")
         env.get_norm_error_state()
         acts = [env.rollout_actor(actors, k, max_action=1e6)["action"] for k in splits]
@@ -144,6 +144,9 @@ def test_in_kernel_noise_statistics_and_streams():
     assert not np.array_equal(z, run(n, seed=4))                       # seeded
     assert np.array_equal(z[:, 1000:1600], run(600, offset=1000))      # a shard draws its global envs' numbers
     assert np.array_equal(z, run(n, splits=(8, 24)))                   # step_base advances across calls
+    # with in-launch resets the launch carries a helper wavefront per tile, which samples the noise a step ahead: the
+    # same numbers (the mean is zero here, so the action is the noise whatever the env does)
+    assert np.array_equal(z, run(n, auto_reset=True)) and np.array_equal(z, run(n, splits=(5, 27), auto_reset=True))
 
 
 def test_policy_rollout_with_auto_reset_and_storage():
