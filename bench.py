@@ -362,6 +362,11 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": (traffic or {}).get("bytes_per_launch"),
                          "traffic_source": (traffic or {}).get("source"),
                          "kernel": kname, "grid": grid, "block": block, "avg_launch_us": launch_us,
+                         # the committed rocprofv3 --kernel-trace figure of the same command, for comparison: the tool costs
+                         # ~4.8 us per dispatch by itself (profiles/r02/rocprof_dispatch_floor.txt) and inflates kernels shorter
+                         # than ~6 us; both clocks are listed, `achieved` uses this run's HIP events
+                         "committed_profile": {k: (traffic or {}).get(k) for k in ("rocprofv3_kernel_mean_us", "rocprofv3_kernel_median_us",
+                                                                                     "bench_py_us_per_step_under_rocprofv3")},
                          "algorithmic_bytes_per_env_step": algo, "layout_bytes_per_env_step": layout,
                          "achieved_layout_GBs": layout * N / (launch_us * 1e-6) / 1e9,
                          "note": "algorithmic bytes = SURVEY.md 8(d) (165 B + 24 B per-env params for Quad-v0); "

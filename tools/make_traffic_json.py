@@ -39,7 +39,14 @@ for fn, kind, envs, layout, ar, sub in CONFIGS:
     fetch, write, cf, cw = float(mf.group(1)), float(mw.group(1)), float(cf.group(1)), float(cw.group(1))
     assert abs(cf - 0.5) < 0.01 and abs(cw - 1.0) < 0.01, (fn, cf, cw)
     b = int(round((2 * fetch + write) * 1024))
-    out.append({"kind": kind, "envs": envs, "layout": layout, "auto_reset": ar, "substeps": sub, "FETCH_SIZE_KB_raw": fetch,
+    ka = re.search(r"step_kernel dispatches \d+: mean (\d+) ns median (\d+) ns", txt)
+    kb = re.search(r"bench.py UNDER the profiler: ([\d.]+) us", txt)
+    prof = {}
+    if ka:
+        prof = {"rocprofv3_kernel_mean_us": int(ka.group(1)) / 1e3, "rocprofv3_kernel_median_us": int(ka.group(2)) / 1e3}
+    if kb:
+        prof["bench_py_us_per_step_under_rocprofv3"] = float(kb.group(1))
+    out.append({**prof, "kind": kind, "envs": envs, "layout": layout, "auto_reset": ar, "substeps": sub, "FETCH_SIZE_KB_raw": fetch,
                 "WRITE_SIZE_KB": write, "bytes_per_launch": b, "bytes_per_env_step": round(b / envs, 1),
                 "source": f"profiles/{RND}/{fn}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes "
                           "(tools/profile.sh); FETCH_SIZE doubled (gfx950 tallies 128-B requests as 64 B: the 256 MiB "
