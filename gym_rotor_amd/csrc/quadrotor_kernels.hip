@@ -236,8 +236,8 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   // (POLICY with a helper wave) the step's exploration noise, sampled a step ahead by the helper: [t & 1][lane][8]
   __shared__ __attribute__((aligned(16))) float eps_lds[HELP && POLICY ? 2 * 64 * 8 : 4];
   // Quad-v0's reward (an atan2, a sqrt: ~90 instructions) is formed by the helper wave as well
-  constexpr bool kHelpReward = HELP && SINGLE && !TRAJ && KIND == QR_KIND_QUAD && QR_HELP_REWARD;  // (TRAJ: the goal lives in the stepping wave's registers)
-  __shared__ typename std::conditional<kHelpReward, PostLds<T, X>, char>::type post_lds;
+  constexpr bool kHelpReward = HELP && !POLICY && !TRAJ && KIND == QR_KIND_QUAD && QR_HELP_REWARD;  // (TRAJ: the goal lives in the stepping wave's registers)
+  __shared__ typename std::conditional<kHelpReward, PostLds<T, X>, char>::type post_lds[SINGLE ? 1 : 2];  // (a rollout alternates)
   __shared__ PoolLds<T> own_pool;  // pools this wave samples itself (no helper; or a tile's 13th.. resetting lane)
   constexpr bool kHelpRows = HELP && SINGLE && QR_HELP_ROWS;
   __shared__ __attribute__((aligned(16))) float smem1[(kHelpRows || (HELP && POLICY)) && KT::D1 > 0 ? B * D1 : 4];  // (Decoupled: both tiles at once)
@@ -263,6 +263,26 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       const bool heval = (hflags & QR_FLAG_EVAL_RESET) != 0;
       PoolRole hrole;
       pool_role(hrole, !heval && !(hflags & QR_FLAG_NO_UDM) && params != nullptr, heval, c);
+      // the reward of env-step t from the post-step state the stepping wave left in LDS (kHelpReward)
+      auto help_reward = [&](int t) {
+        if constexpr (kHelpReward) {
+          const unsigned hl = threadIdx.x - B;
+          const auto& ps = post_lds[SINGLE ? 0 : (t & 1)];
+          X hx[3], hv[3];
+          T hq[4], hW[3];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) { hx[j] = ps.x[j][hl]; hv[j] = ps.v[j][hl]; hW[j] = ps.W[j][hl]; }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) hq[j] = ps.q[j][hl];
+          const float r = quad_reward_raw<T, X>(hx, hv, hq, hW, hgoal, c);
+          const bool d = quad_done<T, X>(hx, hv, hq, hW, c);
+          if ((int)hl < rows) {
+            const int64_t hrow = (int64_t)t * n_envs + first;
+            (ka.reward + hrow)[hl] = d ? -1.0f : interp01(r, c.rmin_mono, c.inv_nrmin_mono);  // crash override (quad.py:162-166)
+            if (ka.reward_raw) (ka.reward_raw + hrow)[hl] = r;
+          }
+        }
+      };
       ResetPool<T> hp;
       if constexpr (POLICY != 0) {
         // qr_rollout_actor.  Per env-step t the helper meets the stepping wave twice: B1(t), when the step's noise is in
@@ -308,27 +328,14 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
           make_pool<T>(hp, hrole, hseed, hgfirst, rc + (uint32_t)t, 0);
           pool_to_lds(pool_lds[t & 1], hp);
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          help_reward(t);  // (Quad-v0) this step's reward, before the next step's pool
         }
         return;
       }
       make_pool<T>(hp, hrole, hseed, hgfirst, rc, 0);
       pool_to_lds(pool_lds[0], hp);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if constexpr (kHelpReward) {  // ---- then the reward of the step, from the post-step state the stepping wave left in LDS ----
-        const unsigned hl = threadIdx.x - B;
-        X hx[3], hv[3];
-        T hq[4], hW[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { hx[j] = post_lds.x[j][hl]; hv[j] = post_lds.v[j][hl]; hW[j] = post_lds.W[j][hl]; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) hq[j] = post_lds.q[j][hl];
-        const float r = quad_reward_raw<T, X>(hx, hv, hq, hW, hgoal, c);
-        const bool d = quad_done<T, X>(hx, hv, hq, hW, c);
-        if ((int)hl < rows) {
-          (ka.reward + first)[hl] = d ? -1.0f : interp01(r, c.rmin_mono, c.inv_nrmin_mono);  // crash override (quad.py:162-166)
-          if (ka.reward_raw) (ka.reward_raw + first)[hl] = r;
-        }
-      }
+      if constexpr (kHelpReward) help_reward(0);  // ---- then the reward of the step, from the post-step state the stepping wave left in LDS ----
       if constexpr (kHelpRows) {  // ---- and the observation rows: the stepping wave leaves the tile in LDS, this wave carries it out ----
         float* const ob0 = ka.obs0;
         if (KIND != QR_KIND_QUAD || ob0 != nullptr) {
@@ -576,10 +583,11 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     if constexpr (KIND == QR_KIND_QUAD) {
       if constexpr (kHelpReward) {
         // the helper wave forms and stores the reward (below, after the barrier): hand it the post-step state
+        auto& ps = post_lds[SINGLE ? 0 : (t & 1)];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { post_lds.x[j][lane] = w.x[j]; post_lds.v[j][lane] = w.v[j]; post_lds.W[j][lane] = w.W[j]; }
+        for (int j = 0; j < 3; ++j) { ps.x[j][lane] = w.x[j]; ps.v[j][lane] = w.v[j]; ps.W[j][lane] = w.W[j]; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) post_lds.q[j][lane] = w.q[j];
+        for (int j = 0; j < 4; ++j) ps.q[j][lane] = w.q[j];
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         rraw[0] = rwd[0] = 0.0f;
       } else {
