@@ -588,14 +588,15 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         for (int j = 0; j < 3; ++j) { ps.x[j][lane] = w.x[j]; ps.v[j][lane] = w.v[j]; ps.W[j][lane] = w.W[j]; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) ps.q[j][lane] = w.q[j];
+        dn[0] = quad_done<T, X>(w.x, w.v, w.q, w.W, c);  // (formed while the LDS writes land)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         rraw[0] = rwd[0] = 0.0f;
       } else {
         const float r = quad_reward_raw<T, X>(w.x, w.v, w.q, w.W, w.goal, c);
         rraw[0] = r;
         rwd[0] = interp01(r, c.rmin_mono, c.inv_nrmin_mono);
+        dn[0] = quad_done<T, X>(w.x, w.v, w.q, w.W, c);
       }
-      dn[0] = quad_done<T, X>(w.x, w.v, w.q, w.W, c);
     } else {
       quat_to_R(w.q, R);
       error_obs<KIND, T, X>(w, R, c, o0, o1);
