@@ -259,6 +259,13 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
           for (int f = 0; f < 9; ++f) hgoal[f] = goal.load(f, ufirst, hll);
         }
       }
+      // the helper's own output pointers, read with its first scalar loads: behind the barriers they would be a kernarg
+      // cache miss at the very end of the launch
+      float* const hob0 = ka.obs0;
+      float* const hob1 = KT::D1 > 0 ? ka.obs1 : nullptr;
+      float* const hrew = ka.reward;
+      float* const hraw = ka.reward_raw;
+      asm volatile("" ::"s"(hob0), "s"(hob1), "s"(hrew), "s"(hraw));
       const uint32_t rc = (uint32_t)reset_count[blockIdx.x];
       const uint32_t hflags = ka.flags;
       const uint64_t hseed = ka.seed;
@@ -281,8 +288,8 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
           const bool d = quad_done<T, X>(hx, hv, hq, hW, c);
           if ((int)hl < rows) {
             const int64_t hrow = (int64_t)t * n_envs + first;
-            (ka.reward + hrow)[hl] = d ? -1.0f : interp01(r, c.rmin_mono, c.inv_nrmin_mono);  // crash override (quad.py:162-166)
-            if (ka.reward_raw) (ka.reward_raw + hrow)[hl] = r;
+            (hrew + hrow)[hl] = d ? -1.0f : interp01(r, c.rmin_mono, c.inv_nrmin_mono);  // crash override (quad.py:162-166)
+            if (hraw) (hraw + hrow)[hl] = r;
           }
         }
       };
@@ -295,8 +302,8 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         const int hl = (int)threadIdx.x - B;
         const bool own_noise = !ka.deterministic && ka.noise == nullptr;
         const uint64_t nseed = ka.noise_seed, sbase = ka.step_base, hgid = (uint64_t)(ka.env_offset + first + hl);
-        float* const ob0 = ka.obs0;
-        float* const ob1 = KT::D1 > 0 ? ka.obs1 : nullptr;
+        float* const ob0 = hob0;
+        float* const ob1 = hob1;
         auto make_eps = [&](int t) {
           if (!own_noise) return;
           float z[4];
@@ -340,12 +347,11 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if constexpr (kHelpReward) help_reward(0);  // ---- then the reward of the step, from the post-step state the stepping wave left in LDS ----
       if constexpr (kHelpRows) {  // ---- and the observation rows: the stepping wave leaves the tile in LDS, this wave carries it out ----
-        float* const ob0 = ka.obs0;
-        if (KIND != QR_KIND_QUAD || ob0 != nullptr) {
+        if (KIND != QR_KIND_QUAD || hob0 != nullptr) {
           asm volatile("s_barrier" ::: "memory");
           const int hl = (int)threadIdx.x - B;
-          lds_to_rows<B, D0>(ob0 + first * D0, smem, hl, rows);
-          if constexpr (KT::D1 > 0) lds_to_rows<B, D1>(ka.obs1 + first * D1, smem1, hl, rows);
+          lds_to_rows<B, D0>(hob0 + first * D0, smem, hl, rows);
+          if constexpr (KT::D1 > 0) lds_to_rows<B, D1>(hob1 + first * D1, smem1, hl, rows);
         }
       }
       return;
