@@ -60,6 +60,7 @@ namespace qr {
 // byte offset of the Args block in the step kernel's kernarg segment: 6 pointers + 2 x int32 precede it
 constexpr int kArgsOffset = 6 * 8 + 2 * 4;
 static_assert(alignof(Args) == 8, "Args follows the leading scalar arguments without padding");
+static_assert(sizeof(Coeffs) <= 5 * 64 && offsetof(Args, c) + sizeof(Coeffs) == sizeof(Args), "the step kernel touches the five kernarg lines of the coefficient block (the last field of Args)");
 
 // QR_STAMPS: diagnostic build (tools/stamp_timeline.py).  Every wave records the 100 MHz real-time clock at
 // seven points of the step; the values go to a buffer of their own that nothing else reads.
@@ -80,6 +81,9 @@ __device__ unsigned long long* g_stamps = nullptr;
 #endif
 #ifndef QR_HELP_POLICY
 #define QR_HELP_POLICY 1  // 0: no helper wave in qr_rollout_actor
+#endif
+#ifndef QR_TOUCH_COEFFS
+#define QR_TOUCH_COEFFS 1
 #endif
 #ifndef QR_PREFETCH_OUT_PTRS
 #define QR_PREFETCH_OUT_PTRS 1
@@ -358,6 +362,21 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     }
   }
   QR_STAMP(0, tid);
+#if QR_TOUCH_COEFFS && defined(__HIP_DEVICE_COMPILE__)
+  // The coefficient block spans five 64-byte lines of the kernarg segment (host-visible memory: ~0.5 us per miss).  The
+  // compiler reads coefficients where they are used, i.e. it requests those lines only AFTER the first batch of scalar
+  // loads is back, and the first arithmetic then waits for them.  One dummy word per line, requested with the wave's
+  // first instructions, has them in the scalar cache by then.  (The words are never used; their registers stay
+  // reserved until a point behind the first scalar wait, see below.)
+  uint32_t ctouch[5];
+  {
+    constexpr int kC = kArgsOffset + (int)offsetof(Args, c);
+    asm volatile("s_load_dword %0, %5, %6\n\ts_load_dword %1, %5, %7\n\ts_load_dword %2, %5, %8\n\t"
+                 "s_load_dword %3, %5, %9\n\ts_load_dword %4, %5, %10"
+                 : "=&s"(ctouch[0]), "=&s"(ctouch[1]), "=&s"(ctouch[2]), "=&s"(ctouch[3]), "=&s"(ctouch[4])
+                 : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "i"(kC), "i"(kC + 64), "i"(kC + 128), "i"(kC + 192), "i"(kC + 256));
+  }
+#endif
 
   // ---- issue the loads of the env's working set (SoA, lane-contiguous) and of its action row ----
   Work<T, X> w;
@@ -439,6 +458,10 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 #pragma unroll
     for (int f = 0; f < 7; ++f) tr.set(f, traj.load(f, ufirst, ll));
   }
+#if QR_TOUCH_COEFFS && defined(__HIP_DEVICE_COMPILE__)
+  // (steps_ptr is back => s_waitcnt lgkmcnt(0) has been passed => the dummy words have landed: their registers are free)
+  asm volatile("" ::"s"(ctouch[0]), "s"(ctouch[1]), "s"(ctouch[2]), "s"(ctouch[3]), "s"(ctouch[4]), "s"(steps_ptr));
+#endif
   int32_t steps = (steps_ptr && active) ? (steps_ptr + first)[lane] : 0;
   bool params_dirty = false;
   bool traj_dirty = false;  // this lane started a new episode: its generator state changed
