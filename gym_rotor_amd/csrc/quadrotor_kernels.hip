@@ -368,13 +368,14 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   // loads is back, and the first arithmetic then waits for them.  One dummy word per line, requested with the wave's
   // first instructions, has them in the scalar cache by then.  (The words are never used; their registers stay
   // reserved until a point behind the first scalar wait, see below.)
-  uint32_t ctouch[5];
+  uint32_t ctouch[6];  // ([5]: the line of the per-call integers — substeps is wanted at the first RK4 stage)
   {
     constexpr int kC = kArgsOffset + (int)offsetof(Args, c);
-    asm volatile("s_load_dword %0, %5, %6\n\ts_load_dword %1, %5, %7\n\ts_load_dword %2, %5, %8\n\t"
-                 "s_load_dword %3, %5, %9\n\ts_load_dword %4, %5, %10"
-                 : "=&s"(ctouch[0]), "=&s"(ctouch[1]), "=&s"(ctouch[2]), "=&s"(ctouch[3]), "=&s"(ctouch[4])
-                 : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "i"(kC), "i"(kC + 64), "i"(kC + 128), "i"(kC + 192), "i"(kC + 256));
+    asm volatile("s_load_dword %0, %6, %7\n\ts_load_dword %1, %6, %8\n\ts_load_dword %2, %6, %9\n\t"
+                 "s_load_dword %3, %6, %10\n\ts_load_dword %4, %6, %11\n\ts_load_dword %5, %6, %12"
+                 : "=&s"(ctouch[0]), "=&s"(ctouch[1]), "=&s"(ctouch[2]), "=&s"(ctouch[3]), "=&s"(ctouch[4]), "=&s"(ctouch[5])
+                 : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "i"(kC), "i"(kC + 64), "i"(kC + 128), "i"(kC + 192), "i"(kC + 256),
+                   "i"(kArgsOffset + (int)offsetof(Args, substeps)));
   }
 #endif
 
@@ -460,7 +461,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   }
 #if QR_TOUCH_COEFFS && defined(__HIP_DEVICE_COMPILE__)
   // (steps_ptr is back => s_waitcnt lgkmcnt(0) has been passed => the dummy words have landed: their registers are free)
-  asm volatile("" ::"s"(ctouch[0]), "s"(ctouch[1]), "s"(ctouch[2]), "s"(ctouch[3]), "s"(ctouch[4]), "s"(steps_ptr));
+  asm volatile("" ::"s"(ctouch[0]), "s"(ctouch[1]), "s"(ctouch[2]), "s"(ctouch[3]), "s"(ctouch[4]), "s"(ctouch[5]), "s"(steps_ptr));
 #endif
   int32_t steps = (steps_ptr && active) ? (steps_ptr + first)[lane] : 0;
   bool params_dirty = false;
