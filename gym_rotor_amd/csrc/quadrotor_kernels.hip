@@ -430,9 +430,9 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   const int n_steps = SINGLE ? 1 : ka.n_steps;
   const bool eval_reset = (flags & QR_FLAG_EVAL_RESET) != 0;
   const bool randomise = !eval_reset && !(flags & QR_FLAG_NO_UDM) && a.params != nullptr;
-#if !QR_LAZY_ROLE
-  if (!HELP && auto_reset) pool_role(role, randomise, eval_reset, c);  // (scalars only: runs while the loads are in flight)
-#endif
+  // One-step launches form the role constants in the reset block (below); a rollout forms them once, here.
+  constexpr bool kLazyRole = QR_LAZY_ROLE && SINGLE;
+  if (!kLazyRole && !HELP && auto_reset) pool_role(role, randomise, eval_reset, c);  // (scalars only: runs while the loads are in flight)
 #pragma unroll
   for (int f = 0; f < 12; ++f) w.goal[f] = f == 6 ? 1.0f : 0.0f;  // hover default (quad.py:98-101)
   if (!TRAJ && goal_ptr) {  // (with the fused generator the goal is formed in registers every step)
@@ -748,12 +748,10 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
           rcount_s = (uint32_t)reset_count[blockIdx.x];  // (still this launch's base: advanced only at the end)
         }
       }
-#if QR_LAZY_ROLE
-      // The lane's role constants are formed HERE, not while the loads are in flight: twelve values held across the whole
-      // step cost the plain kernel its fourth wave per SIMD (142 -> 128 VGPRs), and the grids that run it are either large
-      // (other waves cover this) or take the helper-wave instantiation.
-      if (!HELP) pool_role(role, randomise, eval_reset, c);
-#endif
+      // (one-step launches) the lane's role constants are formed HERE, not while the loads are in flight: twelve values
+      // held across the whole step cost the plain kernel its fourth wave per SIMD (142 -> 128 VGPRs), and the grids that
+      // run it are either large (other waves cover this) or take the helper-wave instantiation.
+      if (kLazyRole && !HELP) pool_role(role, randomise, eval_reset, c);
       for (int pass = pass0; 12 * pass < total; ++pass) {  // one pass unless more than 12 lanes reset at once
         const int slot = rank - 12 * pass;
         if (!(have_pool && pass == 0)) make_pool<T>(pool, role, seed, gfirst, rcount_s + (uint32_t)t, pass);
