@@ -7,26 +7,31 @@
 //   observation + trapezoid integrators (quad.py:421-466) -> reward -> np.interp
 //   normalisation -> done -> crash override [-> auto-reset].
 //
-// What bounds it: measured on MI355X the step moves its working set through the fabric at
-// the HBM rate even at N = 65 536 (dirty L2 lines are written back at every kernel
-// boundary), and all arithmetic fits under that, so the design minimises BYTES per env:
-//   * attitude is a unit quaternion (4 words) integrated directly — q' = q (0,W)/2 is the
-//     same flow as R' = R hat(W) — so the state is 13 words, not 18; R(q) is rebuilt in
-//     registers only where the observation / reward needs it;
-//   * x, v are stored as float32 and q, W as float64 in the default (mixed) layout: fp32
-//     rounding of W and R is what breaks the 1e-5 / 1000-step parity bar, x and v do not
-//     feed back into the rotation;
-//   * the whole working set stays in VGPRs across substeps and, in qr_rollout, across
-//     env-steps: HBM is touched once in and once out.
-// Per-env SoA buffers are read/written with lane-contiguous accesses; caller-facing AoS
-// rows (actions, observations) go through LDS so global traffic is linear 16-byte-per-lane
-// stores.  The physics has no contraction larger than 3x3, so no MFMA there; the one real
-// contraction on the path — the 16-wide PPO actor of qr_rollout_actor — does run on the
-// matrix cores (qr_actor.h).
+// What bounds it: at N >= ~250 000 envs the bytes — the step streams its working set through the
+// fabric at 67-73 % of the HBM roofline; at the metric's N = 65 536 (1024 tiles = one stepping wave per SIMD) the
+// launch boundary (1.8 us between dependent kernels) plus the length of ONE wave's instruction stream, which a lone
+// wave issues at one VALU instruction per ~5.6 cycles whatever its type.  So the design minimises BYTES per env and
+// INSTRUCTIONS on the stepping wave's path:
+//   * attitude is a unit quaternion integrated directly — q' = q (0,W)/2 is the same flow as R' = R hat(W) — and
+//     stored as its smallest three components: the state is 12 words, not 18; R(q) is rebuilt in registers only
+//     where the observation / reward needs it;
+//   * x, v are stored as float32 and q, W as float64 in the default (mixed) layout; W is integrated and q accumulated
+//     in float64, the RK4 stage quaternions are float32 (qr_dynamics.h);
+//   * the whole working set stays in VGPRs across substeps and, in qr_rollout, across env-steps: HBM is touched once
+//     in and once out;
+//   * for grids small enough that every wave is resident at once, each tile gets a second, HELPER wavefront in the
+//     same workgroup (HELP): it samples the tile's reset pool, forms Quad-v0's reward, samples the policy's noise
+//     and carries observation rows out, in issue slots the lone stepping wave leaves empty;
+//   * arguments are read so that scalar-cache misses on the kernarg segment (~0.4 us each) stay off the stepping
+//     wave's critical path.
+// Per-env SoA buffers are read/written with lane-contiguous accesses through buffer descriptors; caller-facing AoS
+// rows (actions, observations) go through LDS so global traffic is linear 16-byte-per-lane stores.  The physics has
+// no contraction larger than 3x3, so no MFMA there; the one real contraction on the path — the 16-wide PPO actor of
+// qr_rollout_actor — does run on the matrix cores (qr_actor.h).
 //
-// Written directly for CDNA4: 64-lane wavefronts, one wavefront per workgroup (N = 65 536 ->
-// 1024 workgroups = one per SIMD; no cross-wave barriers), <= 256 VGPRs so that two waves fit
-// per SIMD at large N.
+// Written directly for CDNA4: 64-lane wavefronts, one stepping wavefront per 64-env tile (N = 65 536 -> 1024
+// workgroups = one per SIMD-32), workgroups of one or two wavefronts, 120-128 VGPRs for the Quad-v0 one-step kernels
+// (four waves per SIMD at large N).
 //
 // Files (included in this order):
 //   qr_args.h      kernel argument block, constants, per-env working set
