@@ -38,7 +38,7 @@ if f:
               f"{pc(per, .1)} / {pc(per, .5)} / {pc(per, .9)};  idle gap before a dispatch p50/p90: {pc(gap, .5)} / {pc(gap, .9)}")
 f = os.path.join(out, "stats.log")
 if os.path.exists(f):
-    import json, re
+    import json
     for line in open(f, errors="replace"):
         if line.startswith("{") and "ms_per_step" in line:
             j = json.loads(line)
