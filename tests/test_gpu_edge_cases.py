@@ -254,7 +254,7 @@ def test_torch_custom_op_policy_rollout_and_gae():
 
 def test_fuzz_configurations_vs_oracle():
     """48 random configurations — kind x layout x substeps x batch size (ragged tails, N = 1) x field
-    stride x with/without per-env parameters and goals x step()/rollout() — each run a few steps
+    stride x with/without per-env parameters and goals x step()/rollout() x plain / helper-wave launches — each run a few steps
     against the oracle.  Catches interactions the targeted tests do not enumerate."""
     rng = np.random.default_rng(2024)
     for trial in range(48):
@@ -265,8 +265,11 @@ def test_fuzz_configurations_vs_oracle():
         T = int(rng.integers(1, 5))
         use_params, use_goal, use_rollout = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
         stride = None if rng.integers(2) else 4 * ((n + int(rng.integers(1, 70)) + 3) // 4)
+        # in-launch auto-reset on: the launches then carry a helper wavefront per tile (default layout).  Nothing terminates
+        # within these few steps from interior states (asserted below), so the oracle comparison is unchanged.
+        auto_reset = bool(rng.integers(2))
         A = orc.ACTION_DIM[kind]
-        env = _env(kind, n, layout=layout, substeps=S, use_UDM=use_params, obs_rows=True, field_stride=stride)
+        env = _env(kind, n, layout=layout, substeps=S, use_UDM=use_params, obs_rows=True, field_stride=stride, auto_reset=auto_reset)
         state = orc.sample_reset_state(rng, n).astype(np.float32).astype(np.float64)
         params = orc.sample_params(rng, n).astype(np.float32).astype(np.float64) if use_params else None
         integ = rng.uniform(-0.5, 0.5, (n, 8)).astype(np.float32).astype(np.float64)
@@ -283,7 +286,8 @@ def test_fuzz_configurations_vs_oracle():
             g = torch.from_numpy(goal).float().cuda()
             env.set_goal_state(g[:, 0:3], g[:, 3:6], g[:, 6:9], None, g[:, 9:12])
         acts = rng.uniform(-1, 1, (T, n, A)).astype(np.float32)
-        tag = f"trial {trial}: {kind}/{layout} N={n} S={S} T={T} params={use_params} goal={use_goal} rollout={use_rollout} stride={stride}"
+        tag = (f"trial {trial}: {kind}/{layout} N={n} S={S} T={T} params={use_params} goal={use_goal} rollout={use_rollout} "
+               f"stride={stride} auto_reset={auto_reset}")
         if use_rollout:
             ro = env.rollout(torch.from_numpy(acts).cuda())
             rwd_all, done_all, obs_last = _np(ro["reward"]), _np(ro["terminated"]), ro["obs0"][T - 1]
@@ -301,6 +305,7 @@ def test_fuzz_configurations_vs_oracle():
             # a done flag may differ only where its deciding quantity sits on the threshold
             mism = done_all[t] != o["done"]
             assert mism.sum() == 0, tag
+            assert not (auto_reset and o["done"].any()), tag
             assert np.abs(rwd_all[t] - o["reward"]).max() <= 2e-5, tag
         assert grouped_rel_err(_np(env.get_current_state()), s) <= (2e-7 if layout == "f64" else 1e-6), tag
         ref_obs = np.asarray(o["obs"][0], np.float64)
