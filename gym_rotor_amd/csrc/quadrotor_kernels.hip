@@ -112,6 +112,9 @@ __device__ unsigned long long* g_stamps = nullptr;
 // 131 072 9.64 / 9.06; Decoupled 32 768 5.86 / 6.51, 98 304 7.83 / 8.63, 131 072 9.66 / 8.98.
 #define QR_HELPER_GRID 2048       // Quad-v0 (128 VGPRs: four waves per SIMD)
 #endif
+#ifndef QR_HELPER_GRID_ROLLOUT
+#define QR_HELPER_GRID_ROLLOUT (QR_HELPER_GRID < 1024 ? QR_HELPER_GRID : 1024)  // qr_rollout / qr_rollout_actor (two waves per SIMD)
+#endif
 #ifndef QR_HELPER_GRID_WRAP
 #define QR_HELPER_GRID_WRAP (QR_HELPER_GRID < 1536 ? QR_HELPER_GRID : 1536)  // the wrappers (three waves per SIMD)
 #endif
@@ -1175,8 +1178,12 @@ static inline bool wants_adapt(const Args& a) {
 }
 static inline bool wants_helper(const Args& a, int kind, int layout) {  // a helper wave per tile (HELP)
   const unsigned tiles = (unsigned)((a.n + 63) / 64);
+  // (the multi-step instantiations hold the loop's state across steps: 181-216 VGPRs = two waves per SIMD, so a stepping
+  // and a helper wave per tile are all resident only up to 1024 tiles; beyond, measured: Quad-v0 98 304 envs 3.52 against
+  // 2.97 us per env-step plain, Coupled 5.06 against 3.74)
+  const unsigned limit = a.n_steps > 1 ? (unsigned)QR_HELPER_GRID_ROLLOUT : (unsigned)(kind == QR_KIND_QUAD ? QR_HELPER_GRID : QR_HELPER_GRID_WRAP);
   return layout == QR_LAYOUT_MIXED && a.act_out == nullptr && a.goal_mode == QR_GOAL_EXTERNAL && !wants_adapt(a) &&
-         (a.flags & QR_FLAG_AUTO_RESET) && tiles <= (unsigned)(kind == QR_KIND_QUAD ? QR_HELPER_GRID : QR_HELPER_GRID_WRAP);
+         (a.flags & QR_FLAG_AUTO_RESET) && tiles <= limit;
 }
 
 static inline bool wants_helper_traj(const Args& a, int kind) {  // the same with the fused goal generator (one-step launches)
@@ -1205,7 +1212,7 @@ static void launch_kind(const Args& a, hipStream_t s) {
         // per tile (noise, reset pool, observation rows).  Measured, Coupled 65 536 envs, T = 32: 5.37 -> 4.51 us per step;
         // with the fused goal generator the same split measured SLOWER (5.65 -> 6.25 us per step, tools/ppo_rollout_bench.py;
         // both waves of a tile must be resident, which caps the kernel at 256 registers) and is not instantiated.
-        if (QR_HELP_POLICY && !general && !traj && (a.flags & QR_FLAG_AUTO_RESET) && grid.x <= (unsigned)QR_HELPER_GRID_WRAP) {
+        if (QR_HELP_POLICY && !general && !traj && (a.flags & QR_FLAG_AUTO_RESET) && grid.x <= (unsigned)QR_HELPER_GRID_ROLLOUT) {
           hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 1, false, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
           return;
         }

@@ -185,8 +185,8 @@ def test_abi_argument_errors_without_gpu():
 def test_launch_geometry_rule_without_gpu():
     """qr_step_kernel_info (host-only) reports the launch the step launcher would use: one 64-lane wavefront per 64-env
     tile, plus a helper wavefront (128 threads per workgroup) exactly for: in-launch auto-reset, default layout, no rate
-    adaptivity in reach, and grids of <= 2048 tiles (Quad-v0) / <= 1536 (wrappers); with the fused goal generator only
-    for one-step launches."""
+    adaptivity in reach, and grids of <= 2048 tiles (Quad-v0) / <= 1536 (wrappers) / <= 1024 (rollouts); with the fused
+    goal generator only for one-step launches."""
     L = _lib()
     lib = L.load()
 
@@ -213,7 +213,7 @@ def test_launch_geometry_rule_without_gpu():
     assert info(0, 65536, 0)[2] == 64                                      # no in-launch reset: nothing for a helper to sample
     assert info(0, 65536, AR, layout=1)[2] == 64 and info(0, 65536, AR, layout=2)[2] == 64
     assert info(0, 65536, AR, w_adapt=3.0)[2] == 64                        # rate adaptivity within reach of |W| < W_lim: the adaptive kernel
-    assert info(0, 65536, AR, n_steps=100)[2] == 128                       # rollouts too
+    assert info(0, 65536, AR, n_steps=100)[2] == 128 and info(0, 65536 + 64, AR, n_steps=100)[2] == 64   # rollouts: up to 1024 tiles
     gm = int(re.search(r"#define QR_GOAL_MODE0\s+(\d+)", hdr).group(1))
     assert GOAL_EXTERNAL == 0 and info(1, 65536, AR, goal_mode=gm)[2] == 128 and info(1, 65536, AR, goal_mode=gm, n_steps=8)[2] == 64
     assert info(0, -5, AR)[0] == ""                                        # invalid descriptor
