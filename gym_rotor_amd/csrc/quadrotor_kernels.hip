@@ -93,6 +93,12 @@ __device__ unsigned long long* g_stamps = nullptr;
 #ifndef QR_PREFETCH_OUT_PTRS
 #define QR_PREFETCH_OUT_PTRS 1
 #endif
+#ifndef QR_EARLY_TILE
+#define QR_EARLY_TILE 1
+#endif
+#ifndef QR_LATE_LOADS
+#define QR_LATE_LOADS 1
+#endif
 #ifndef QR_LAZY_ROLE
 #define QR_LAZY_ROLE 1
 #endif
@@ -255,7 +261,13 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   __shared__ typename std::conditional<kHelpReward, PostLds<T, X>, char>::type post_lds[SINGLE ? 1 : 2];  // (a rollout alternates)
   __shared__ PoolLds<T> own_pool;  // pools this wave samples itself (no helper; or a tile's 13th.. resetting lane)
   constexpr bool kHelpRows = HELP && SINGLE && QR_HELP_ROWS;
-  __shared__ __attribute__((aligned(16))) float smem1[(kHelpRows || (HELP && POLICY)) && KT::D1 > 0 ? B * D1 : 4];  // (Decoupled: both tiles at once)
+  // (plain one-step wrapper kernels: large grids) the observation rows go to their LDS tile as soon as they are formed,
+  // BEFORE the reset block, and a re-sampled env overwrites its row there: the 18-23 row registers need not survive the
+  // reset block.  With the late loads below: Coupled 150 -> 114 VGPRs, Decoupled 148 -> 115, i.e. four waves per SIMD
+  // (262 144 envs 19.1 -> 16.5 us).  Not in the helper-wave launches, where the second write of a re-sampled env's row
+  // is on the stepping wave's path (65 536 envs: 6.03 -> 6.15 us with it).
+  constexpr bool kEarlyTile = QR_EARLY_TILE && SINGLE && !HELP && !POLICY && KIND != QR_KIND_QUAD;
+  __shared__ __attribute__((aligned(16))) float smem1[(kHelpRows || kEarlyTile || (HELP && POLICY)) && KT::D1 > 0 ? B * D1 : 4];  // (Decoupled: both tiles at once)
   if constexpr (HELP) {
     // (the wave's first lane decides: a wave-uniform branch in the compiler's eyes too — on threadIdx.x itself everything
     // after it counts as divergent control flow, and scalar offsets of the loads below were re-derived per lane)
@@ -421,7 +433,11 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   // has been consumed 6.12 us — against 5.42 us, although scalar loads return out of order and the first use of a kernarg
   // coefficient therefore also waits for this one: the in-kernel timelines of those variants are shorter, their launches not.)
   if (!HELP && auto_reset) rcount_s = (uint32_t)reset_count[blockIdx.x];
-  if constexpr (KIND != QR_KIND_QUAD) {
+  // (kLateLoads) The plain one-step wrapper kernel serves grids of several waves per SIMD, where a load's latency is
+  // other waves' time: it requests the 20 words only the error observation wants (goal, integrators) AFTER the
+  // integration instead of holding them across it — registers for occupancy.
+  constexpr bool kLateLoads = QR_LATE_LOADS && SINGLE && !HELP && !ADAPT && !TRAJ && !POLICY && KIND != QR_KIND_QUAD;
+  if constexpr (KIND != QR_KIND_QUAD && !kLateLoads) {
     const SoA<float> integ(a.integ, 8, L);
 #pragma unroll
     for (int f = 0; f < 8; ++f) w.integ[f] = integ.load(f, ufirst, ll);
@@ -443,7 +459,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   if (!kLazyRole && !HELP && auto_reset) pool_role(role, randomise, eval_reset, c);  // (scalars only: runs while the loads are in flight)
 #pragma unroll
   for (int f = 0; f < 12; ++f) w.goal[f] = f == 6 ? 1.0f : 0.0f;  // hover default (quad.py:98-101)
-  if (!TRAJ && goal_ptr) {  // (with the fused generator the goal is formed in registers every step)
+  if (!TRAJ && !kLateLoads && goal_ptr) {  // (with the fused generator the goal is formed in registers every step)
     const SoA<float> goal(goal_ptr, 12, L);
 #pragma unroll
     for (int f = 0; f < 12; ++f) w.goal[f] = goal.load(f, ufirst, ll);
@@ -585,6 +601,10 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     // ---- action_wrapper ----
     Dyn<T> dyn;
     action_map<KIND, T, X>(act, w, c, dyn);
+    if constexpr (SINGLE && !HELP) {  // (plain one-step launch: the loaded parameters are dead from here on — a re-sampled
+#pragma unroll                        //  env stores the ones it takes from the pool — so their registers need not survive)
+      for (int f = 0; f < 6; ++f) w.prm[f] = 0.0f;
+    }
     // The output pointers sit in a kernarg cache line that nothing before the epilogue touches.  In the plain
     // instantiation (large grids) they are read with the first batch of scalar loads, so that the scalar-cache miss does
     // not sit in front of the first output store with the wave's registers held meanwhile (1 M envs: Quad-v0 36.6 -> 34.0 us,
@@ -620,6 +640,16 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       integrate(w.x, w.v, w.q, w.W, dyn, nsub, T(c.dt) * recip(T(nsub)));
     }
     renorm_quat(w.q);
+    if constexpr (kLateLoads) {
+      const SoA<float> integ(a.integ, 8, L);
+#pragma unroll
+      for (int f = 0; f < 8; ++f) w.integ[f] = integ.load(f, ufirst, ll);
+      if (goal_ptr) {
+        const SoA<float> goal(goal_ptr, 12, L);
+#pragma unroll
+        for (int f = 0; f < 12; ++f) w.goal[f] = goal.load(f, ufirst, ll);
+      }
+    }
     // The attitude as it is stored (qr_traj.h: QuatPack) is formed once per env-step: here when this wave may store
     // its settled lanes early (below), otherwise after the reset block, when every lane holds what it will store.
     if (early_store) pack_quat(w.q, qp);
@@ -666,6 +696,10 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         dn[0] = out3(&o0[0]) | out3(&o0[6]) | out3(&o0[12]);
         dn[NAG - 1] = !(fabsf(o1[2]) < 1.0f);
       }
+    }
+    if constexpr (kEarlyTile) {
+      rows_to_lds<D0>(o0, smem, tid);
+      if constexpr (KT::D1 > 0) rows_to_lds<D1>(o1, smem1, tid);
     }
     // crash override (quad.py:162-166)
 #pragma unroll
@@ -736,11 +770,11 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         } else {
           float* fo = ka.final_obs0 + (row0 + lane) * D0;
 #pragma unroll
-          for (int j = 0; j < D0; ++j) fo[j] = o0[j];
+          for (int j = 0; j < D0; ++j) fo[j] = kEarlyTile ? smem[tid * D0 + j] : o0[j];
           if constexpr (KT::D1 > 0) {
             float* f1 = ka.final_obs1 + (row0 + lane) * D1;
 #pragma unroll
-            for (int j = 0; j < D1; ++j) f1[j] = o1[j];
+            for (int j = 0; j < D1; ++j) f1[j] = kEarlyTile ? smem1[tid * D1 + j] : o1[j];
           }
         }
       }
@@ -798,6 +832,10 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 #pragma unroll
           for (int f = 0; f < 8; ++f) w.integ[f] = 0.0f;
           error_obs<KIND, T, X>(w, R, c, o0, o1);  // first observation of the new episode (main.py:226-230)
+          if constexpr (kEarlyTile) {
+            rows_to_lds<D0>(o0, smem, tid);
+            if constexpr (KT::D1 > 0) rows_to_lds<D1>(o1, smem1, tid);
+          }
         }
         if (early_store) pack_quat(w.q, qp);
       }
@@ -819,10 +857,16 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 #pragma unroll
           for (int j = 0; j < 9; ++j) o0[6 + j] = (float)R[j];
         }
-        rows_to_lds<D0>(o0, smem, tid);
-        if constexpr (KT::D1 > 0) rows_to_lds<D1>(o1, smem1, tid);
+        if constexpr (!kEarlyTile) {
+          rows_to_lds<D0>(o0, smem, tid);
+          if constexpr (KT::D1 > 0) rows_to_lds<D1>(o1, smem1, tid);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       }
+    } else if constexpr (kEarlyTile) {  // (plain one-step wrapper kernel) the tile(s) are complete: carry them out
+      tile_sync<B>();
+      lds_to_rows<B, D0>(ka.obs0 + row0 * D0, smem, tid, rows);
+      if constexpr (KT::D1 > 0) lds_to_rows<B, D1>(ka.obs1 + row0 * D1, smem1, tid, rows);
     } else if constexpr (HELP && POLICY != 0) {  // the tile is next step's MFMA operand AND this step's rows (helper wave)
       rows_to_lds<D0>(o0, smem, tid);
       if constexpr (KT::D1 > 0) rows_to_lds<D1>(o1, smem1, tid);
