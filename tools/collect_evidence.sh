@@ -33,6 +33,7 @@ python3 tools/evidence.py > "$OUT/runtime_ab.json" 2> "$OUT/runtime_ab.err"
 for ar in 1 0; do QR_LIB=$L/libquadrotor_hip_q_stamps.so python3 tools/stamp_timeline.py --auto-reset $ar --json "$OUT/stamps_quad65536_ar$ar.json" > "$OUT/stamps_quad65536_ar$ar.txt" 2>&1; done
 QR_LIB=$L/libquadrotor_hip_q_stamps.so python3 tools/stamp_timeline.py --auto-reset 1 --envs 1048576 --json "$OUT/stamps_quad1M_ar1.json" > "$OUT/stamps_quad1M_ar1.txt" 2>&1
 bash tools/rocprof_floor.sh > "$OUT/rocprof_dispatch_floor.txt" 2>&1
+bash tools/pmc_insts.sh > "$OUT/pmc_insts.txt" 2>&1
 ./build/valu_mb > "$OUT/valu_microbench.json" 2> /dev/null
 python3 tools/ppo_rollout_bench.py > "$OUT/ppo_rollout.json" 2> "$OUT/ppo_rollout.err"
 ls "$OUT"
