@@ -136,7 +136,9 @@ __device__ __forceinline__ float interp01(float r, float rmin, float inv_nrmin) 
 // per access (v_mad_u64_u32 / v_lshl_add_u64: ~110 of the ~1100 instructions of the step).
 // soffset is 32-bit: every SoA buffer must be < 4 GiB (checked on the host, QR_E_SIZE).
 // A null base gives a descriptor without records: its loads return 0 and touch no memory (the range check of raw
-// buffer accesses), which spares optional buffers a branch.
+// buffer accesses), which spares optional buffers a branch.  Any other buffer gets the maximum record count: every
+// access is in bounds by construction (lanes past a ragged tail are clamped onto the last env, stores are guarded), and
+// an exact byte count would cost each of the step's seven descriptors half a dozen scalar instructions.
 typedef int v2i_t __attribute__((ext_vector_type(2)));
 
 #ifndef QR_STORE_AUX
@@ -148,7 +150,7 @@ struct SoA {
   __amdgpu_buffer_rsrc_t rsrc;
   unsigned L;  // elements between fields
   __device__ __forceinline__ SoA(const void* base, int fields, int64_t ld)
-      : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, base == nullptr ? 0 : (int)((int64_t)fields * ld * (int64_t)sizeof(E) > 0x7fffffffLL ? 0x7fffffffLL : (int64_t)fields * ld * (int64_t)sizeof(E)), 0x00020000)),
+      : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, base == nullptr ? 0 : 0x7fffffff, 0x00020000)),
         L((unsigned)ld) {}
   __device__ __forceinline__ unsigned soff(int f, unsigned first) const { return ((unsigned)f * L + first) * (unsigned)sizeof(E); }
   __device__ __forceinline__ E load(int f, unsigned first, unsigned lane) const {
