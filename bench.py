@@ -2,6 +2,7 @@
 """bench.py — env-steps/s of the batched quadrotor step on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 1000 --warmup 50
+    python bench.py --gpus N ...          (no launcher: starts the N ranks itself as child processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -205,8 +206,28 @@ def _ensure_library(dist, local_rank):
             dist.barrier()
 
 
+def _spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` called without a launcher (no WORLD_SIZE in the environment): start the N ranks
+    as CHILD processes — `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` — relay
+    their output (rank 0 prints the JSON line) and return their exit code.  Decided before anything in this
+    process touches the GPU; nothing is exec'ed over a process that did."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between processes on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_spawn_ranks(a.gpus))
     dist, rank, local_rank, world, backend = _init_dist()
     n_gpus = world
     if a.gpus != world and rank == 0:
@@ -342,7 +363,7 @@ def main():
             "metric": "quadrotor env-steps/sec at 65 536 envs; 1/2/4/8 MI355X + CPU ref",
             "value": N * n_gpus / (ms_per_step * 1e-3), "unit": "env-steps/s", "n_gpus": n_gpus, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if a.layout == "f32" else "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"mixed": "mixed f32/f64", "f64": "f64", "f32": "f32"}[a.layout], "data": "synthetic",
             "config": {"workload": (f"BASELINE.json configs[1]: Quad-v0 batched {N} envs per GPU, random actions, fp32 I/O, "
                                     + ("terminated envs re-sampled in the launch" if auto_reset else "free run from one reset")
                                     if a.kind == "quad" else f"{a.kind} wrapper, {N} envs per GPU, random actions, fp32 I/O"),

@@ -93,6 +93,42 @@ struct Args {
   Coeffs c;
 };
 
+// Cache policy of the step kernel's stores (gfx940+ aux bits of the buffer / global stores: 1 = sc0, 2 = nt, 16 = sc1).
+// Measured on MI355X (profiles/r03/ab_store_policy_all_kinds.txt, ab_load_order_store_policy.txt): with every store of a
+// launch written THROUGH (sc1) the launch-to-launch time of the helper-wave launches drops by 8-15 % (Quad-v0 65 536 envs
+// 4.41 -> 4.00 us, Coupled 5.97 -> 5.10, Decoupled 32 768 4.98 -> 4.31): a kernel that ends with clean L2s has nothing to
+// write back between its last wave and the next dispatch.  nt and sc0 alone change nothing.  The plain launches of large
+// grids are bound by bytes and gain nothing (1 M envs: equal; Coupled 131 072 envs 9.2 -> 9.6-9.9 us), and a rollout has one
+// boundary per horizon and pays for the write-through instead (Quad-v0 65 536 envs, T = 100: 1.73 -> 1.91 us per env-step,
+// profiles/r03/ab_rollout_store_policy.txt): both keep plain stores.
+#ifndef QR_HELP_AUX
+#define QR_HELP_AUX 16   // one-step helper-wave instantiations (grids in the launch-latency regime)
+#endif
+#ifndef QR_PLAIN_AUX
+#define QR_PLAIN_AUX 0   // everything else
+#endif
+
+// A store of a caller-facing output (any address, per lane) with the cache policy AUX (0: a plain store; otherwise written through).
+typedef float f4_t __attribute__((ext_vector_type(4)));
+template <int AUX = 0, typename V>
+__device__ __forceinline__ void gstore(V* p, V v) {
+  if constexpr (AUX == 0) {
+    *p = v;
+  } else if constexpr (sizeof(V) == 1) {
+    __hip_atomic_store(reinterpret_cast<uint8_t*>(p), __builtin_bit_cast(uint8_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else if constexpr (sizeof(V) == 2) {
+    __hip_atomic_store(reinterpret_cast<uint16_t*>(p), __builtin_bit_cast(uint16_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else if constexpr (sizeof(V) == 4) {
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else if constexpr (sizeof(V) == 8) {
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(p), __builtin_bit_cast(uint64_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else {
+    static_assert(sizeof(V) == 16, "1, 2, 4, 8 or 16 bytes");
+    const f4_t x = __builtin_bit_cast(f4_t, v);
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(x) : "memory");
+  }
+}
+
 constexpr double kPi = 3.14159265358979323846;
 
 template <typename T> __device__ __forceinline__ T clampT(T v, T lo, T hi) { return v < lo ? lo : (v > hi ? hi : v); }

@@ -391,25 +391,25 @@ __device__ __forceinline__ void rows_to_lds(const float (&vals)[D], float* smem,
   for (int j = 0; j < D; ++j) smem[tid * D + j] = vals[j];
 }
 
-template <int B, int D>
+template <int B, int D, int AUX = 0>
 __device__ __forceinline__ void lds_to_rows(float* __restrict__ gbase, const float* smem, int tid, int rows) {
   if (rows == B && (reinterpret_cast<uintptr_t>(gbase) & 15u) == 0) {
     constexpr int nvec = B * D / 4;  // B is a multiple of 4
     const float4* s4 = reinterpret_cast<const float4*>(smem);
     float4* g4 = reinterpret_cast<float4*>(gbase);
 #pragma unroll
-    for (int idx = tid; idx < nvec; idx += B) g4[idx] = s4[idx];
+    for (int idx = tid; idx < nvec; idx += B) gstore<AUX>(g4 + idx, s4[idx]);
   } else {
     const int total = rows * D;
-    for (int idx = tid; idx < total; idx += B) gbase[idx] = smem[idx];
+    for (int idx = tid; idx < total; idx += B) gstore<AUX>(gbase + idx, smem[idx]);
   }
 }
 
-template <int B, int D>
+template <int B, int D, int AUX = 0>
 __device__ __forceinline__ void store_rows(float* __restrict__ gbase, const float (&vals)[D], float* smem, int tid, int rows) {
   rows_to_lds<D>(vals, smem, tid);
   tile_sync<B>();
-  lds_to_rows<B, D>(gbase, smem, tid, rows);
+  lds_to_rows<B, D, AUX>(gbase, smem, tid, rows);
   tile_sync<B>();
 }
 

@@ -141,10 +141,6 @@ __device__ __forceinline__ float interp01(float r, float rmin, float inv_nrmin) 
 // an exact byte count would cost each of the step's seven descriptors half a dozen scalar instructions.
 typedef int v2i_t __attribute__((ext_vector_type(2)));
 
-#ifndef QR_STORE_AUX
-#define QR_STORE_AUX 0  // cache policy of the SoA stores (gfx940+ aux bits: 1 = sc0, 2 = nt, 16 = sc1)
-#endif
-
 template <typename E>
 struct SoA {
   __amdgpu_buffer_rsrc_t rsrc;
@@ -160,11 +156,12 @@ struct SoA {
       return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane * 8u, soff(f, first), 0));
     }
   }
+  template <int AUX = 0>  // cache policy (qr_args.h: QR_HELP_AUX)
   __device__ __forceinline__ void store(int f, unsigned first, unsigned lane, E v) const {
     if constexpr (sizeof(E) == 4) {
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsrc, lane * 4u, soff(f, first), QR_STORE_AUX);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsrc, lane * 4u, soff(f, first), AUX);
     } else {
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_t, v), rsrc, lane * 8u, soff(f, first), QR_STORE_AUX);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_t, v), rsrc, lane * 8u, soff(f, first), AUX);
     }
   }
 };
@@ -221,33 +218,41 @@ __device__ __forceinline__ void unpack_quat(const QuatPack<T>& p, T (&q)[4]) {
   q[3] = idx == 3 ? w : k2;
 }
 
+// Issue order = arrival order (a wave's vector loads complete in order, and at 65 536 envs the load phase of a launch is
+// bound by what a CU can pull in, ~11 B per cycle: the LAST word of a wave's 112 B lands ~0.7 us after the first): W and
+// the attitude first — the integration starts from them — x and v last: they enter the step only in its final update.
 template <typename XV, typename QW>
-__device__ __forceinline__ void load_state(const Args& a, int64_t first64, unsigned lane, Work<QW, XV>& w) {
+__device__ __forceinline__ void load_state_raw(const Args& a, int64_t first64, unsigned lane, Work<QW, XV>& w, QuatPack<QW>& p) {
   const SoA<XV> pv(a.pos_vel, 6, a.ld);
   const SoA<QW> ar(a.att_rate, 6, a.ld);
   const unsigned first = (unsigned)first64;
-  QuatPack<QW> p;
 #pragma unroll
   for (int f = 0; f < 3; ++f) p.k[f] = ar.load(f, first, lane);
 #pragma unroll
   for (int f = 0; f < 3; ++f) w.W[f] = ar.load(3 + f, first, lane);
 #pragma unroll
   for (int f = 0; f < 3; ++f) { w.x[f] = pv.load(f, first, lane); w.v[f] = pv.load(3 + f, first, lane); }
+}
+
+template <typename XV, typename QW>
+__device__ __forceinline__ void load_state(const Args& a, int64_t first64, unsigned lane, Work<QW, XV>& w) {
+  QuatPack<QW> p;
+  load_state_raw<XV, QW>(a, first64, lane, w, p);
   unpack_quat(p, w.q);
 }
 
 // (the packed attitude is passed in: the step kernel forms it once per env-step, see QuatPack)
-template <typename XV, typename QW>
+template <typename XV, typename QW, int AUX = 0>
 __device__ __forceinline__ void store_state(const Args& a, int64_t first64, unsigned lane, const Work<QW, XV>& w, const QuatPack<QW>& p) {
   const SoA<XV> pv(a.pos_vel, 6, a.ld);
   const SoA<QW> ar(a.att_rate, 6, a.ld);
   const unsigned first = (unsigned)first64;
 #pragma unroll
-  for (int f = 0; f < 3; ++f) ar.store(f, first, lane, p.k[f]);
+  for (int f = 0; f < 3; ++f) ar.template store<AUX>(f, first, lane, p.k[f]);
 #pragma unroll
-  for (int f = 0; f < 3; ++f) ar.store(3 + f, first, lane, w.W[f]);
+  for (int f = 0; f < 3; ++f) ar.template store<AUX>(3 + f, first, lane, w.W[f]);
 #pragma unroll
-  for (int f = 0; f < 3; ++f) { pv.store(f, first, lane, w.x[f]); pv.store(3 + f, first, lane, w.v[f]); }
+  for (int f = 0; f < 3; ++f) { pv.template store<AUX>(f, first, lane, w.x[f]); pv.template store<AUX>(3 + f, first, lane, w.v[f]); }
 }
 
 template <typename XV, typename QW>

@@ -116,13 +116,13 @@ __device__ unsigned long long* g_stamps = nullptr;
 // grid — stepping and helper — is resident at once.  Measured (bench.py, HELP / plain, us per launch): Quad-v0 65 536 envs
 // 4.55 / 5.46, 98 304 5.65 / 6.42, 131 072 6.13 / 6.81, 196 608 9.23 / 8.40; Coupled 65 536 6.71 / 7.72, 98 304 7.78 / 8.63,
 // 131 072 9.64 / 9.06; Decoupled 32 768 5.86 / 6.51, 98 304 7.83 / 8.63, 131 072 9.66 / 8.98.
-#define QR_HELPER_GRID 2048       // Quad-v0 (128 VGPRs: four waves per SIMD)
+#define QR_HELPER_GRID 2560       // Quad-v0 (profiles/r03/ab_helper_thresholds.txt: 163 840 envs 7.3 against 8.3 us plain, 196 608 equal, 262 144 10.3 against 9.9)
 #endif
 #ifndef QR_HELPER_GRID_ROLLOUT
 #define QR_HELPER_GRID_ROLLOUT (QR_HELPER_GRID < 1024 ? QR_HELPER_GRID : 1024)  // qr_rollout / qr_rollout_actor (two waves per SIMD)
 #endif
 #ifndef QR_HELPER_GRID_WRAP
-#define QR_HELPER_GRID_WRAP (QR_HELPER_GRID < 1536 ? QR_HELPER_GRID : 1536)  // the wrappers (three waves per SIMD)
+#define QR_HELPER_GRID_WRAP (QR_HELPER_GRID < 2560 ? QR_HELPER_GRID : 4096)  // the wrappers (r03/ab_helper_thresholds.txt: ahead of the plain launch up to 262 144 envs)
 #endif
 #ifndef QR_SPEC_GRID
 // Grids up to this many waves sample their reset pool SPECULATIVELY, right after issuing their loads.  Measured on
@@ -236,6 +236,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   using X = XV;  // and so are x, v
   using KT = KindTraits<KIND>;
   constexpr int A = KT::A, D0 = KT::D0, D1 = KT::D1 ? KT::D1 : 1, NAG = KT::NAG;
+  constexpr int AUX = (HELP && SINGLE) ? QR_HELP_AUX : QR_PLAIN_AUX;  // cache policy of every store of this launch (qr_args.h)
   __shared__ __attribute__((aligned(16))) float smem[B * (D0 > A ? D0 : A)];
   const int tid = threadIdx.x;
   const unsigned lane = threadIdx.x;
@@ -312,8 +313,8 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
           const bool d = quad_done<T, X>(hx, hv, hq, hW, c);
           if ((int)hl < rows) {
             const int64_t hrow = (int64_t)t * n_envs + first;
-            (hrew + hrow)[hl] = d ? -1.0f : interp01(r, c.rmin_mono, c.inv_nrmin_mono);  // crash override (quad.py:162-166)
-            if (hraw) (hraw + hrow)[hl] = r;
+            gstore<AUX>(hrew + hrow + hl, d ? -1.0f : interp01(r, c.rmin_mono, c.inv_nrmin_mono));  // crash override (quad.py:162-166)
+            if (hraw) gstore<AUX>(hraw + hrow + hl, r);
           }
         }
       };
@@ -343,8 +344,8 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         for (int t = 0; t < hsteps; ++t) {
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B1(t)
           if (t > 0) {
-            lds_to_rows<B, D0>(ob0 + ((int64_t)(t - 1) * n_envs + first) * D0, smem, hl, rows);
-            if constexpr (KT::D1 > 0) lds_to_rows<B, D1>(ob1 + ((int64_t)(t - 1) * n_envs + first) * D1, smem1, hl, rows);
+            lds_to_rows<B, D0, AUX>(ob0 + ((int64_t)(t - 1) * n_envs + first) * D0, smem, hl, rows);
+            if constexpr (KT::D1 > 0) lds_to_rows<B, D1, AUX>(ob1 + ((int64_t)(t - 1) * n_envs + first) * D1, smem1, hl, rows);
           }
           make_pool<T>(hp, hrole, hseed, hgfirst, rc + (uint32_t)t, 0);
           pool_to_lds(pool_lds[0], hp);
@@ -352,8 +353,8 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B2(t)
         }
         asm volatile("s_barrier" ::: "memory");  // the tile of the last step
-        lds_to_rows<B, D0>(ob0 + ((int64_t)(hsteps - 1) * n_envs + first) * D0, smem, hl, rows);
-        if constexpr (KT::D1 > 0) lds_to_rows<B, D1>(ob1 + ((int64_t)(hsteps - 1) * n_envs + first) * D1, smem1, hl, rows);
+        lds_to_rows<B, D0, AUX>(ob0 + ((int64_t)(hsteps - 1) * n_envs + first) * D0, smem, hl, rows);
+        if constexpr (KT::D1 > 0) lds_to_rows<B, D1, AUX>(ob1 + ((int64_t)(hsteps - 1) * n_envs + first) * D1, smem1, hl, rows);
         return;
       }
       if constexpr (!SINGLE) {  // a rollout: one pool per env-step, each handed over at that step's barrier
@@ -374,8 +375,8 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         if (KIND != QR_KIND_QUAD || hob0 != nullptr) {
           asm volatile("s_barrier" ::: "memory");
           const int hl = (int)threadIdx.x - B;
-          lds_to_rows<B, D0>(hob0 + first * D0, smem, hl, rows);
-          if constexpr (KT::D1 > 0) lds_to_rows<B, D1>(hob1 + first * D1, smem1, hl, rows);
+          lds_to_rows<B, D0, AUX>(hob0 + first * D0, smem, hl, rows);
+          if constexpr (KT::D1 > 0) lds_to_rows<B, D1, AUX>(hob1 + first * D1, smem1, hl, rows);
         }
       }
       return;
@@ -420,6 +421,8 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   const bool auto_reset = HELP || reset_count != nullptr;  // passed only with QR_FLAG_AUTO_RESET: its presence IS the flag, known without a load
   PoolRole role;
   uint32_t rcount_s = 0;  // the tile's position in the in-launch reset stream
+  // (Measured and NOT adopted, profiles/r03/ab_load_order_store_policy.txt: requesting parameters and action row first, x and v
+  // last, and rebuilding the quaternion behind the action map — 4.47 against 4.46 us per launch at 65 536 envs.)
   load_state<XV, QW>(a, first, ll, w);
   w.nominal = a.params == nullptr;
   {  // (without a params buffer: a descriptor without records, the loads return 0 — no branch between the load batches)
@@ -572,13 +575,13 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       if (active) {
         const int64_t arow = ((int64_t)t * N + first) * A;
         if constexpr (A == 4) {
-          reinterpret_cast<float4*>(ka.act_out + arow)[lane] = make_float4(act[0], act[1], act[2], act[3]);
-          if (ka.logp_out) reinterpret_cast<float4*>(ka.logp_out + arow)[lane] = make_float4(logp[0], logp[1], logp[2], logp[3]);
+          gstore<AUX>(reinterpret_cast<float4*>(ka.act_out + arow) + lane, make_float4(act[0], act[1], act[2], act[3]));
+          if (ka.logp_out) gstore<AUX>(reinterpret_cast<float4*>(ka.logp_out + arow) + lane, make_float4(logp[0], logp[1], logp[2], logp[3]));
         } else {
 #pragma unroll
           for (int j = 0; j < A; ++j) {
-            (ka.act_out + arow)[lane * A + j] = act[j];
-            if (ka.logp_out) (ka.logp_out + arow)[lane * A + j] = logp[j];
+            gstore<AUX>(ka.act_out + arow + lane * A + j, act[j]);
+            if (ka.logp_out) gstore<AUX>(ka.logp_out + arow + lane * A + j, logp[j]);
           }
         }
       }
@@ -724,16 +727,16 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     if (active) {
       if constexpr (NAG == 1) {
         if constexpr (!kHelpReward) {
-          (ka.reward + row0)[lane] = rwd[0];
-          if (ka.reward_raw) (ka.reward_raw + row0)[lane] = rraw[0];
+          gstore<AUX>(ka.reward + row0 + lane, rwd[0]);
+          if (ka.reward_raw) gstore<AUX>(ka.reward_raw + row0 + lane, rraw[0]);
         }
-        (done_ptr + row0)[lane] = dn[0] ? 1 : 0;
+        gstore<AUX>(done_ptr + row0 + lane, (uint8_t)(dn[0] ? 1 : 0));
       } else {
-        (reinterpret_cast<float2*>(ka.reward) + row0)[lane] = make_float2(rwd[0], rwd[NAG - 1]);
-        if (ka.reward_raw) (reinterpret_cast<float2*>(ka.reward_raw) + row0)[lane] = make_float2(rraw[0], rraw[NAG - 1]);
-        (reinterpret_cast<uchar2*>(done_ptr) + row0)[lane] = make_uchar2(dn[0] ? 1 : 0, dn[NAG - 1] ? 1 : 0);
+        gstore<AUX>(reinterpret_cast<float2*>(ka.reward) + row0 + lane, make_float2(rwd[0], rwd[NAG - 1]));
+        if (ka.reward_raw) gstore<AUX>(reinterpret_cast<float2*>(ka.reward_raw) + row0 + lane, make_float2(rraw[0], rraw[NAG - 1]));
+        gstore<AUX>(reinterpret_cast<uchar2*>(done_ptr) + row0 + lane, make_uchar2(dn[0] ? 1 : 0, dn[NAG - 1] ? 1 : 0));
       }
-      if (trunc_ptr) (trunc_ptr + row0)[lane] = trunc ? 1 : 0;
+      if (trunc_ptr) gstore<AUX>(trunc_ptr + row0 + lane, (uint8_t)(trunc ? 1 : 0));
     }
     // (HELP) the helper wave's pool is in LDS: it got there while this wave waited for its loads.  A bare s_barrier:
     // nothing of this wave's own (its reward / done stores in flight) has to be waited for.
@@ -747,11 +750,11 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         // cost more than the overlap gains once the launch is bound by bytes (measured, bench.py: 65 536 envs 5.43
         // with / 5.49 us without; 1 M envs 39.4 with / 37.4 us without).
         if (active && !need_reset) {
-          store_state<XV, QW>(a, first, lane, w, qp);
+          store_state<XV, QW, AUX>(a, first, lane, w, qp);
           if (KIND != QR_KIND_QUAD) {
             const SoA<float> integ(a.integ, 8, L);
 #pragma unroll
-            for (int f = 0; f < 8; ++f) integ.store(f, ufirst, lane, w.integ[f]);
+            for (int f = 0; f < 8; ++f) integ.store<AUX>(f, ufirst, lane, w.integ[f]);
           }
         }
         stored_early = active && !need_reset;
@@ -764,17 +767,17 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
           quat_to_R(w.q, Rf);
           float* fo = ka.final_obs0 + (row0 + lane) * D0;
 #pragma unroll
-          for (int j = 0; j < 3; ++j) { fo[j] = (float)w.x[j]; fo[3 + j] = (float)w.v[j]; fo[15 + j] = (float)w.W[j]; }
+          for (int j = 0; j < 3; ++j) { gstore<AUX>(fo + j, (float)w.x[j]); gstore<AUX>(fo + 3 + j, (float)w.v[j]); gstore<AUX>(fo + 15 + j, (float)w.W[j]); }
 #pragma unroll
-          for (int j = 0; j < 9; ++j) fo[6 + j] = (float)Rf[j];
+          for (int j = 0; j < 9; ++j) gstore<AUX>(fo + 6 + j, (float)Rf[j]);
         } else {
           float* fo = ka.final_obs0 + (row0 + lane) * D0;
 #pragma unroll
-          for (int j = 0; j < D0; ++j) fo[j] = kEarlyTile ? smem[tid * D0 + j] : o0[j];
+          for (int j = 0; j < D0; ++j) gstore<AUX>(fo + j, kEarlyTile ? smem[tid * D0 + j] : o0[j]);
           if constexpr (KT::D1 > 0) {
             float* f1 = ka.final_obs1 + (row0 + lane) * D1;
 #pragma unroll
-            for (int j = 0; j < D1; ++j) f1[j] = kEarlyTile ? smem1[tid * D1 + j] : o1[j];
+            for (int j = 0; j < D1; ++j) gstore<AUX>(f1 + j, kEarlyTile ? smem1[tid * D1 + j] : o1[j]);
           }
         }
       }
@@ -811,7 +814,9 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 #endif
       }
       if (need_reset) {
-        w.nominal = !randomise;
+        // (with a params buffer the float32 words about to be stored are also what the following steps of a rollout use,
+        // randomised or not: exactly what a one-step launch re-loads)
+        w.nominal = a.params == nullptr;
 #if QR_ABLATE != 5
         if (a.params != nullptr) params_dirty = true;
 #endif
@@ -865,8 +870,8 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       }
     } else if constexpr (kEarlyTile) {  // (plain one-step wrapper kernel) the tile(s) are complete: carry them out
       tile_sync<B>();
-      lds_to_rows<B, D0>(ka.obs0 + row0 * D0, smem, tid, rows);
-      if constexpr (KT::D1 > 0) lds_to_rows<B, D1>(ka.obs1 + row0 * D1, smem1, tid, rows);
+      lds_to_rows<B, D0, AUX>(ka.obs0 + row0 * D0, smem, tid, rows);
+      if constexpr (KT::D1 > 0) lds_to_rows<B, D1, AUX>(ka.obs1 + row0 * D1, smem1, tid, rows);
     } else if constexpr (HELP && POLICY != 0) {  // the tile is next step's MFMA operand AND this step's rows (helper wave)
       rows_to_lds<D0>(o0, smem, tid);
       if constexpr (KT::D1 > 0) rows_to_lds<D1>(o1, smem1, tid);
@@ -879,12 +884,12 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         for (int j = 0; j < 3; ++j) { o0[j] = (float)w.x[j]; o0[3 + j] = (float)w.v[j]; o0[15 + j] = (float)w.W[j]; }
 #pragma unroll
         for (int j = 0; j < 9; ++j) o0[6 + j] = (float)R[j];
-        store_rows<B, D0>(ka.obs0 + row0 * D0, o0, smem, tid, rows);
+        store_rows<B, D0, AUX>(ka.obs0 + row0 * D0, o0, smem, tid, rows);
       }
     } else {
-      store_rows<B, D0>(ka.obs0 + row0 * D0, o0, smem, tid, rows);
+      store_rows<B, D0, AUX>(ka.obs0 + row0 * D0, o0, smem, tid, rows);
     }
-    if constexpr (KT::D1 > 0) store_rows<B, D1>(ka.obs1 + row0 * D1, o1, smem, tid, rows);
+    if constexpr (KT::D1 > 0) store_rows<B, D1, AUX>(ka.obs1 + row0 * D1, o1, smem, tid, rows);
     }
     if constexpr (POLICY) {
 #pragma unroll
@@ -899,26 +904,26 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   // ---- write the working set back ----
   if (active) {
     if (!(SINGLE && stored_early)) {
-      store_state<XV, QW>(a, first, lane, w, qp);
+      store_state<XV, QW, AUX>(a, first, lane, w, qp);
       if (KIND != QR_KIND_QUAD) {
         const SoA<float> integ(a.integ, 8, L);
 #pragma unroll
-        for (int f = 0; f < 8; ++f) integ.store(f, ufirst, lane, w.integ[f]);
+        for (int f = 0; f < 8; ++f) integ.store<AUX>(f, ufirst, lane, w.integ[f]);
       }
     }
-    if (steps_ptr) (steps_ptr + first)[lane] = steps;
+    if (steps_ptr) gstore<AUX>(steps_ptr + first + lane, steps);
     if constexpr (TRAJ) {
       const SoA<float> traj(ka.traj, 8, L);
-      traj.store(0, ufirst, lane, tr.calls);
+      traj.store<AUX>(0, ufirst, lane, tr.calls);
       if (traj_dirty) {  // the rest changes only at a reset
 #pragma unroll
-        for (int f = 1; f < 7; ++f) traj.store(f, ufirst, lane, tr.get(f));
+        for (int f = 1; f < 7; ++f) traj.store<AUX>(f, ufirst, lane, tr.get(f));
       }
     }
     if (params_dirty) {
       const SoA<float> prm(a.params, 6, L);
 #pragma unroll
-      for (int f = 0; f < 6; ++f) prm.store(f, ufirst, lane, w.prm[f]);
+      for (int f = 0; f < 6; ++f) prm.store<AUX>(f, ufirst, lane, w.prm[f]);
     }
   }
   if constexpr (HELP) {  // (the helper wave read the counter; this wave only advances it)

@@ -5,7 +5,8 @@ body is one ctypes call into libquadrotor_hip.so on the current stream of the bu
 no CPU kernel behind these ops (a CPU tensor raises).
 
 Argument convention (the same for every env op):
-    state   pos_vel [6, N], att_rate [7, N]            SoA views (row stride = QrEnv.field_stride)
+    state   pos_vel [6, N] (x, v), att_rate [6, N] (the three smaller quaternion components k0 k1 k2, W)
+                                                       SoA views (row stride = QrEnv.field_stride)
     per-env integ [8, N]?, params [6, N]?, goal [12, N]?, traj [8, N]?, episode [N] i32?, steps [N] i32?,
             reset_count [ceil(N/64)] i32?              None where the env has no such buffer
     cfg     List[int] = [kind, layout, flags, seed, env_offset, goal_mode, max_episode_steps]   (QrEnv scalars)
@@ -48,7 +49,8 @@ def default_coeffs_list() -> List[float]:
 def env_args(env):
     """(tensors, cfg, coeffs) of a QuadVecEnv for the ops below: tensors = (pos_vel, att_rate, integ, params, goal, traj,
     episode, steps, reset_count); cfg / coeffs are the plain-Python copies the env keeps of its QrEnv scalars and
-    QrCoeffs (so that torch.compile can trace through this function).  Seeds are passed as int64: use seeds < 2^63."""
+    QrCoeffs (so that torch.compile can trace through this function).  Seeds are passed as int64 (QuadVecEnv accepts
+    0 <= seed < 2^63 only, so the op path and the env path draw the same streams)."""
     tensors = (env._pos_vel, env._att_rate, env._integ, env._params, env._goal, env._traj, env._episode, env._steps, env._reset_count)
     return tensors, env._op_cfg, env._op_coeffs
 
@@ -62,6 +64,8 @@ def _env_struct(pos_vel, att_rate, integ, params, goal, traj, episode, steps, re
     e = _lib.QrEnv()
     e.kind, e.layout, e.flags = int(cfg[0]), int(cfg[1]), int(cfg[2])
     e.seed, e.env_offset, e.goal_mode, e.max_episode_steps = int(cfg[3]) & (2 ** 64 - 1), int(cfg[4]), int(cfg[5]), int(cfg[6])
+    if pos_vel.shape[0] != 6 or att_rate.shape[0] != 6 or att_rate.shape[1] != pos_vel.shape[1] or att_rate.stride(0) != pos_vel.stride(0):
+        raise ValueError("pos_vel and att_rate must be [6, N] SoA views with the same row stride (quadrotor_hip.h: field_stride)")
     e.num_envs, e.field_stride = pos_vel.shape[1], pos_vel.stride(0)
     e.pos_vel, e.att_rate, e.integ, e.params, e.goal, e.traj = _p(pos_vel), _p(att_rate), _p(integ), _p(params), _p(goal), _p(traj)
     e.episode, e.steps, e.reset_count = _p(episode), _p(steps), _p(reset_count)
@@ -171,6 +175,16 @@ def qr_reset(pos_vel: torch.Tensor, att_rate: torch.Tensor, integ: Optional[torc
         _lib.check(_lib.load().qr_reset(C.byref(e), _p(mask), _stream(pos_vel)), "qr_reset")
 
 
+@torch.library.custom_op(f"{_NS}::qr_traj_start", mutates_args=("traj",))
+def qr_traj_start(pos_vel: torch.Tensor, att_rate: torch.Tensor, traj: torch.Tensor, episode: Optional[torch.Tensor],
+                  mask: Optional[torch.Tensor], draws: Optional[torch.Tensor], cfg: List[int], coeffs: List[float]) -> None:
+    """TrajectoryGenerator.mark_traj_start for masked envs from the current state (qr_traj_start); draws [3, N] injects
+    theta_b1d, t_traj, w_b1d, default: the env's stream (seed, global env id, episode)."""
+    e = _env_struct(pos_vel, att_rate, None, None, None, traj, episode, None, None, cfg, coeffs)
+    with torch.cuda.device(pos_vel.device):
+        _lib.check(_lib.load().qr_traj_start(C.byref(e), _p(mask), _p(draws), _stream(pos_vel)), "qr_traj_start")
+
+
 @torch.library.custom_op(f"{_NS}::qr_get_state", mutates_args=("rows",))
 def qr_get_state(pos_vel: torch.Tensor, att_rate: torch.Tensor, rows: torch.Tensor, cfg: List[int], coeffs: List[float]) -> None:
     """QuadEnv.get_current_state: float64 rows [N, 18] = (x, v, vec_F(R(q)), W) (qr_get_state)."""
@@ -250,10 +264,15 @@ def error_obs(env) -> None:
 
 
 def reset(env, env_type: str = "train", mask: Optional[torch.Tensor] = None) -> None:
+    """What QuadVecEnv.reset launches: qr_reset, then (fused goal generator) qr_traj_start for the same envs — main.py:226-227;
+    the previous episode's observation rows stop being the env's current observation."""
     t, cfg, co = env_args(env)
-    cfg = list(cfg)
-    cfg[2] = (cfg[2] & ~3) | (2 if env_type == "eval" else 0)  # clear QR_FLAG_AUTO_RESET, select QR_FLAG_EVAL_RESET
-    torch.ops.gym_rotor_amd.qr_reset(t[0], t[1], env._integ, env._params, env._episode, env._steps, mask, cfg, co)
+    rcfg = list(cfg)
+    rcfg[2] = (rcfg[2] & ~3) | (2 if env_type == "eval" else 0)  # clear QR_FLAG_AUTO_RESET, select QR_FLAG_EVAL_RESET
+    torch.ops.gym_rotor_amd.qr_reset(t[0], t[1], env._integ, env._params, env._episode, env._steps, mask, rcfg, co)
+    if env.goal_mode is not None:
+        torch.ops.gym_rotor_amd.qr_traj_start(t[0], t[1], env._traj, env._episode, mask, None, cfg, co)
+    env._last_obs = None
 
 
 def get_state(env, rows: torch.Tensor) -> None:

@@ -147,7 +147,7 @@ class QuadVecEnv:
         self.layout = layout
         self.use_UDM, self.UDM_percentage = bool(use_UDM), float(UDM_percentage)
         self.auto_reset, self.max_episode_steps = bool(auto_reset), int(max_episode_steps)
-        self.env_offset, self.seed = int(env_offset), int(seed)
+        self.env_offset, self.seed = int(env_offset), self._check_seed(seed)
         c = self.constants = constants or QuadConstants(UDM_percentage=UDM_percentage)
 
         # ---- attributes the reference's callers read (trajectory_generator.py:44-46,
@@ -231,6 +231,14 @@ class QuadVecEnv:
         self._closed = False
 
     # ------------------------------------------------------------------------------
+    @staticmethod
+    def _check_seed(seed) -> int:
+        """Seeds are Philox keys of 64 bits; the torch custom ops carry them as int64, so both paths accept 0 <= seed < 2^63."""
+        seed = int(seed)
+        if not 0 <= seed < 2 ** 63:
+            raise ValueError("seed must satisfy 0 <= seed < 2**63")
+        return seed
+
     def _soa(self, fields: int, dtype) -> torch.Tensor:
         """[fields, N] view of a zeroed [fields, ld] buffer (the view starts at the buffer's base)."""
         return torch.zeros(fields, self._ld, dtype=dtype, device=self.device)[:, :self.num_envs]
@@ -239,7 +247,7 @@ class QuadVecEnv:
         e, o = self._cenv, self._cout
         e.kind, e.layout = _lib.KIND_ID[self.kind], _lib.LAYOUT_ID[self.layout]
         e.num_envs, e.field_stride = self.num_envs, self._ld
-        e.env_offset, e.seed = self.env_offset, self.seed & (2 ** 64 - 1)
+        e.env_offset, e.seed = self.env_offset, self.seed
         e.pos_vel, e.att_rate = _ptr(self._pos_vel), _ptr(self._att_rate)
         e.integ, e.params, e.goal = _ptr(self._integ), _ptr(self._params), _ptr(self._goal)
         e.traj = _ptr(self._traj)
@@ -252,7 +260,7 @@ class QuadVecEnv:
         o.final_obs0, o.final_obs1 = _ptr(self._final0), _ptr(self._final1)
         # the same QrEnv scalars / QrCoeffs as plain Python values, for the torch custom ops (torch_ops.env_args):
         # [kind, layout, flags, seed, env_offset, goal_mode, max_episode_steps]
-        self._op_cfg = [int(e.kind), int(e.layout), int(e.flags), int(self.seed) & (2 ** 63 - 1), int(self.env_offset),
+        self._op_cfg = [int(e.kind), int(e.layout), int(e.flags), int(self.seed), int(self.env_offset),
                         int(e.goal_mode), int(self.max_episode_steps)]
         self._op_coeffs = [float(getattr(e.coeffs, n)) for n, _ in _lib.QrCoeffs._fields_]
 
@@ -455,9 +463,9 @@ class QuadVecEnv:
         if env_type not in ("train", "eval"):
             raise ValueError("env_type must be 'train' or 'eval'")
         if seed is not None:
-            self.seed = int(seed)
-            self._cenv.seed = self.seed & (2 ** 64 - 1)
-            self._op_cfg[3] = self.seed & (2 ** 63 - 1)
+            self.seed = self._check_seed(seed)
+            self._cenv.seed = self.seed
+            self._op_cfg[3] = self.seed
         m = None
         if mask is not None:
             if mask.shape != (self.num_envs,) or mask.device != self.device:
@@ -547,8 +555,8 @@ class QuadVecEnv:
         return rows[:, 0:3], rows[:, 3:6], rows[:, 6:9], rows[:, 9:12], rows[:, 12:15]
 
     def get_current_state(self) -> torch.Tensor:
-        """quad.py:409-410: float64 [N,18] = (x, v, vec_F(R), W), rebuilt from the 13-word
-        internal state (R = R(q)) by a small kernel; a fresh tensor each call."""
+        """quad.py:409-410: float64 [N,18] = (x, v, vec_F(R), W), rebuilt from the 12-word
+        internal state (x, v, smallest-three quaternion, W; R = R(q)) by a small kernel; a fresh tensor each call."""
         rows = torch.empty(self.num_envs, 18, dtype=torch.float64, device=self.device)
         with self._on_device():
             _lib.check(self._lib.qr_get_state(C.byref(self._cenv), rows.data_ptr(), self._stream()), "qr_get_state")
@@ -558,7 +566,8 @@ class QuadVecEnv:
         """Inject states (and optionally integrator terms / parameters): [N,18] / [N,8] / [N,6]; with
         `mask` only the masked envs change (state, integ and params alike).  R goes through the
         reference's ensure_SO3 rule and is stored as a unit quaternion.  A row whose attitude block
-        has no nearest rotation (det R <= 0, NaN/Inf) raises ValueError and leaves that env untouched."""
+        has no nearest rotation (det R <= 0, NaN/Inf) is rejected: that env keeps its state, and ValueError is
+        raised BEFORE any integrator terms / parameters are applied (to any env) — the other rows' states are set."""
         s = torch.as_tensor(state, device=self.device).to(torch.float64).contiguous()
         if tuple(s.shape) != (self.num_envs, 18):
             raise ValueError(f"state must be [{self.num_envs}, 18]")
@@ -568,6 +577,12 @@ class QuadVecEnv:
         self._rejected.zero_()
         with self._on_device():
             _lib.check(self._lib.qr_set_state(C.byref(self._cenv), s.data_ptr(), _ptr(m), self._rejected.data_ptr(), self._stream()), "qr_set_state")
+        self._last_obs = None
+        bad = int(self._rejected.item())  # off the hot path: one host sync per injection
+        if bad:
+            raise ValueError(f"set_state: {bad} row(s) rejected — the attitude block has det R <= 0 or non-finite entries "
+                             "(no nearest rotation); those envs keep their previous state, and no integrator terms / "
+                             "parameters were applied")
         sel = None if m is None else m.bool()[None, :]
 
         def put(dst, rows):
@@ -584,11 +599,6 @@ class QuadVecEnv:
                 self._params.copy_(torch.tensor(self.constants.nominal_params, dtype=torch.float32, device=self.device)[:, None].expand(6, self.num_envs))
                 self._cenv.params = self._params.data_ptr()
             put(self._params, params)
-        self._last_obs = None
-        bad = int(self._rejected.item())  # off the hot path: one host sync per injection
-        if bad:
-            raise ValueError(f"set_state: {bad} row(s) rejected — the attitude block has det R <= 0 or non-finite entries "
-                             "(no nearest rotation); those envs keep their previous state")
 
     def final_observation(self):
         """Terminal observation rows of the envs re-sampled by the LAST step() (final_obs=True): rows of
@@ -613,8 +623,8 @@ class QuadVecEnv:
         sd = dict(sd)
         self._policy_steps = int(sd.pop("policy_steps", 0))
         if "seed" in sd:
-            self.seed = int(sd.pop("seed"))
-            self._cenv.seed = self.seed & (2 ** 64 - 1)
+            self.seed = self._check_seed(sd.pop("seed"))
+            self._cenv.seed = self.seed
         last = sd.pop("last_obs", None)
         self._last_obs = None
         if last is not None:

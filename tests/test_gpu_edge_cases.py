@@ -212,17 +212,57 @@ def test_torch_custom_ops_match_the_env_bit_for_bit(kind, kw):
     assert int(rej) == 0
     _same_env_state(env, ref)
     mask = torch.rand(n, device="cuda", generator=g) < 0.3
-    ops.reset(env, "train", mask.to(torch.uint8))
+    ops.reset(env, "train", mask.to(torch.uint8))                       # (fused goals: qr_reset + qr_traj_start, like QuadVecEnv.reset)
     flags = ref._cenv.flags
-    ref.goal_mode, keep = None, ref.goal_mode                           # (plain qr_reset, without mark_traj_start)
     ref.reset("train", mask=mask)
-    ref.goal_mode = keep
     assert ref._cenv.flags == flags
     _same_env_state(env, ref)
+    assert env._last_obs is None                                        # the old episode's rows are not the new one's observation
     if kind != "quad":
         ops.error_obs(env); ref.get_norm_error_state()
         _same_env_state(env, ref)
         assert torch.equal(env._obs0, ref._obs0)
+
+
+@pytest.mark.parametrize("kind", ["quad", "decoupled"])
+def test_rollout_equals_steps_with_nominal_params_in_a_params_buffer(kind):
+    """use_UDM=False with a params buffer (set_state(params=...)): an env re-sampled inside a rollout keeps using the
+    float32 parameter words it stores — what a one-step launch re-loads — so qr_rollout(T) == T x qr_step bit for bit."""
+    n, T = 2048, 150
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    e1, e2 = (_env(kind, n, seed=4, use_UDM=False, auto_reset=True, obs_rows=True) for _ in range(2))
+    prm = torch.tensor(orc.NOMINAL_PARAMS, dtype=torch.float32, device="cuda")[None].expand(n, 6) * (1 + 0.05 * torch.rand(n, 6, device="cuda", generator=g))
+    for e in (e1, e2):
+        e.reset("train")
+        e.set_state(e.get_current_state(), params=prm)
+        assert e._params is not None
+        if kind != "quad":
+            e.get_norm_error_state()
+    acts = torch.rand(T, n, e1.action_dim, device="cuda", generator=g) * 2 - 1
+    rew = []
+    for t in range(T):
+        _, r, d, _, _ = e1.step(acts[t])
+        rew.append(r.clone())
+    ro = e2.rollout(acts)
+    assert int(e1._episode.sum()) > n + n // 4                          # (1 per qr_reset + the in-launch resets, stepped on afterwards)
+    assert torch.equal(torch.stack(rew), ro["reward"])
+    _same_env_state(e1, e2)
+    # the re-sampled envs carry the float32 NOMINAL parameters now (no randomisation)
+    reset_rows = e1._episode > 1
+    assert torch.equal(e1.params[reset_rows], torch.tensor(orc.NOMINAL_PARAMS, dtype=torch.float32, device="cuda")[None].expand(int(reset_rows.sum()), 6))
+
+
+def test_set_state_raises_before_applying_integrators_and_params():
+    """A rejected attitude row: ValueError, and neither integrator terms nor parameters were applied to any env."""
+    n = 128
+    env = _env("coupled", n, seed=2)
+    env.reset("train")
+    s = _np(env.get_current_state())
+    s[5, 6:15] = 0.0
+    integ0, prm0 = env._integ.clone(), env._params.clone()
+    with pytest.raises(ValueError, match="1 row"):
+        env.set_state(s, integ=np.ones((n, 8)), params=np.full((n, 6), 2.0))
+    assert torch.equal(env._integ, integ0) and torch.equal(env._params, prm0)
 
 
 def test_torch_custom_op_policy_rollout_and_gae():
@@ -232,7 +272,7 @@ def test_torch_custom_op_policy_rollout_and_gae():
     env, ref = _twin("decoupled", n, seed=3, auto_reset=True)
     actors = random_actors("decoupled", "cuda", generator=torch.Generator("cuda").manual_seed(2), log_std=-0.7)
     want = ref.rollout_actor(actors, T)
-    out = {k: torch.empty_like(v) for k, v in want.items() if isinstance(v, torch.Tensor)}
+    out = {k: torch.zeros_like(v) for k, v in want.items() if isinstance(v, torch.Tensor)}   # (no time limit: `truncated` is not written)
     ops.rollout_actor(env, actors, T, [env._obs0, env._obs1], out, step_base=0)
     for k, v in out.items():
         assert torch.equal(v, want[k]), k

@@ -185,7 +185,7 @@ def test_abi_argument_errors_without_gpu():
 def test_launch_geometry_rule_without_gpu():
     """qr_step_kernel_info (host-only) reports the launch the step launcher would use: one 64-lane wavefront per 64-env
     tile, plus a helper wavefront (128 threads per workgroup) exactly for: in-launch auto-reset, default layout, no rate
-    adaptivity in reach, and grids of <= 2048 tiles (Quad-v0) / <= 1536 (wrappers) / <= 1024 (rollouts); with the fused
+    adaptivity in reach, and grids of <= 2560 tiles (Quad-v0) / <= 4096 (wrappers) / <= 1024 (rollouts); with the fused
     goal generator only for one-step launches."""
     L = _lib()
     lib = L.load()
@@ -207,9 +207,9 @@ def test_launch_geometry_rule_without_gpu():
     GOAL_EXTERNAL = int(re.search(r"#define QR_GOAL_EXTERNAL\s+(\d+)", hdr).group(1))
     assert info(0, 65536, AR) == ("qr::step_kernel<0,...>", 1024, 128)
     assert info(0, 65536 + 1, AR)[1:] == (1025, 128)                      # ragged tail: one more tile
-    assert info(0, 131072, AR)[2] == 128 and info(0, 131072 + 64, AR)[2] == 64
-    assert info(1, 98304, AR)[2] == 128 and info(1, 98304 + 64, AR)[2] == 64
-    assert info(2, 32768, AR)[2] == 128 and info(2, 131072, AR)[2] == 64
+    assert info(0, 163840, AR)[2] == 128 and info(0, 163840 + 64, AR)[2] == 64
+    assert info(1, 262144, AR)[2] == 128 and info(1, 262144 + 64, AR)[2] == 64
+    assert info(2, 32768, AR)[2] == 128 and info(2, 262144, AR)[2] == 128 and info(2, 524288, AR)[2] == 64
     assert info(0, 65536, 0)[2] == 64                                      # no in-launch reset: nothing for a helper to sample
     assert info(0, 65536, AR, layout=1)[2] == 64 and info(0, 65536, AR, layout=2)[2] == 64
     assert info(0, 65536, AR, w_adapt=3.0)[2] == 64                        # rate adaptivity within reach of |W| < W_lim: the adaptive kernel
@@ -285,11 +285,20 @@ def test_all_gather_rows_single_process_is_identity():
 
 def test_torch_custom_ops_are_registered():
     import gym_rotor_amd  # noqa: F401
-    for name in ("qr_step", "qr_rollout", "qr_rollout_actor", "qr_error_obs", "qr_reset", "qr_get_state", "qr_set_state", "qr_gae"):
+    for name in ("qr_step", "qr_rollout", "qr_rollout_actor", "qr_error_obs", "qr_reset", "qr_traj_start", "qr_get_state", "qr_set_state", "qr_gae"):
         assert hasattr(torch.ops.gym_rotor_amd, name)
     with pytest.raises(RuntimeError, match="GPU only"):
         torch.ops.gym_rotor_amd.qr_gae(torch.zeros(2, 3), torch.zeros(2, 3, dtype=torch.bool), torch.zeros(3, 3), 0.9, 0.9,
                                        torch.zeros(2, 3), torch.zeros(2, 3))
+
+
+def test_seed_range():
+    """Seeds are 64-bit Philox keys carried as int64 by the torch ops: both paths accept 0 <= seed < 2^63 only."""
+    from gym_rotor_amd import QuadVecEnv
+    for bad in (-1, 2 ** 63, 2 ** 64):
+        with pytest.raises(ValueError, match="seed"):
+            QuadVecEnv._check_seed(bad)
+    assert QuadVecEnv._check_seed(2 ** 63 - 1) == 2 ** 63 - 1
 
 
 def test_gymnasium_is_optional():
@@ -359,6 +368,52 @@ def test_bench_multi_rank_control_flow():
     assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2 * d["config"]["envs_per_gpu"] and d["scaling"] == "weak"
     assert d["value"] > 1e9 and abs(d["value"] - d["config"]["global_envs"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d                           # N = 1 only
+
+
+def test_bench_gpus_n_spawns_its_own_ranks_without_gpu(monkeypatch):
+    """`bench.py --gpus 4` with no WORLD_SIZE: the ranks are started as child processes through torch.distributed.run
+    (same arguments, 127.0.0.1 rendezvous) and the children's exit code is the caller's; under a launcher nothing is spawned."""
+    import importlib
+    import subprocess as sp
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    calls = []
+
+    class R:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        calls.append((cmd, env))
+        return R()
+
+    monkeypatch.setattr(sp, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 7 and len(calls) == 1
+    cmd, env = calls[0]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_without_a_launcher():
+    """`python bench.py --gpus 2` called the way the driver calls the 1-GPU bench: it starts its two ranks itself
+    (QR_BENCH_BACKEND=gloo lets them share the one GPU of this box) and relays rank 0's line."""
+    import json
+    env = dict(os.environ, QR_BENCH_BACKEND="gloo", PYTHONPATH=ROOT)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "100", "--warmup", "5", "--extras", "0"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2 * d["config"]["envs_per_gpu"] == 131072
+    assert d["dtype"] == "mixed f32/f64" and "cpu_baseline" not in d
 
 
 @pytest.mark.gpu
