@@ -77,8 +77,16 @@ __device__ unsigned long long* g_stamps = nullptr;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory");    \
     if (g_stamps != nullptr && lane == 0) g_stamps[(size_t)blockIdx.x * 8 + (k)] = t_;            \
   } while (0)
+// the helper wave's stamps: rows gridDim.x .. 2 gridDim.x - 1 of the same buffer
+#define QR_HSTAMP(k, dep)                                                                         \
+  do {                                                                                            \
+    unsigned long long t_;                                                                        \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory");    \
+    if (g_stamps != nullptr && threadIdx.x == 64) g_stamps[((size_t)gridDim.x + blockIdx.x) * 8 + (k)] = t_; \
+  } while (0)
 #else
 #define QR_STAMP(k, dep) do { } while (0)
+#define QR_HSTAMP(k, dep) do { } while (0)
 #endif
 
 #ifndef QR_EARLY_STORE_GRID
@@ -273,6 +281,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     // (the wave's first lane decides: a wave-uniform branch in the compiler's eyes too — on threadIdx.x itself everything
     // after it counts as divergent control flow, and scalar offsets of the loads below were re-derived per lane)
     if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= B) {  // ---- the helper wavefront: pass 0 of the tile's reset pool -> LDS ----
+      QR_HSTAMP(0, threadIdx.x);
       float hgoal[12];
 #pragma unroll
       for (int f = 0; f < 12; ++f) hgoal[f] = f == 6 ? 1.0f : 0.0f;  // hover default (quad.py:98-101)
@@ -367,10 +376,14 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         }
         return;
       }
+      QR_HSTAMP(1, hrole.off[0] + (float)rc);
       make_pool<T>(hp, hrole, hseed, hgfirst, rc, 0);
       pool_to_lds(pool_lds[0], hp);
+      QR_HSTAMP(2, hp.v[0] + (float)hp.q[0]);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if constexpr (kHelpReward) help_reward(0);  // ---- then the reward of the step, from the post-step state the stepping wave left in LDS ----
+      QR_HSTAMP(3, threadIdx.x);
+      if constexpr (kHelpReward) help_reward(0);
+      QR_HSTAMP(4, threadIdx.x);  // ---- then the reward of the step, from the post-step state the stepping wave left in LDS ----
       if constexpr (kHelpRows) {  // ---- and the observation rows: the stepping wave leaves the tile in LDS, this wave carries it out ----
         if (KIND != QR_KIND_QUAD || hob0 != nullptr) {
           asm volatile("s_barrier" ::: "memory");

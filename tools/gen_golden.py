@@ -23,6 +23,9 @@ Files written (see tests/golden/README.md for the field lists):
   actor_td3.npz            the reference's MLP_Actor_TD3 + explicit-noise choose_action
   actor_sac.npz            the reference's MLP_Actor_SAC forward + explicit-noise sample
   actorloop_{kind}.npz     closed loop: reference wrapper env stepped by the reference's actor(s), 4 envs x 200 steps
+  closedloop_td3_{mono,modul}.npz   (`python tools/gen_golden.py td3`) the reference's eval loop (main.py:270-345) with the SHIPPED
+                           TD3-EMLP actors (models/*.pth) in TrajectoryGenerator modes 0 / 1 / 6: realistic, non-random actions
+                           incl. eight-shaped-curve tracking.  Needs tools/_plum_shim (see there).
 """
 import os
 import sys
@@ -612,6 +615,189 @@ def gen_actorloop(kind, n_env=4, T=200, seed=0):
           f"max|x| {np.abs(states[..., 0:3]).max():.2f}, |action| mean {np.abs(actions).mean():.3f}")
 
 
+# ------------------------------------------------------------------------------------------------------------
+# f3: closed loop with the shipped TD3-EMLP actors
+# ------------------------------------------------------------------------------------------------------------
+def _td3_args(framework):
+    sys.argv = ["x", "--framework", framework, "--test_model", "True"]
+    import torch
+    import args_parse
+    args = args_parse.create_parser().parse_args()
+    args.device = torch.device("cpu")
+    return args
+
+
+def _install_deterministic_tiebreak():
+    """The reference orders representations of equal size by `hash(self) < hash(other)` (representation.py:171-188), and
+    its hashes are `hash((type(self), self.G))` / `hash(repr(group))`: the addresses of type objects and salted string
+    hashes, i.e. different in every interpreter.  The order decides which input slots a BiLinear layer's torch.randint
+    picks (representation.py:374-376) — it is part of the function the checkpoint's weights belong to, and it is not
+    in the checkpoint.  Here `hash` is replaced, inside those two modules only, by a deterministic salted hash, and the
+    salt is chosen so that the actors reproduce the reference-owned flight log (build_shipped_actors)."""
+    import zlib
+    import algos.emlp_torch.reps.representation as rep_mod
+    import algos.emlp_torch.groups as grp_mod
+    salt = [0]
+
+    def det_hash(o):
+        if isinstance(o, tuple):
+            s = "(" + ",".join(str(det_hash(x)) for x in o) + ")"
+        elif isinstance(o, type):
+            s = o.__module__ + "." + o.__qualname__
+        elif isinstance(o, (int, np.integer)):
+            return int(o)
+        elif isinstance(o, str):
+            s = o
+        else:
+            return o.__hash__()
+        return zlib.crc32((str(salt[0]) + "|" + s).encode())
+
+    rep_mod.hash = det_hash
+    grp_mod.hash = det_hash
+    return salt
+
+
+def _flightlog_obs():
+    """Observations (MODUL) rebuilt from the flight log: row i's action was computed from the observation returned by
+    step i-1, i.e. from state i and the goal of row i-1 (quad.py:421-466 uses the goal set BEFORE the step); the
+    integral terms and eb1 are logged directly (main.py:343-352, utils.py:21-39)."""
+    log = np.loadtxt(os.path.join(REF, "results", "MODUL_log_20250303_120200.dat"))
+    act, st, eIx, eb1, eIb1, cmd = log[:, 0:5], log[:, 5:23], log[:, 23:26], log[:, 26], log[:, 27], log[:, 28:40]
+    x, v, W, b1, b2, b3 = st[:, 0:3], st[:, 3:6], st[:, 15:18], st[:, 6:9], st[:, 9:12], st[:, 12:15]
+    prev = np.concatenate([cmd[:1], cmd[:-1]])
+    ex, ev, eW = (x - prev[:, 0:3]) / 1.0, (v - prev[:, 3:6]) / 4.0, (W - prev[:, 9:12]) / (2 * np.pi)
+    o1 = np.concatenate([ex, eIx / 3.0, ev, b3, eW[:, 0:1] * b1 + eW[:, 1:2] * b2], 1).astype(np.float32)
+    o2 = np.stack([eb1 / np.pi, eIb1 / 3.0, eW[:, 2]], 1).astype(np.float32)
+    return o1, o2, act
+
+
+def build_shipped_actors():
+    """The three shipped TD3-EMLP actors, constructed as main.py constructs them in test mode (set_seed(1992), then the agents in
+    order: main.py:64,82-83; only actors: td3.py:35-47) and validated against the reference-owned flight log: fed the log's own
+    observations, the MODUL pair must reproduce the logged action columns to 1e-6 on rows 1..3599 (row 0's observation
+    was formed with a goal the log does not hold).  Returns ({'MODUL': [a0, a1], 'MONO': [a]}, report dict)."""
+    import random
+    import torch
+    sys.path.insert(0, os.path.join(HERE, "_plum_shim"))
+    args = _td3_args("MODUL")
+    salt = _install_deterministic_tiebreak()
+    from algos.td3.td3_emlp import EMLP_MODUL1_Actor_TD3, EMLP_MODUL2_Actor_TD3, EMLP_MONO_Actor_TD3
+    sd = {k: torch.load(os.path.join(REF, "models", f), map_location="cpu") for k, f in
+          (("m0", "TD3_MODUL_564.0k_steps_agent_0_1992.pth"), ("m1", "TD3_MODUL_850.0k_steps_agent_1_1992.pth"),
+           ("mono", "TD3_MONO_700.0k_steps_agent_0_1992.pth"))}
+    o1, o2, act = _flightlog_obs()
+
+    def seeded():
+        random.seed(1992); np.random.seed(1992); torch.manual_seed(1992)
+
+    report = {}
+    for s_ in range(64):
+        salt[0] = s_
+        seeded()
+        a0, a1 = EMLP_MODUL1_Actor_TD3(args, 0), EMLP_MODUL2_Actor_TD3(args, 1)
+        a0.load_state_dict(sd["m0"]); a1.load_state_dict(sd["m1"])
+        with torch.no_grad():
+            pred = np.concatenate([a0(torch.from_numpy(o1)).numpy(), a1(torch.from_numpy(o2)).numpy()], 1)
+        err = np.abs(pred - act)[1:]
+        if err.max() <= 1e-6:
+            report = {"tiebreak_salt": s_, "flightlog_action_max_err_rows_1_3599": float(err.max()),
+                      "flightlog_action_err_row_0": np.abs(pred - act)[0].tolist()}
+            break
+    else:
+        raise SystemExit("f3: no tie-break order reproduces the flight log's actions; last worst error %g" % err.max())
+    # MONO: no reference-owned log.  Its representations hold no equal-size ties inside one group, so its function must
+    # not depend on the tie-break at all: checked over salts on random observations.
+    margs = _td3_args("MONO")
+    outs = []
+    probe = torch.from_numpy(np.random.default_rng(5).uniform(-1, 1, (64, 23)).astype(np.float32))
+    for s_ in (report["tiebreak_salt"], 0, 1, 2, 3, 4, 5):
+        salt[0] = s_
+        seeded()
+        am = EMLP_MONO_Actor_TD3(margs, 0)
+        am.load_state_dict(sd["mono"])
+        with torch.no_grad():
+            outs.append(am(probe).numpy())
+    report["mono_max_spread_over_tiebreaks"] = float(max(np.abs(o - outs[0]).max() for o in outs))
+    salt[0] = report["tiebreak_salt"]
+    seeded()
+    am = EMLP_MONO_Actor_TD3(margs, 0)
+    am.load_state_dict(sd["mono"])
+    print("shipped actors:", report)
+    return {"MODUL": [a0, a1], "MONO": [am]}, report
+
+
+def gen_closedloop_td3(framework, actors, report, modes=((0, 600), (1, 1000), (6, 1800))):
+    """main.py's eval loop (:290-345) with the shipped actor(s): eval reset, mark_traj_start, per step get_desired(current
+    state) -> set_goal_state -> actor(obs) -> step.  One env per mode; the generator's draws are injected and recorded."""
+    import torch
+    import utils.trajectory_generator as tg_mod
+    kind = {"MODUL": "decoupled", "MONO": "coupled"}[framework]
+    A, nag = orc.ACTION_DIM[kind], orc.N_AGENTS[kind]
+    obs_dims = {"coupled": [23], "decoupled": [15, 3]}[kind]
+    rng = np.random.default_rng(9100 + len(framework))
+    out = {"params": f32r(orc.NOMINAL_PARAMS)[None], "modes": np.array([m for m, _ in modes]), "steps": np.array([T for _, T in modes]),
+           "tiebreak_salt": np.array(report["tiebreak_salt"]),
+           "flightlog_action_max_err": np.array(report["flightlog_action_max_err_rows_1_3599"])}
+    saved_uniform = np.random.uniform
+    for mode, T in modes:
+        env = make_env(kind)
+        sys.argv = ["x", "--framework", framework]
+        gen = tg_mod.TrajectoryGenerator(env)
+        draws = np.array([f32r(rng.uniform(-np.deg2rad(25), np.deg2rad(25))), f32r(rng.uniform(2.0, 5.0)),
+                          f32r(rng.uniform(-0.15 * np.pi, 0.15 * np.pi))])
+        queue = {0: [draws[0]], 1: [draws[1], draws[2]]}.get(mode, [])
+
+        def fake_uniform(size=None, low=0.0, high=1.0):
+            return np.array([queue.pop(0)])
+
+        init = state_in(orc.sample_reset_state(rng, 1, "eval"))[0]       # eval reset: |x| <= 0.4, yaw only (quad.py:352-356)
+        states = np.zeros((T + 1, 18)); goals = np.zeros((T, 15)); actions = np.zeros((T, A), np.float32)
+        rewards = np.zeros((T, nag)); dones = np.zeros((T, nag), bool)
+        obs_in = [np.zeros((T, d), np.float32) for d in obs_dims]; obs_out = [np.zeros((T, d), np.float32) for d in obs_dims]
+        np.random.uniform = fake_uniform
+        try:
+            inject_params(env, out["params"][0])
+            inject(env, init, orc.DEFAULT_GOAL, np.zeros(8))
+            gen.mark_traj_start(env.state)
+            xd, vd, b1d, b1d_dot, Wd = gen.get_desired(env.state, mode)
+            env.set_goal_state(xd, vd, b1d, b1d_dot, Wd)
+            first_goal = np.concatenate([xd, vd, b1d, b1d_dot, Wd])
+            obs = env.get_norm_error_state(framework)
+            first_obs = [np.asarray(o, np.float32).copy() for o in obs]
+            n_done = T
+            for t in range(T):
+                states[t] = env.state
+                xd, vd, b1d, b1d_dot, Wd = gen.get_desired(env.state, mode)
+                env.set_goal_state(np.copy(xd), np.copy(vd), np.copy(b1d), np.copy(b1d_dot), np.copy(Wd))
+                goals[t] = np.concatenate([xd, vd, b1d, b1d_dot, Wd])
+                with torch.no_grad():   # TD3.choose_action with explor_noise_std = 0 (td3.py:82-96, main.py:335)
+                    act = np.concatenate([a(torch.tensor(np.asarray(o), dtype=torch.float)[None]).numpy().flatten().clip(-1.0, 1.0)
+                                          for a, o in zip(actors, obs)])
+                for k, o in enumerate(obs):
+                    obs_in[k][t] = o
+                actions[t] = act
+                _, _, _, obs, _, rwd, done = ref_step(env, kind, actions[t].astype(np.float64))
+                rewards[t], dones[t] = rwd, done
+                for k, o in enumerate(obs):
+                    obs_out[k][t] = o
+                if any(done):
+                    n_done = t + 1
+                    break
+            states[n_done] = env.state
+        finally:
+            np.random.uniform = saved_uniform
+        assert n_done == T, f"{framework} mode {mode}: the shipped policy lost the vehicle at step {n_done}"
+        tag = f"m{mode}_"
+        out.update({tag + "init_state": init, tag + "draws": draws, tag + "first_goal": first_goal, tag + "states": states,
+                    tag + "goals": goals, tag + "actions": actions, tag + "rewards": rewards, tag + "dones": dones})
+        for k in range(len(obs_dims)):
+            out[tag + f"first_obs{k}"] = first_obs[k]; out[tag + f"obs_in{k}"] = obs_in[k]; out[tag + f"obs{k}"] = obs_out[k]
+        ex = np.abs(states[-200:, 0:3] - goals[-200:, 0:3].mean(0)).max() if mode != 6 else np.abs(states[:T, 0:3] - goals[:, 0:3]).max()
+        print(f"closedloop_td3_{framework.lower()} mode {mode}: {T} steps, max|x - xd| {'over the flight' if mode == 6 else 'last 200 steps'} {ex:.3f} m, "
+              f"|x| max {np.abs(states[:, 0:3]).max():.2f}, reward mean {rewards.mean(0)}")
+    np.savez_compressed(os.path.join(OUT, f"closedloop_td3_{framework.lower()}.npz"), **out)
+
+
 def gen_flightlog(rows=3600):
     log = np.loadtxt(os.path.join(REF, "results", "MODUL_log_20250303_120200.dat"))
     np.savez_compressed(os.path.join(OUT, "flightlog_modul.npz"), log=log[:rows])
@@ -620,6 +806,11 @@ def gen_flightlog(rows=3600):
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if ARGV[:1] == ["td3"]:  # f3: the shipped TD3-EMLP actors in the loop (needs tools/_plum_shim)
+        shipped, rep = build_shipped_actors()
+        for fw in ("MODUL", "MONO"):
+            gen_closedloop_td3(fw, shipped[fw], rep)
+        sys.exit(0)
     if ARGV[:1] == ["actor"]:  # only the actor files
         gen_actor()
         gen_actor_td3()

@@ -37,7 +37,7 @@ env.reset("train")
 if a.kind != "quad":
     env.get_norm_error_state()
 nw = (a.envs + 63) // 64
-stamps = torch.zeros(nw, 8, dtype=torch.int64, device=dev)
+stamps = torch.zeros(2 * nw, 8, dtype=torch.int64, device=dev)  # rows nw..2nw-1: the helper waves (HELP launches)
 acts = [torch.rand(a.envs, env.action_dim, device=dev) * 2 - 1 for _ in range(8)]
 s = torch.cuda.Stream()
 with torch.cuda.stream(s):
@@ -60,7 +60,8 @@ with torch.cuda.stream(s):
     torch.cuda.synchronize()
     lib.qr_debug_set_stamps(None)
 us_per_launch = e0.elapsed_time(e1) * 1e3 / a.steps
-st = stamps.cpu().numpy()
+st_all = stamps.cpu().numpy()
+st, sth = st_all[:nw], st_all[nw:]
 t = (st[:, :7] - st[:, 0].min()) * 0.01  # us since the first wave's entry (last launch of the replay)
 has_reset = st[:, 7] != 0
 out = {"envs": a.envs, "kind": a.kind, "auto_reset": a.auto_reset, "waves": nw, "us_per_launch_with_stamps": us_per_launch,
@@ -78,5 +79,12 @@ for k, name in enumerate(out["names"]):
     out[name] = {"pct_0_10_50_90_100": [float(x) for x in q], "reset_waves_median_max": [float(np.median(r)), float(r.max())],
                  "segment_median_all_reset": [float(np.median(seg)), float(np.median(segr))]}
     print(f"{name:18s} {q[0]:6.2f} {q[1]:6.2f} {q[2]:6.2f} {q[3]:6.2f} {q[4]:6.2f}   | {np.median(r):6.2f} {r.max():6.2f}               | {np.median(seg):6.2f} / {np.median(segr):6.2f}")
+if sth[:, 0].any():  # helper waves stamped: entry, scalars read, pool in LDS, released from the barrier, reward stored
+    th = (sth[:, :5] - st[:, 0].min()) * 0.01
+    out["helper"] = {}
+    for k, name in enumerate(["helper entry", "helper scalars read", "helper pool in LDS", "helper past barrier 1", "helper reward stored"]):
+        q = np.percentile(th[:, k], [0, 10, 50, 90, 100])
+        out["helper"][name] = [float(x) for x in q]
+        print(f"{name:22s} {q[0]:6.2f} {q[1]:6.2f} {q[2]:6.2f} {q[3]:6.2f} {q[4]:6.2f}")
 if a.json:
     json.dump(out, open(a.json, "w"), indent=1)
