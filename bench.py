@@ -76,7 +76,20 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     p.add_argument("--action-batches", type=int, default=64, help="distinct pre-generated [N,A] action slabs cycled through (64 x 1 MiB > L2: every step streams its actions)")
     p.add_argument("--extras", type=int, default=1, help="0: only the headline measurement (used under rocprofv3)")
-    return p.parse_args()
+    p.add_argument("--workload", default="step", choices=["step", "rollout", "rollout_actor"],
+                   help="step: one qr_step launch per env-step (the metric's configuration).  rollout: --horizon env-steps per qr_rollout "
+                        "launch, state in registers (SURVEY.md 8(d) config 2).  rollout_actor: the PPO collection loop with the actor inside "
+                        "the step kernel (qr_rollout_actor; BASELINE configs[2]; --kind coupled|decoupled).  --steps counts env-steps in all three")
+    p.add_argument("--horizon", type=int, default=0, help="env-steps per launch of the rollout workloads (default 100 / 32)")
+    a = p.parse_args()
+    if a.workload == "rollout_actor" and a.kind == "quad":
+        a.kind = "coupled"
+    if a.horizon <= 0:
+        a.horizon = {"step": 1, "rollout": 100, "rollout_actor": 32}[a.workload]
+    if a.workload == "step":
+        a.horizon = 1
+    a.steps = -(-a.steps // a.horizon) * a.horizon   # whole launches
+    return a
 
 
 def _cpu_single_env_loop(args):
@@ -144,7 +157,7 @@ def cpu_baseline(kind: str, seconds: float):
             "numpy": np.__version__, "scipy": scipy.__version__}
 
 
-def committed_traffic(kind, envs, layout, auto_reset, substeps=1):
+def committed_traffic(kind, envs, layout, auto_reset, substeps=1, workload="step", horizon=1):
     """HBM bytes per launch from the PMC profile committed under profiles/ (None if absent); the newest file wins."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
@@ -154,7 +167,8 @@ def committed_traffic(kind, envs, layout, auto_reset, substeps=1):
         if fn.endswith("_traffic.json"):
             try:
                 for rec in json.load(open(os.path.join(pdir, fn))):
-                    if (rec["kind"], rec["envs"], rec["layout"], rec["auto_reset"], rec.get("substeps", 1)) == (kind, envs, layout, auto_reset, substeps):
+                    if (rec["kind"], rec["envs"], rec["layout"], rec["auto_reset"], rec.get("substeps", 1), rec.get("workload", "step"),
+                            rec.get("env_steps_per_launch", 1)) == (kind, envs, layout, auto_reset, substeps, workload, horizon):
                         best = rec
             except Exception:
                 pass
@@ -250,8 +264,9 @@ def main():
     def run(ar: bool, timed: bool):
         """W warm-up steps, then repetitions of exactly K timed steps; returns the per-repetition
         (HIP-event ms, wall ms) lists and a few facts about the final state."""
+        H = a.horizon
         env = QuadVecEnv(a.kind, N, device=dev, seed=0, substeps=a.substeps, layout=a.layout, use_UDM=True,
-                         auto_reset=ar, env_offset=rank * N)
+                         auto_reset=ar, env_offset=rank * N, **({"obs_rows": True} if a.workload == "rollout_actor" else {}))
 
         def fresh():  # the timed steps start from reset-distribution states (configs[1])
             env.reset("train")
@@ -260,12 +275,28 @@ def main():
 
         fresh()
         gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
-        acts = [torch.rand(N, env.action_dim, device=dev, generator=gen) * 2 - 1 for _ in range(a.action_batches)]
-        for i in range(a.warmup):
-            env.step(acts[i % len(acts)])
+        if a.workload == "step":
+            acts = [torch.rand(N, env.action_dim, device=dev, generator=gen) * 2 - 1 for _ in range(a.action_batches)]
+            launch = lambda i: env.step(acts[i % len(acts)])                      # noqa: E731
+            last_done = lambda: env._done                                          # noqa: E731
+        elif a.workload == "rollout":   # [H, N, A] action slabs (4 x 105 MB at H = 100: streamed from HBM) and preallocated outputs
+            acts = [torch.rand(H, N, env.action_dim, device=dev, generator=gen) * 2 - 1 for _ in range(min(a.action_batches, 4))]
+            ro = env.rollout(acts[0])
+            launch = lambda i: env.rollout(acts[i % len(acts)], out=ro)            # noqa: E731
+            last_done = lambda: ro["terminated"][H - 1]                            # noqa: E731
+        else:                           # the actor(s) inside the step kernel, exploration noise drawn in the kernel
+            from gym_rotor_amd import random_actors
+            actors = random_actors(a.kind, dev, generator=torch.Generator(device=dev).manual_seed(7), log_std=-0.5)
+            po = env.rollout_actor(actors, H)
+            pout = {k: v for k, v in po.items() if k != "obs"}
+            launch = lambda i: env.rollout_actor(actors, H, out=pout)              # noqa: E731
+            last_done = lambda: pout["terminated"][H - 1]                          # noqa: E731
+        n_launch = a.steps // H
+        for i in range(-(-a.warmup // H)):
+            launch(i)
         # untimed lead-in of every repetition: long enough (~1.5 ms) to bring the chip back to its busy clocks after the
         # barrier's idle gap — the first ~50 launches after an idle period run 5-20 % slow — and to keep the queue ahead
-        n_lead = max(10, 300 - a.steps)
+        n_lead = max(10, 300 - a.steps) if H == 1 else max(1, 300 // H)     # (in launches)
         # a graph launch costs a fixed ~9 us on the device whatever it holds (measured: the 20-step graph ran 8 % slower per step
         # than the 1000-step one): for small K the timed graph holds `copies` back-to-back copies of the K steps
         copies = max(1, -(-300 // a.steps)) if a.mode == "graph" else 1
@@ -277,11 +308,11 @@ def main():
             graph, lead = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.stream(side):
                 with torch.cuda.graph(graph, stream=side):
-                    for i in range(a.steps * copies):
-                        env.step(acts[i % len(acts)])
+                    for i in range(n_launch * copies):
+                        launch(i)
                 with torch.cuda.graph(lead, stream=side):
                     for i in range(n_lead):
-                        env.step(acts[(a.steps + i) % len(acts)])
+                        launch(n_launch + i)
             torch.cuda.current_stream(dev).wait_stream(side)
             # untimed: the first replay uploads the graph; keep replaying for ~50 ms so the timed
             # repetitions run at the clocks a training loop sees, not at the idle-to-busy ramp
@@ -297,14 +328,14 @@ def main():
                 lead.replay()
             else:
                 for i in range(n_lead):
-                    env.step(acts[(a.steps + i) % len(acts)])
+                    launch(n_launch + i)
 
         def issue_steps():
             if graph is not None:
                 graph.replay()
             else:
-                for i in range(a.steps):
-                    env.step(acts[i % len(acts)])
+                for i in range(n_launch):
+                    launch(i)
 
         dev_ms, wall_ms = [], []
         reps_min, reps_max, budget_ms = 20, 200, 50.0
@@ -330,8 +361,8 @@ def main():
             if stop:
                 break
         finite = bool(torch.isfinite(env.get_current_state()).all())
-        done_rate = float(env._done.float().mean())
-        return dev_ms, wall_ms, finite, done_rate, env.kernel_info(), n_lead, copies
+        done_rate = float(last_done().float().mean())
+        return dev_ms, wall_ms, finite, done_rate, env.kernel_info(H), n_lead * H, copies
 
     dev_ms, wall_ms, finite, done_rate, kinfo, n_lead, copies = run(auto_reset, True)
     reps = len(dev_ms)
@@ -347,18 +378,31 @@ def main():
     med_dev, med_wall = float(tmax[0]), float(tmax[1])
 
     if rank == 0:
+        H = a.horizon
         ms_per_step = med_dev / a.steps              # THE clock of this line: HIP events around the K steps
-        launch_us = ms_per_step * 1e3
+        launch_us = ms_per_step * 1e3 * H            # duration of one launch (= H env-steps)
         wall_ms_per_step = med_wall / (a.steps * copies + n_lead)
         algo = ALGO_BYTES[a.kind] + ALGO_BYTES_PARAMS
+        # Algorithmic bytes per env-step of the rollout launches: per step only what crosses memory EVERY step — action row in
+        # (or, with the actor in the kernel, action + log-prob rows out), reward, done, [observation rows] — plus the launch's
+        # once-per-horizon share of the working set (state r/w, params, integrators r/w).
+        per_step_io = {"quad": 16 + 4 + 1, "coupled": 16 + 92 + 4 + 1, "decoupled": 20 + 72 + 8 + 2}[a.kind]
+        if a.workload == "rollout_actor":
+            per_step_io += {"coupled": 16, "decoupled": 20}[a.kind]          # action AND log-prob rows are written
+        once = 144 + 24 + (64 if a.kind != "quad" else 0)
+        if a.workload != "step":
+            algo = per_step_io + once / H
         # bytes this layout really moves per env-step: 12-word state r/w (x, v, smallest-three quaternion, W), action, [integ r/w, obs rows],
         # reward, done, params
         state_b = {"mixed": 6 * 4 + 6 * 8, "f64": 12 * 8, "f32": 12 * 4}[a.layout] * 2
         layout = state_b + {"quad": 16 + 4 + 1 + 24, "coupled": 16 + 64 + 92 + 4 + 1 + 24,
                             "decoupled": 20 + 64 + 72 + 8 + 2 + 24}[a.kind]
-        achieved = algo * N / (launch_us * 1e-6) / 1e9
+        achieved = algo * N * H / (launch_us * 1e-6) / 1e9
         kname, grid, block = kinfo
-        traffic = committed_traffic(a.kind, N, a.layout, auto_reset, a.substeps)
+        traffic = committed_traffic(a.kind, N, a.layout, auto_reset, a.substeps, a.workload, H)
+        wl = {"step": "", "rollout": f"; fused rollout, {H} env-steps per qr_rollout launch (state in registers)",
+              "rollout_actor": f"; PPO collection, {H} env-steps per qr_rollout_actor launch with the 23->16->16->4 actor (MFMA) and its "
+                               "action sampling inside the step kernel"}[a.workload]
         out = {
             "metric": "quadrotor env-steps/sec at 65 536 envs; 1/2/4/8 MI355X + CPU ref",
             "value": N * n_gpus / (ms_per_step * 1e-3), "unit": "env-steps/s", "n_gpus": n_gpus, "steps": a.steps,
@@ -366,7 +410,8 @@ def main():
             "vs_baseline": None, "dtype": {"mixed": "mixed f32/f64", "f64": "f64", "f32": "f32"}[a.layout], "data": "synthetic",
             "config": {"workload": (f"BASELINE.json configs[1]: Quad-v0 batched {N} envs per GPU, random actions, fp32 I/O, "
                                     + ("terminated envs re-sampled in the launch" if auto_reset else "free run from one reset")
-                                    if a.kind == "quad" else f"{a.kind} wrapper, {N} envs per GPU, random actions, fp32 I/O"),
+                                    if a.kind == "quad" else f"{a.kind} wrapper, {N} envs per GPU, random actions, fp32 I/O") + wl,
+                       "workload_kind": a.workload, "env_steps_per_launch": H,
                        "kind": a.kind, "envs_per_gpu": N, "global_envs": N * n_gpus, "substeps": a.substeps,
                        "integrator": "RK4 per substep on (v, unit quaternion, W): W and the q accumulation in float64, stage quaternions in "
                                      "float32; substeps x ceil(max|W|/16 rad/s) per wavefront", "state_layout": a.layout, "io_dtype": "f32",
@@ -387,7 +432,7 @@ def main():
                          # ~4.8 us per dispatch by itself (profiles/r02/rocprof_dispatch_floor.txt) and inflates kernels shorter
                          # than ~6 us; both clocks are listed, `achieved` uses this run's HIP events
                          "committed_profile": {k: (traffic or {}).get(k) for k in ("rocprofv3_kernel_mean_us", "rocprofv3_kernel_median_us",
-                                                                                     "bench_py_us_per_step_under_rocprofv3")},
+                                                                                     "bench_py_us_per_step_under_rocprofv3", "valu")},
                          "algorithmic_bytes_per_env_step": algo, "layout_bytes_per_env_step": layout,
                          "achieved_layout_GBs": layout * N / (launch_us * 1e-6) / 1e9,
                          "note": "algorithmic bytes = SURVEY.md 8(d) (165 B + 24 B per-env params for Quad-v0); "
@@ -395,7 +440,7 @@ def main():
                                  "~1.8 us boundary between dependent kernels); block 128 = a 64-lane stepping wavefront plus a "
                                  "64-lane helper wavefront per 64-env tile (reset pool, Quad-v0 reward, observation rows)"},
         }
-        if n_gpus == 1 and a.extras:
+        if n_gpus == 1 and a.extras and a.workload == "step":
             # secondary figure: the other reset mode (no reset inside step = the reference's own semantics)
             d2, _, _, _, _, _, _ = run(not auto_reset, False)
             us2 = float(np.median(d2)) * 1e3 / a.steps

@@ -182,6 +182,31 @@ def test_abi_argument_errors_without_gpu():
     assert lib.qr_step(C.byref(e4), 0x6000, 1, C.byref(o4), None) == -1      # reset_count missing
 
 
+def test_abi_argument_errors_under_sanitizers(tmp_path):
+    """The host-side launcher code (fill_env, fill_coeffs, do_rollout, the launch-geometry rule: everything a C-ABI call
+    executes before it reaches a kernel) built with -fsanitize=address,undefined (`make host-sanitize`: the host pass of the
+    single-source file only) and driven through every argument-error path by the two tests above, in a subprocess with the
+    sanitizer runtime preloaded.  CPU box only; a report aborts the child (-fno-sanitize-recover, ASan's default)."""
+    import glob
+    import shutil
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    rt = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+    if not rt:
+        pytest.skip("no ASan runtime in this ROCm install")
+    out = tmp_path / "libquadrotor_hip_hostsan.so"
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "gym_rotor_amd", "csrc"), "host-sanitize", f"SAN_OUT={out}"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and out.exists(), r.stderr[-2000:]
+    env = dict(os.environ, QR_LIB=str(out), LD_PRELOAD=rt[0], ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", PYTHONPATH=ROOT,
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_host_logic.py"),
+                        "-k", "test_abi_argument_errors_without_gpu or test_launch_geometry_rule_without_gpu or test_library_exports"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert "3 passed" in r.stdout and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+
+
 def test_launch_geometry_rule_without_gpu():
     """qr_step_kernel_info (host-only) reports the launch the step launcher would use: one 64-lane wavefront per 64-env
     tile, plus a helper wavefront (128 threads per workgroup) exactly for: in-launch auto-reset, default layout, no rate

@@ -13,18 +13,24 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
-CONFIGS = [  # summary file -> (kind, envs, layout, auto_reset, substeps)
+CONFIGS = [  # summary file -> (kind, envs, layout, auto_reset, substeps[, workload, env-steps per launch])
     ("quad65536_summary.txt", "quad", 65536, "mixed", True, 1),
     ("quad65536_noreset_summary.txt", "quad", 65536, "mixed", False, 1),
     ("quad1M_summary.txt", "quad", 1048576, "mixed", True, 1),
     ("quad131072x10_summary.txt", "quad", 131072, "mixed", True, 10),
+    ("quad1Mx10_summary.txt", "quad", 1048576, "mixed", True, 10),
     ("coupled65536_summary.txt", "coupled", 65536, "mixed", True, 1),
     ("decoupled32768_summary.txt", "decoupled", 32768, "mixed", True, 1),
+    ("decoupled262144_summary.txt", "decoupled", 262144, "mixed", True, 1),
     ("coupled1M_summary.txt", "coupled", 1048576, "mixed", True, 1),
     ("decoupled1M_summary.txt", "decoupled", 1048576, "mixed", True, 1),
+    ("rollout_quad65536_T100_summary.txt", "quad", 65536, "mixed", True, 1, "rollout", 100),
+    ("rollout_actor_coupled65536_T32_summary.txt", "coupled", 65536, "mixed", True, 1, "rollout_actor", 32),
 ]
 out = []
-for fn, kind, envs, layout, ar, sub in CONFIGS:
+for cfg in CONFIGS:
+    fn, kind, envs, layout, ar, sub = cfg[:6]
+    workload, horizon = (cfg[6], cfg[7]) if len(cfg) > 6 else ("step", 1)
     p = os.path.join(ROOT, "profiles", RND, fn)
     if not os.path.exists(p):
         continue
@@ -46,8 +52,23 @@ for fn, kind, envs, layout, ar, sub in CONFIGS:
         prof = {"rocprofv3_kernel_mean_us": int(ka.group(1)) / 1e3, "rocprofv3_kernel_median_us": int(ka.group(2)) / 1e3}
     if kb:
         prof["bench_py_us_per_step_under_rocprofv3"] = float(kb.group(1))
-    out.append({**prof, "kind": kind, "envs": envs, "layout": layout, "auto_reset": ar, "substeps": sub, "FETCH_SIZE_KB_raw": fetch,
-                "WRITE_SIZE_KB": write, "bytes_per_launch": b, "bytes_per_env_step": round(b / envs, 1),
+    mi = re.search(r"instructions per step_kernel dispatch: waves (\d+); per wave VALU ([\d.]+) SALU ([\d.]+) LDS ([\d.]+) SMEM ([\d.]+)", txt)
+    if mi:  # wave-instructions issued per launch and the share of the chip's VALU issue slots that is: 1024 SIMDs, one wave64
+        #     VALU instruction per 2 cycles each (MI355X_MICROARCH.md), at the 2.4 GHz the chip is specified for
+        waves, valu = int(mi.group(1)), float(mi.group(2))
+        prof["valu"] = {"waves_per_launch": waves, "valu_insts_per_wave": valu, "salu_insts_per_wave": float(mi.group(3)),
+                        "lds_insts_per_wave": float(mi.group(4)), "smem_insts_per_wave": float(mi.group(5))}
+        if ka:
+            dur_us = int(ka.group(1)) / 1e3
+            prof["valu"]["issue_slots_used_frac"] = round(waves * valu / (1024 * dur_us * 1e-6 * 2.4e9 / 2.0), 4)
+            prof["valu"]["note"] = "VALU wave-instructions per launch / (1024 SIMDs x launch duration x 2.4 GHz / 2 cycles per wave64 instruction)"
+    mb = re.search(r"== SQ cycles per step_kernel dispatch.*?: (.*)", txt)
+    if mb:
+        toks = mb.group(1).split()
+        prof["sq_counters_raw"] = {toks[i]: float(toks[i + 1]) for i in range(0, len(toks) - 1, 2)}
+    out.append({**prof, "kind": kind, "envs": envs, "layout": layout, "auto_reset": ar, "substeps": sub, "workload": workload,
+                "env_steps_per_launch": horizon, "FETCH_SIZE_KB_raw": fetch,
+                "WRITE_SIZE_KB": write, "bytes_per_launch": b, "bytes_per_env_step": round(b / envs / horizon, 1),
                 "source": f"profiles/{RND}/{fn}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes "
                           "(tools/profile.sh); FETCH_SIZE doubled (gfx950 tallies 128-B requests as 64 B: the 256 MiB "
                           f"calibration clone reads {cf:.3f}x), WRITE_SIZE exact ({cw:.3f}x)"})

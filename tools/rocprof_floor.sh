@@ -8,10 +8,10 @@ cd /tmp && export TMPDIR=/tmp
 run() {  # tag lib bench-args...
   tag=$1; lib=$2; shift 2
   echo "== $tag: bench.py $* (QR_LIB=$lib)"
-  un=$(QR_LIB=$ROOT/gym_rotor_amd/$lib python3 "$ROOT/bench.py" --cpu-seconds 0 --extras 0 "$@" 2>/dev/null | grep -o '"ms_per_step": [0-9.e-]*')
+  un=$(QR_LIB=$ROOT/build/evidence/$lib python3 "$ROOT/bench.py" --cpu-seconds 0 --extras 0 "$@" 2>/dev/null | grep -o '"ms_per_step": [0-9.e-]*')
   echo "   un-profiled            $un"
   rm -rf /tmp/floor_$tag
-  pr=$(QR_LIB=$ROOT/gym_rotor_amd/$lib rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/floor_$tag -- python3 "$ROOT/bench.py" --cpu-seconds 0 --extras 0 "$@" 2>/dev/null | grep -o '"ms_per_step": [0-9.e-]*')
+  pr=$(QR_LIB=$ROOT/build/evidence/$lib rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/floor_$tag -- python3 "$ROOT/bench.py" --cpu-seconds 0 --extras 0 "$@" 2>/dev/null | grep -o '"ms_per_step": [0-9.e-]*')
   echo "   under rocprofv3        $pr"
   python3 "$ROOT/tools/trace_periods.py" /tmp/floor_$tag | sed 's/^/   /'
   rm -rf /tmp/floor_$tag

@@ -65,3 +65,24 @@ for sub, ctr in (("calib_fetch", "FETCH_SIZE"), ("calib_write", "WRITE_SIZE")):
         big = [float(r["Counter_Value"]) for r in rows if float(r["Counter_Value"]) > 50000]
         if big:
             print(f"== calibration {ctr}: 256 MiB torch clone -> {statistics.mean(big):.0f} KB per dispatch (expected 262144 KB; ratio {statistics.mean(big) / 262144:.3f})")
+
+# instruction issue (tools/profile.sh passes 4a / 4b): per step_kernel dispatch, mean over the second half of the dispatches
+def pmc_all(sub):
+    f = find(sub, "*counter_collection.csv")
+    acc = {}
+    if f:
+        for r in csv.DictReader(open(f)):
+            if "step_kernel" in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    return {k: statistics.mean(v[len(v) // 2:]) for k, v in acc.items()}
+
+
+m = pmc_all("insts")
+if m:
+    w = m.get("SQ_WAVES", 0) or 1
+    print(f"== instructions per step_kernel dispatch: waves {w:.0f}; per wave VALU {m.get('SQ_INSTS_VALU', 0) / w:.1f} SALU {m.get('SQ_INSTS_SALU', 0) / w:.1f} "
+          f"LDS {m.get('SQ_INSTS_LDS', 0) / w:.1f} SMEM {m.get('SQ_INSTS_SMEM', 0) / w:.1f}; per dispatch VALU {m.get('SQ_INSTS_VALU', 0):.0f}")
+b = pmc_all("busy")
+if b:
+    print("== SQ cycles per step_kernel dispatch (raw counter values, summed over the chip as rocprofv3 reports them): "
+          + " ".join(f"{k} {v:.0f}" for k, v in sorted(b.items())))
