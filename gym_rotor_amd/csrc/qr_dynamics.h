@@ -366,6 +366,142 @@ __device__ __forceinline__ void integrate(float (&x)[3], float (&v)[3], double (
 }
 
 // ------------------------------------------------------------------------------------
+// The same step with the quaternion stages in DELTA FORM — the arithmetic of the launches that step envs on WITHOUT
+// in-launch resets (the rate-adaptive instantiations, ADAPT), where a free run far beyond termination amplifies the
+// float32 stage noise of `integrate` (~1e-9 per step) through the Decoupled action map's feedback ~100x over 900 steps
+// (6.8e-6 after 1000 steps, against 1.0e-6 for all-float64 stages):
+//     dq = h k1 + h/6 (2 (k2 - k1) + 2 (k3 - k1) + (k4 - k1)),      k1 = q (0, W/2) in FLOAT64,
+//     k_i - k1 = qdot(q, w_i - w_1) + qdot(qt_i - q, w_i)           in float32 (qdot is bilinear),
+// i.e. what is large (k1 ~ |W|/2) is exact, and float32 only ever rounds quantities that are O(h |W|^2): the stage
+// noise drops ~10x and the free run lands on the truncation floor of RK4 itself (tools/numerics_delta.py: Decoupled,
+// 256 envs x 1000 steps: 7.5e-6 -> 1.3e-6 = all-float64 stages; applied only beyond termination it changes nothing —
+// the perturbations that the feedback amplifies are planted IN regime).  +12 f64 and ~+40 f32 instructions per
+// substep: not in the launches with in-launch resets, whose envs never leave the regime (1.0-1.5e-6 there).
+// Same W chain, same thrust sums, same final x / v update as `integrate`.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void integrate_delta(float (&x)[3], float (&v)[3], double (&q)[4], double (&W)[3], const Dyn<double>& p, int nsub,
+                                                double h) {
+  const float hf = (float)h, h2f = 0.5f * hf, h6f = hf * (1.0f / 6.0f);
+  const double h2 = 0.5 * h, h6 = h * (1.0 / 6.0);
+  double a3 = p.A1 * W[2];
+  const double da = p.A1 * p.U3 * h2;
+  double W3h = 0.5 * W[2];                       // W3 / 2 at the substep's start, float64 (k1)
+  const double dW3h = 0.5 * p.U3 * h;           // its advance per substep
+  const float dw3 = (float)(0.5 * p.U3 * h2);
+  const float u1 = (float)(0.5 * p.U1), u2 = (float)(0.5 * p.U2);
+  double W1 = W[0], W2 = W[1];
+  float g1[3] = {0.f, 0.f, 0.f}, g23[3] = {0.f, 0.f, 0.f}, g4[3] = {0.f, 0.f, 0.f}, xx[3] = {0.f, 0.f, 0.f};
+#define QR_THRUST(G, Qw, Qx, Qy, Qz)                            \
+  G[0] = fmaf(Qx, Qz, fmaf(Qw, Qy, G[0]));                      \
+  G[1] = fmaf(Qy, Qz, fmaf(-Qw, Qx, G[1]));                     \
+  G[2] = fmaf(Qx, Qx, fmaf(Qy, Qy, G[2]));
+#define QR_QDOT(K, Q, A, B, C)                                  \
+  K[0] = -fmaf(Q[1], A, fmaf(Q[2], B, Q[3] * C));               \
+  K[1] = fmaf(Q[0], A, fmaf(Q[2], C, -Q[3] * B));               \
+  K[2] = fmaf(Q[0], B, fmaf(Q[3], A, -Q[1] * C));               \
+  K[3] = fmaf(Q[0], C, fmaf(Q[1], B, -Q[2] * A));
+#define QR_QDOT_ACC(K, Q, A, B, C)                              \
+  K[0] = fmaf(-Q[1], A, fmaf(-Q[2], B, fmaf(-Q[3], C, K[0])));  \
+  K[1] = fmaf(Q[0], A, fmaf(Q[2], C, fmaf(-Q[3], B, K[1])));    \
+  K[2] = fmaf(Q[0], B, fmaf(Q[3], A, fmaf(-Q[1], C, K[2])));    \
+  K[3] = fmaf(Q[0], C, fmaf(Q[1], B, fmaf(-Q[2], A, K[3])));
+  for (int s = 0; s < nsub; ++s) {
+    if (s > 0) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) xx[j] += fmaf(2.0f, g23[j], g1[j] + g4[j]);
+    }
+    // ---- k1 = q (0, W/2) in float64, and the float32 copies the stages start from ----
+    float qs[4], k1f[4];
+    {
+      const double hw1 = 0.5 * W1, hw2 = 0.5 * W2;
+      const double k0 = -fma(q[1], hw1, fma(q[2], hw2, q[3] * W3h));
+      const double k1 = fma(q[0], hw1, fma(q[2], W3h, -(q[3] * hw2)));
+      const double k2 = fma(q[0], hw2, fma(q[3], hw1, -(q[1] * W3h)));
+      const double k3 = fma(q[0], W3h, fma(q[1], hw2, -(q[2] * hw1)));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) qs[j] = (float)q[j];
+      k1f[0] = (float)k0; k1f[1] = (float)k1; k1f[2] = (float)k2; k1f[3] = (float)k3;
+      q[0] = fma(h, k0, q[0]); q[1] = fma(h, k1, q[1]); q[2] = fma(h, k2, q[2]); q[3] = fma(h, k3, q[3]);  // h k1: exact part of the increment
+    }
+    const float w1 = (float)(0.5 * W1), w2 = (float)(0.5 * W2), w3 = (float)W3h;
+    const float a3f = (float)a3, daf = (float)da;
+    // ---- W1, W2 in float64 (running sums: nothing of the chain stays live) ----
+    {
+      const double am = a3 + da, a1 = am + da;
+      double ka = fma(a3, W2, p.U1), kb = fma(-a3, W1, p.U2);
+      double sa = ka, sb = kb;
+      double s1 = fma(h2, ka, W1), s2 = fma(h2, kb, W2);
+      ka = fma(am, s2, p.U1); kb = fma(-am, s1, p.U2);
+      sa = fma(2.0, ka, sa); sb = fma(2.0, kb, sb);
+      s1 = fma(h2, ka, W1); s2 = fma(h2, kb, W2);
+      ka = fma(am, s2, p.U1); kb = fma(-am, s1, p.U2);
+      sa = fma(2.0, ka, sa); sb = fma(2.0, kb, sb);
+      s1 = fma(h, ka, W1); s2 = fma(h, kb, W2);
+      ka = fma(a1, s2, p.U1); kb = fma(-a1, s1, p.U2);
+      W1 = fma(h6, sa + ka, W1); W2 = fma(h6, sb + kb, W2);
+      a3 = a1; W3h += dW3h;
+    }
+    // ---- float32 stage rates (half units) and their DIFFERENCES from the start rate ----
+    const float bm = a3f + daf, b1 = bm + daf;
+    const float zm = w3 + dw3, z1 = zm + dw3;
+    float dq_[4], d[4], acc[4], qt[4];
+    // stage 1: thrust direction at the substep's start
+    QR_THRUST(g1, qs[0], qs[1], qs[2], qs[3])
+    float ka = fmaf(a3f, w2, u1), kb = fmaf(-a3f, w1, u2);
+    float dA = h2f * ka, dB = h2f * kb;                 // (w_2 - w_1): exactly the increment the float32 rate track takes
+    float t1 = w1 + dA, t2 = w2 + dB;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dq_[j] = h2f * k1f[j]; qt[j] = qs[j] + dq_[j]; }
+    // stage 2
+    QR_THRUST(g23, qt[0], qt[1], qt[2], qt[3])
+    QR_QDOT(d, qs, dA, dB, dw3)
+    QR_QDOT_ACC(d, dq_, t1, t2, zm)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[j] = 2.0f * d[j]; dq_[j] = h2f * (k1f[j] + d[j]); qt[j] = qs[j] + dq_[j]; }
+    ka = fmaf(bm, t2, u1); kb = fmaf(-bm, t1, u2);
+    dA = h2f * ka; dB = h2f * kb;
+    t1 = w1 + dA; t2 = w2 + dB;
+    // stage 3
+    QR_THRUST(g23, qt[0], qt[1], qt[2], qt[3])
+    QR_QDOT(d, qs, dA, dB, dw3)
+    QR_QDOT_ACC(d, dq_, t1, t2, zm)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[j] = fmaf(2.0f, d[j], acc[j]); dq_[j] = hf * (k1f[j] + d[j]); qt[j] = qs[j] + dq_[j]; }
+    ka = fmaf(bm, t2, u1); kb = fmaf(-bm, t1, u2);
+    dA = hf * ka; dB = hf * kb;
+    t1 = w1 + dA; t2 = w2 + dB;
+    // stage 4
+    QR_THRUST(g4, qt[0], qt[1], qt[2], qt[3])
+    QR_QDOT(d, qs, dA, dB, 2.0f * dw3)
+    QR_QDOT_ACC(d, dq_, t1, t2, z1)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] += (double)(h6f * (acc[j] + d[j]));   // + h/6 (2 d2 + 2 d3 + d4): the small part, exactly
+    (void)b1;
+  }
+#undef QR_THRUST
+#undef QR_QDOT
+#undef QR_QDOT_ACC
+  const float cf = (float)p.c, dtf = hf * (float)nsub, gc = (float)(p.g - p.c);
+  const float hc3 = hf * cf * (1.0f / 3.0f), hhc3 = hf * hc3;
+  float G[3], X2[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { G[j] = fmaf(2.0f, g23[j], g1[j] + g4[j]); X2[j] = xx[j] + (g1[j] + g23[j]); }
+  x[0] = fmaf(-hhc3, X2[0], fmaf(dtf, v[0], x[0]));
+  x[1] = fmaf(-hhc3, X2[1], fmaf(dtf, v[1], x[1]));
+  x[2] = fmaf(hhc3, X2[2], fmaf(0.5f * dtf * dtf, gc, fmaf(dtf, v[2], x[2])));
+  v[0] = fmaf(-hc3, G[0], v[0]);
+  v[1] = fmaf(-hc3, G[1], v[1]);
+  v[2] = fmaf(hc3, G[2], fmaf(dtf, gc, v[2]));
+  W[0] = W1; W[1] = W2;
+  W[2] = fma(p.U3, h * (double)nsub, W[2]);
+}
+// (uniform layouts: plain RK4 in T already — nothing to refine)
+template <typename T>
+__device__ __forceinline__ void integrate_delta(T (&x)[3], T (&v)[3], T (&q)[4], T (&W)[3], const Dyn<T>& p, int nsub, T h) {
+  integrate(x, v, q, W, p, nsub, h);
+}
+
+// ------------------------------------------------------------------------------------
 // LDS transposes between lane-per-env registers and AoS rows in global memory.
 // The workgroup's rows [first, first+rows) x D floats are contiguous in global memory.
 // ------------------------------------------------------------------------------------

@@ -42,6 +42,7 @@
 //   this file      step / rollout kernel, auxiliary kernels, host launchers and the C-ABI
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -89,6 +90,18 @@ __device__ unsigned long long* g_stamps = nullptr;
 #define QR_HSTAMP(k, dep) do { } while (0)
 #endif
 
+#ifndef QR_DEV_COEFFS
+// 1 (experiment build, profiles/r03/ab_dev_coeffs.txt): the step kernel reads its coefficient block from a device-resident copy
+// (a __device__ global the launcher refreshes when a call's coefficients differ from the last upload) instead of from the
+// kernarg segment.  Not the product path: the upload is a synchronous copy outside any stream order.
+#define QR_DEV_COEFFS 0
+#endif
+#if QR_DEV_COEFFS
+__device__ __attribute__((aligned(64))) Coeffs g_coeffs;
+#endif
+#ifndef QR_DELTA_STAGES
+#define QR_DELTA_STAGES 1  // 0: the rate-adaptive instantiations use the plain stage arithmetic (A/B: profiles/r03/ab_delta_stages.txt)
+#endif
 #ifndef QR_EARLY_STORE_GRID
 #define QR_EARLY_STORE_GRID 4096  // grids up to this many waves store a resetting wave's settled lanes before it samples
 #endif
@@ -256,7 +269,11 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   const bool active = tid < rows;
   // lanes past a ragged tail read the tail's last env (valid memory, finite numbers) and store nothing
   const unsigned ll = min(lane, (unsigned)(rows - 1));
+#if QR_DEV_COEFFS && defined(__HIP_DEVICE_COMPILE__)
+  const Coeffs& c = g_coeffs;
+#else
   const Coeffs& c = ka.c;
+#endif
 #if QR_ABLATE == 1  // measurement build: launch floor only
   return;
 #endif
@@ -403,6 +420,15 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   // first instructions, has them in the scalar cache by then.  (The words are never used; their registers stay
   // reserved until a point behind the first scalar wait, see below.)
   uint32_t ctouch[6];  // ([5]: the line of the per-call integers — substeps is wanted at the first RK4 stage)
+#if QR_DEV_COEFFS
+  {
+    const char* cb = reinterpret_cast<const char*>(&g_coeffs);
+    asm volatile("s_load_dword %0, %6, 0x0\n\ts_load_dword %1, %6, 0x40\n\ts_load_dword %2, %6, 0x80\n\t"
+                 "s_load_dword %3, %6, 0xc0\n\ts_load_dword %4, %6, 0x100\n\ts_load_dword %5, %7, %8"
+                 : "=&s"(ctouch[0]), "=&s"(ctouch[1]), "=&s"(ctouch[2]), "=&s"(ctouch[3]), "=&s"(ctouch[4]), "=&s"(ctouch[5])
+                 : "s"(cb), "s"(__builtin_amdgcn_kernarg_segment_ptr()), "i"(kArgsOffset + (int)offsetof(Args, substeps)));
+  }
+#else
   {
     constexpr int kC = kArgsOffset + (int)offsetof(Args, c);
     asm volatile("s_load_dword %0, %6, %7\n\ts_load_dword %1, %6, %8\n\ts_load_dword %2, %6, %9\n\t"
@@ -411,6 +437,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
                  : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "i"(kC), "i"(kC + 64), "i"(kC + 128), "i"(kC + 192), "i"(kC + 256),
                    "i"(kArgsOffset + (int)offsetof(Args, substeps)));
   }
+#endif
 #endif
 
   // ---- issue the loads of the env's working set (SoA, lane-contiguous) and of its action row ----
@@ -640,9 +667,21 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     // and in regime — |W| < 2 pi < w_adapt — this costs one ballot): every lane takes at least
     // the count its own rate asks for.
     if constexpr (ADAPT) {
+      // (kDelta) The launches that step envs on without in-launch resets — the only ones in which an env can leave the
+      // regime — form the quaternion stages in delta form (qr_dynamics.h: integrate_delta): their free run lands on RK4's
+      // truncation floor instead of 7x above it.  qr_rollout_actor keeps the plain stages (its kernel is at its register limit).
+      constexpr bool kDelta = QR_DELTA_STAGES && !POLICY;
       const T wmax = fmax(fmax(fabs(w.W[0]), fabs(w.W[1])), fabs(w.W[2]));
       const T need = wmax * T(c.inv_w_adapt);
-      if (__ballot(need > T(1)) == 0) {  // in regime: exactly the plain kernel's code path (one ballot)
+      if constexpr (kDelta) {
+        int mul = 1;
+        if (__ballot(need > T(1)) != 0) {  // (in regime: one ballot)
+          mul = 2;
+          while (mul < 16 && __ballot(need > T(mul))) ++mul;
+        }
+        const int nsub = ka.substeps * mul;
+        integrate_delta(w.x, w.v, w.q, w.W, dyn, nsub, T(c.dt) * recip(T(nsub)));
+      } else if (__ballot(need > T(1)) == 0) {  // in regime: exactly the plain kernel's code path (one ballot)
         const int nsub = ka.substeps;
         integrate(w.x, w.v, w.q, w.W, dyn, nsub, T(c.dt) * recip(T(nsub)));
       } else {
@@ -1421,6 +1460,16 @@ static int do_rollout(const QrEnv* env, const float* action, const QrPolicyRollo
   a.reward = out->reward; a.reward_raw = out->reward_raw; a.done = out->done; a.truncated = out->truncated;
   a.n_steps = n_steps; a.substeps = substeps;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#if QR_DEV_COEFFS
+  {
+    static Coeffs last;
+    static bool have = false;
+    if (!have || memcmp(&last, &a.c, sizeof(Coeffs)) != 0) {
+      if (hipMemcpyToSymbol(HIP_SYMBOL(g_coeffs), &a.c, sizeof(Coeffs)) != hipSuccess) return QR_E_NULL;
+      last = a.c; have = true;
+    }
+  }
+#endif
   int rc = 0;
   QR_DISPATCH_LAYOUT(env->layout, (rc = launch_step<XV, QW>(a, env->kind, s)));
   return rc;
