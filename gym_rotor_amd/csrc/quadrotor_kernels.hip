@@ -321,6 +321,11 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       const uint32_t hflags = ka.flags;
       const uint64_t hseed = ka.seed;
       const uint64_t hgfirst = (uint64_t)(ka.env_offset + first);
+      QR_HSTAMP(5, (float)hflags + (float)hseed + (float)hgfirst);   // (diagnostic builds) kernarg scalars back
+      QR_HSTAMP(6, (float)rc);                                       // the tile counter (global memory) back
+      // (Measured and NOT adopted, profiles/r03/ab_helper_touch.txt: requesting this wave's kernarg lines with dummy loads in its
+      // first instructions, like the stepping wave does — 4.148 against 4.151 us per launch; the pool is in LDS ~0.7 us before
+      // the stepping wave asks for it either way.)
       const bool heval = (hflags & QR_FLAG_EVAL_RESET) != 0;
       PoolRole hrole;
       pool_role(hrole, !heval && !(hflags & QR_FLAG_NO_UDM) && params != nullptr, heval, c);

@@ -117,7 +117,7 @@ def test_final_observation_and_bootstrap_values(kind):
     N, T = 2048, 48
     kw = dict(device="cuda", seed=4, max_episode_steps=20, obs_rows=True)
     env = QuadVecEnv(kind, N, auto_reset=True, **kw)
-    ref = QuadVecEnv(kind, N, auto_reset=False, **kw)
+    ref = QuadVecEnv(kind, N, auto_reset=False, w_adapt=0.0, **kw)   # (w_adapt = 0: the plain instantiation, the auto-reset launch's arithmetic)
     env.reset("train"); ref.reset("train")
     st = RolloutStorage(env, T)
     assert st.final_obs is not None

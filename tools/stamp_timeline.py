@@ -80,9 +80,10 @@ for k, name in enumerate(out["names"]):
                  "segment_median_all_reset": [float(np.median(seg)), float(np.median(segr))]}
     print(f"{name:18s} {q[0]:6.2f} {q[1]:6.2f} {q[2]:6.2f} {q[3]:6.2f} {q[4]:6.2f}   | {np.median(r):6.2f} {r.max():6.2f}               | {np.median(seg):6.2f} / {np.median(segr):6.2f}")
 if sth[:, 0].any():  # helper waves stamped: entry, scalars read, pool in LDS, released from the barrier, reward stored
-    th = (sth[:, :5] - st[:, 0].min()) * 0.01
+    th = (sth[:, :7] - st[:, 0].min()) * 0.01
     out["helper"] = {}
-    for k, name in enumerate(["helper entry", "helper scalars read", "helper pool in LDS", "helper past barrier 1", "helper reward stored"]):
+    for k, name in enumerate(["helper entry", "helper role constants formed", "helper pool in LDS", "helper past barrier 1", "helper reward stored",
+                              "helper kernarg scalars back", "helper tile counter back"]):
         q = np.percentile(th[:, k], [0, 10, 50, 90, 100])
         out["helper"][name] = [float(x) for x in q]
         print(f"{name:22s} {q[0]:6.2f} {q[1]:6.2f} {q[2]:6.2f} {q[3]:6.2f} {q[4]:6.2f}")
