@@ -194,34 +194,9 @@ __device__ __forceinline__ void integrate(T (&x)[3], T (&v)[3], T (&q)[4], T (&W
 // substeps R 9e-7 — the bar is 1e-5.  On gfx950 an f32 VALU instruction issues at up to twice
 // the f64 rate once two waves share a SIMD, and the float32 stage code needs half the registers.
 // ------------------------------------------------------------------------------------
-#ifndef QR_PK_QCHAIN
-#define QR_PK_QCHAIN 0  // 1: quaternion stages on packed-float32 instructions (v_pk_*_f32); 0: the same arithmetic, scalar.
-// Measured equal within noise on MI355X at every size (profiles/r02/ab_pk_qchain.json: 5.20 vs 5.20 us at 65 536 envs,
-// 37.1 vs 37.5 us at 1 M, 11.4 vs 11.3 us at 131 072 x 10 substeps): default = the plain form
-#endif
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-// q' = q (0, W/2) on register pairs Q0 = (w, x), Q1 = (y, z), WA = (W1, W2)/2, W3/2 in half SEL of Z: six
-// v_pk_*_f32 — every swizzle and sign is an operand modifier (op_sel / neg) of the packed instruction.
-//   (k_w, k_x) = (-x, w) W1 + (-y, -z) W2 + (-z, y) W3        (k_y, k_z) = (z, -y) W1 + (w, x) W2 + (-x, w) W3
-// (hipcc's own packing of the scalar form inserts v_mov / v_xor for the swizzles and negations.)
-template <int SEL>
-__device__ __forceinline__ void qdot_pk(f2& K0, f2& K1, const f2 Q0, const f2 Q1, const f2 WA, const f2 Z) {
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[1,0]" : "=v"(K0) : "v"(Q0), "v"(WA));
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(K1) : "v"(Q1), "v"(WA));
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(K0) : "v"(Q1), "v"(WA));
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(K1) : "v"(Q0), "v"(WA));
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,%3,0] op_sel_hi:[0,%3,1] neg_lo:[1,0,0]" : "+v"(K0) : "v"(Q1), "v"(Z), "n"(SEL));
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,%3,0] op_sel_hi:[0,%3,1] neg_lo:[1,0,0]" : "+v"(K1) : "v"(Q0), "v"(Z), "n"(SEL));
-}
-// (W1, W2)/2 ' = (a W2/2 + U1/2, -a W1/2 + U2/2), a = A1 W3(t) in half SEL of Bp
-template <int SEL>
-__device__ __forceinline__ f2 wdot_pk(const f2 WA, const f2 Bp, const f2 U) {
-  f2 K;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,%4,0] op_sel_hi:[0,%4,1] neg_hi:[1,0,0]" : "=v"(K) : "v"(WA), "v"(Bp), "v"(U), "n"(SEL));
-  return K;
-}
-
+// (Measured and NOT adopted, profiles/r02/ab_quad_builds.txt column q_pk: the quaternion stages on v_pk_fma_f32 / v_pk_mul_f32 with
+// op_sel / neg swizzles, six packed instructions per derivative — 4.45-4.56 against 4.40-4.47 us per launch at 65 536 envs,
+// 33.7-33.8 against 33.0-33.2 at 1 M: the code is gone, the record stays.)
 __device__ __forceinline__ void integrate(float (&x)[3], float (&v)[3], double (&q)[4], double (&W)[3], const Dyn<double>& p, int nsub,
                                           double h) {
   const float hf = (float)h, h2f = 0.5f * hf, h6f = hf * (1.0f / 6.0f);
@@ -239,11 +214,6 @@ __device__ __forceinline__ void integrate(float (&x)[3], float (&v)[3], double (
   G[0] = fmaf(Qx, Qz, fmaf(Qw, Qy, G[0]));                      \
   G[1] = fmaf(Qy, Qz, fmaf(-Qw, Qx, G[1]));                     \
   G[2] = fmaf(Qx, Qx, fmaf(Qy, Qy, G[2]));
-#if QR_PK_QCHAIN
-  f2 QS0 = {(float)q[0], (float)q[1]}, QS1 = {(float)q[2], (float)q[3]};
-  f2 WA = {0.5f * (float)W[0], 0.5f * (float)W[1]};
-  const f2 U = {u1, u2}, H2 = {h2f, h2f}, H1 = {hf, hf}, H6 = {h6f, h6f}, TWO = {2.0f, 2.0f};
-#else
   float qs[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) qs[j] = (float)q[j];
@@ -253,7 +223,6 @@ __device__ __forceinline__ void integrate(float (&x)[3], float (&v)[3], double (
   K[1] = fmaf(Q[0], A, fmaf(Q[2], C, -Q[3] * B));               \
   K[2] = fmaf(Q[0], B, fmaf(Q[3], A, -Q[1] * C));               \
   K[3] = fmaf(Q[0], C, fmaf(Q[1], B, -Q[2] * A));
-#endif
   for (int s = 0; s < nsub; ++s) {
     if (s > 0) {  // prefix sums of the substeps' thrust sums: the double integral for x
 #pragma unroll
@@ -271,37 +240,6 @@ __device__ __forceinline__ void integrate(float (&x)[3], float (&v)[3], double (
     // ---- stage rates in float32 (half units) for the quaternion ----
     const float b0 = a3f, bm = a3f + daf, b1 = bm + daf;
     const float z0 = w3, zm = w3 + dw3, z1 = zm + dw3;
-#if QR_PK_QCHAIN
-    const f2 B01 = {b0, bm}, B1 = {b1, b1}, Z01 = {z0, zm}, Z1 = {z1, z1};
-    f2 K0, K1, A0, A1v, QT0, QT1, KW, WT;
-    // stage 1
-    qdot_pk<0>(K0, K1, QS0, QS1, WA, Z01);
-    QR_THRUST(g1, QS0.x, QS0.y, QS1.x, QS1.y)
-    KW = wdot_pk<0>(WA, B01, U);
-    WT = KW * H2 + WA;
-    A0 = K0; A1v = K1;
-    QT0 = K0 * H2 + QS0; QT1 = K1 * H2 + QS1;
-    // stage 2
-    qdot_pk<1>(K0, K1, QT0, QT1, WT, Z01);
-    QR_THRUST(g23, QT0.x, QT0.y, QT1.x, QT1.y)
-    KW = wdot_pk<1>(WT, B01, U);
-    WT = KW * H2 + WA;
-    A0 = K0 * TWO + A0; A1v = K1 * TWO + A1v;
-    QT0 = K0 * H2 + QS0; QT1 = K1 * H2 + QS1;
-    // stage 3
-    qdot_pk<1>(K0, K1, QT0, QT1, WT, Z01);
-    QR_THRUST(g23, QT0.x, QT0.y, QT1.x, QT1.y)
-    KW = wdot_pk<1>(WT, B01, U);
-    WT = KW * H1 + WA;
-    A0 = K0 * TWO + A0; A1v = K1 * TWO + A1v;
-    QT0 = K0 * H1 + QS0; QT1 = K1 * H1 + QS1;
-    // stage 4
-    qdot_pk<0>(K0, K1, QT0, QT1, WT, Z1);
-    QR_THRUST(g4, QT0.x, QT0.y, QT1.x, QT1.y)
-    const f2 D0 = (A0 + K0) * H6, D1 = (A1v + K1) * H6;
-    q[0] += (double)D0.x; q[1] += (double)D0.y; q[2] += (double)D1.x; q[3] += (double)D1.y;  // the float64 state takes the increment exactly
-    QS0 += D0; QS1 += D1;  // float32 track for the next substep's stages (re-synchronised every env-step)
-#else
     float kq[4], acc[4], qt[4];
     // stage 1
     QR_QDOT(kq, qs, w1, w2, z0)
@@ -333,15 +271,10 @@ __device__ __forceinline__ void integrate(float (&x)[3], float (&v)[3], double (
       q[j] += (double)dq;   // the float64 state takes the increment exactly
       qs[j] += dq;          // float32 track for the next substep's stages (re-synchronised every env-step)
     }
-#endif
     W1 = fma(h6, fma(2.0, k2a + k3a, k1a + k4a), W1);
     W2 = fma(h6, fma(2.0, k2b + k3b, k1b + k4b), W2);
     a3 = a1; a3f = b1; w3 = z1;
-#if QR_PK_QCHAIN
-    WA.x = 0.5f * (float)W1; WA.y = 0.5f * (float)W2;
-#else
     w1 = 0.5f * (float)W1; w2 = 0.5f * (float)W2;
-#endif
   }
 #undef QR_THRUST
 #undef QR_QDOT

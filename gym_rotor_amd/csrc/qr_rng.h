@@ -245,42 +245,6 @@ __device__ __forceinline__ void make_pool(ResetPool<T>& p, const PoolRole& role,
   if (b == 4) p.v[3] = __builtin_bit_cast(float, ctr[3]);
 }
 
-__device__ __forceinline__ float bperm(int addr4, float v) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr4, __builtin_bit_cast(int, v))); }
-__device__ __forceinline__ double bperm(int addr4, double v) {
-  const uint64_t u = __builtin_bit_cast(uint64_t, v);
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr4, (int)(uint32_t)u);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr4, (int)(uint32_t)(u >> 32));
-  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
-}
-
-// Lanes with take == true copy slot `slot` of the pool into their working set.  Executed by the whole wave.
-template <typename T, typename X, bool TRAJ>
-__device__ __forceinline__ void take_from_pool(const ResetPool<T>& p, bool take, int slot, Work<T, X>& w, uint32_t& r19) {
-  const int a0 = (take ? 5 * slot : 0) << 2, a1 = a0 + 4, a2 = a0 + 8, a3 = a0 + 12, a4 = a0 + 16;
-  float prm[6], x[3], v[3], W[3];
-  T q[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) prm[j] = bperm(a0, p.v[j]);
-  prm[4] = bperm(a1, p.v[0]); prm[5] = bperm(a1, p.v[1]);
-  x[0] = bperm(a1, p.v[2]); x[1] = bperm(a1, p.v[3]); x[2] = bperm(a2, p.v[0]);
-#pragma unroll
-  for (int j = 0; j < 3; ++j) { v[j] = bperm(a2, p.v[1 + j]); W[j] = bperm(a3, p.v[j]); }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) q[j] = bperm(a4, p.q[j]);
-  float rb = 0.0f;
-  if constexpr (TRAJ) rb = bperm(a4, p.v[3]);
-  __builtin_amdgcn_sched_barrier(0);  // all cross-lane reads are in flight before the first select waits for one
-  if (take) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { w.x[j] = X(x[j]); w.v[j] = X(v[j]); w.W[j] = T(W[j]); }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w.q[j] = q[j];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) w.prm[j] = prm[j];
-    if constexpr (TRAJ) r19 = __builtin_bit_cast(uint32_t, rb);
-  }
-}
-
 // The pool as the helper wave of a workgroup leaves it in LDS for the stepping wave (HELP instantiation of the step
 // kernel): 16 bytes of role values per lane, the quaternion of a slot from its role-4 lane.
 template <typename T>
@@ -300,7 +264,9 @@ __device__ __forceinline__ void pool_to_lds(PoolLds<T>& s, const ResetPool<T>& p
   }
 }
 
-// take_from_pool with the pool in LDS: the same values into the same places.
+// Lanes with take == true copy slot `slot` of the pool (in LDS) into their working set.  Executed by the whole wave.  (Through
+// LDS — six 16-byte reads per taking lane — rather than 23 ds_bpermute with all their results in flight at once: 128 instead of
+// 142 VGPRs for the plain Quad-v0 kernel, four waves per SIMD instead of three)
 template <typename T, typename X, bool TRAJ>
 __device__ __forceinline__ void take_from_lds(const PoolLds<T>& s, bool take, int slot, Work<T, X>& w, uint32_t& r19) {
   const int k = take ? slot : 0;

@@ -140,9 +140,8 @@ __device__ __forceinline__ float interp01(float r, float rmin, float inv_nrmin) 
 // access is in bounds by construction (lanes past a ragged tail are clamped onto the last env, stores are guarded), and
 // an exact byte count would cost each of the step's seven descriptors half a dozen scalar instructions.
 typedef int v2i_t __attribute__((ext_vector_type(2)));
-#ifndef QR_LOAD_AUX
-#define QR_LOAD_AUX 0  // cache policy of the SoA loads (experiment knob; measured: profiles/r03/ab_load_policy.txt)
-#endif
+// (Cache-policy bits on the LOADS were measured too, profiles/r03/ab_load_policy.txt: sc0 / sc1 equal, nt +0.5 us per launch at
+// 65 536 envs — non-temporal data does not stay in the Infinity Cache for the next launch.  Plain loads.)
 
 template <typename E>
 struct SoA {
@@ -154,9 +153,9 @@ struct SoA {
   __device__ __forceinline__ unsigned soff(int f, unsigned first) const { return ((unsigned)f * L + first) * (unsigned)sizeof(E); }
   __device__ __forceinline__ E load(int f, unsigned first, unsigned lane) const {
     if constexpr (sizeof(E) == 4) {
-      return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4u, soff(f, first), QR_LOAD_AUX));
+      return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4u, soff(f, first), 0));
     } else {
-      return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane * 8u, soff(f, first), QR_LOAD_AUX));
+      return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane * 8u, soff(f, first), 0));
     }
   }
   template <int AUX = 0>  // cache policy (qr_args.h: QR_HELP_AUX)

@@ -49,11 +49,8 @@
 #include "quadrotor_hip.h"
 
 #ifndef QR_ABLATE
-#define QR_ABLATE 0  // 0 = product build; 1..4 = measurement-only builds (tools/microbench.py)
-#endif
-#ifndef QR_WAVES_PER_SIMD
-#define QR_WAVES_PER_SIMD 2  // 2nd __launch_bounds__ argument of the step kernel (<= 256 VGPRs)
-#endif
+#define QR_ABLATE 0  // 0 = product build; measurement-only builds (Makefile: evidence-libs): 1 = the kernel returns at once
+#endif               // (launch floor), 2 = loads and stores only (no integration)
 
 #include "qr_args.h"
 #include "qr_rng.h"
@@ -64,7 +61,7 @@
 namespace qr {
 
 // byte offset of the Args block in the step kernel's kernarg segment: 6 pointers + 2 x int32 precede it
-constexpr int kArgsOffset = 6 * 8 + 2 * 4;
+[[maybe_unused]] constexpr int kArgsOffset = 6 * 8 + 2 * 4;
 static_assert(alignof(Args) == 8, "Args follows the leading scalar arguments without padding");
 static_assert(sizeof(Coeffs) <= 5 * 64 && offsetof(Args, c) + sizeof(Coeffs) == sizeof(Args), "the step kernel touches the five kernarg lines of the coefficient block (the last field of Args)");
 
@@ -90,47 +87,35 @@ __device__ unsigned long long* g_stamps = nullptr;
 #define QR_HSTAMP(k, dep) do { } while (0)
 #endif
 
-#ifndef QR_DEV_COEFFS
-// 1 (experiment build, profiles/r03/ab_dev_coeffs.txt): the step kernel reads its coefficient block from a device-resident copy
-// (a __device__ global the launcher refreshes when a call's coefficients differ from the last upload) instead of from the
-// kernarg segment.  Not the product path: the upload is a synchronous copy outside any stream order.
-#define QR_DEV_COEFFS 0
-#endif
-#if QR_DEV_COEFFS
-__device__ __attribute__((aligned(64))) Coeffs g_coeffs;
-#endif
 #ifndef QR_DELTA_STAGES
 #define QR_DELTA_STAGES 1  // 0: the rate-adaptive instantiations use the plain stage arithmetic (A/B: profiles/r03/ab_delta_stages.txt)
 #endif
 #ifndef QR_EARLY_STORE_GRID
-#define QR_EARLY_STORE_GRID 4096  // grids up to this many waves store a resetting wave's settled lanes before it samples
+#define QR_EARLY_STORE_GRID 4096  // grids up to this many waves store a resetting wave's settled lanes before it samples (65 536 envs 5.43 / 5.49 us, 1 M 39.4 / 37.4)
 #endif
 #ifndef QR_HELP_POLICY
-#define QR_HELP_POLICY 1  // 0: no helper wave in qr_rollout_actor
+#define QR_HELP_POLICY 1  // 0: no helper wave in qr_rollout_actor (Coupled 65 536 envs, T = 32: 5.37 -> 4.51 us per env-step)
 #endif
 #ifndef QR_TOUCH_COEFFS
-#define QR_TOUCH_COEFFS 1
+#define QR_TOUCH_COEFFS 1       // the stepping wave requests its kernarg lines with its first instructions (Decoupled 5.16 -> 5.02 us)
 #endif
 #ifndef QR_PREFETCH_OUT_PTRS
-#define QR_PREFETCH_OUT_PTRS 1
+#define QR_PREFETCH_OUT_PTRS 1  // plain launches read their output pointers with the first scalar batch (§3.4: Quad-v0 1 M envs 34.7 -> 33.9 us)
 #endif
 #ifndef QR_EARLY_TILE
-#define QR_EARLY_TILE 1
+#define QR_EARLY_TILE 1         // plain wrapper launches write their rows to the LDS tile before the reset block (§3.3: 262 144 envs 19.1 -> 16.5 us)
 #endif
 #ifndef QR_LATE_LOADS
-#define QR_LATE_LOADS 1
+#define QR_LATE_LOADS 1         // ... and request goal / integrators only after the integration (same measurement)
 #endif
 #ifndef QR_LAZY_ROLE
-#define QR_LAZY_ROLE 1
-#endif
-#ifndef QR_TAKE_VIA_LDS
-#define QR_TAKE_VIA_LDS 1
+#define QR_LAZY_ROLE 1          // one-step launches form the pool's role constants in the reset block (§3.3: Quad-v0 142 -> 128 VGPRs)
 #endif
 #ifndef QR_HELP_ROWS
-#define QR_HELP_ROWS 1
+#define QR_HELP_ROWS 1          // the helper wave carries the observation rows out (§3.3 item 3)
 #endif
 #ifndef QR_HELP_REWARD
-#define QR_HELP_REWARD 1
+#define QR_HELP_REWARD 1        // ... and forms Quad-v0's reward (§3.3 item 2; profiles/r03/ab_quad_builds.txt column q_norew)
 #endif
 #ifndef QR_HELPER_GRID
 // Grids up to this many tiles run the one-step kernel with a helper wave per tile (HELP): while every wave of the
@@ -145,15 +130,6 @@ __device__ __attribute__((aligned(64))) Coeffs g_coeffs;
 #ifndef QR_HELPER_GRID_WRAP
 #define QR_HELPER_GRID_WRAP (QR_HELPER_GRID < 2560 ? QR_HELPER_GRID : 4096)  // the wrappers (r03/ab_helper_thresholds.txt: ahead of the plain launch up to 262 144 envs)
 #endif
-#ifndef QR_SPEC_GRID
-// Grids up to this many waves sample their reset pool SPECULATIVELY, right after issuing their loads.  Measured on
-// MI355X at 65 536 envs (profiles/r02/ab_reset_pool.json): the wave's loads are back ~0.7 us after its first
-// instruction but the pool's inputs (seed, flags: kernarg segment) only after ~0.5 us, so of the pool's ~0.6 us
-// only ~0.25 us hide and EVERY wave pays the rest (5.45 us per launch), while sampling on demand costs the ~70 %
-// of the waves that hold a resetting lane ~0.45 us (5.18 us).  Default: on demand (0).
-#define QR_SPEC_GRID 0
-#endif
-
 // ------------------------------------------------------------------------------------
 // Quad-v0 reward and termination (quad.py:274-318) from the post-step state
 // ------------------------------------------------------------------------------------
@@ -228,7 +204,7 @@ struct PostLds {
 // so the helper runs in issue slots that are otherwise empty, and the stepping wave's reset block shrinks from
 // ~230 instructions (Philox, role scaling, attitude, 24 cross-lane reads) to six LDS reads.
 template <int KIND, typename XV, typename QW, int B, bool TRAJ, bool ADAPT, int POLICY = 0, bool SINGLE = false, bool HELP = false>
-__global__ __launch_bounds__(B + (HELP ? 64 : 0), ((HELP && POLICY) ? 2 : (TRAJ || POLICY) ? 1 : QR_WAVES_PER_SIMD))  // (HELP: both waves of every tile resident)
+__global__ __launch_bounds__(B + (HELP ? 64 : 0), ((HELP && POLICY) ? 2 : (TRAJ || POLICY) ? 1 : 2))  // (HELP: both waves of every tile resident)
 void step_kernel(void* pos_vel, void* att_rate, const float* action, float* params, float* integ, int32_t* reset_count,
                  int32_t n_envs, int32_t ld_envs, const Args a_in) {
   // The leading scalar arguments duplicate the fields of Args that the wave's loads depend on: as
@@ -269,11 +245,9 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   const bool active = tid < rows;
   // lanes past a ragged tail read the tail's last env (valid memory, finite numbers) and store nothing
   const unsigned ll = min(lane, (unsigned)(rows - 1));
-#if QR_DEV_COEFFS && defined(__HIP_DEVICE_COMPILE__)
-  const Coeffs& c = g_coeffs;
-#else
+  // (Measured and NOT adopted, profiles/r03/ab_dev_coeffs.txt: the coefficient block in a device-resident global instead of
+  // the kernarg segment — 4.63 against 4.16 us per launch at 65 536 envs.)
   const Coeffs& c = ka.c;
-#endif
 #if QR_ABLATE == 1  // measurement build: launch floor only
   return;
 #endif
@@ -425,15 +399,6 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   // first instructions, has them in the scalar cache by then.  (The words are never used; their registers stay
   // reserved until a point behind the first scalar wait, see below.)
   uint32_t ctouch[6];  // ([5]: the line of the per-call integers — substeps is wanted at the first RK4 stage)
-#if QR_DEV_COEFFS
-  {
-    const char* cb = reinterpret_cast<const char*>(&g_coeffs);
-    asm volatile("s_load_dword %0, %6, 0x0\n\ts_load_dword %1, %6, 0x40\n\ts_load_dword %2, %6, 0x80\n\t"
-                 "s_load_dword %3, %6, 0xc0\n\ts_load_dword %4, %6, 0x100\n\ts_load_dword %5, %7, %8"
-                 : "=&s"(ctouch[0]), "=&s"(ctouch[1]), "=&s"(ctouch[2]), "=&s"(ctouch[3]), "=&s"(ctouch[4]), "=&s"(ctouch[5])
-                 : "s"(cb), "s"(__builtin_amdgcn_kernarg_segment_ptr()), "i"(kArgsOffset + (int)offsetof(Args, substeps)));
-  }
-#else
   {
     constexpr int kC = kArgsOffset + (int)offsetof(Args, c);
     asm volatile("s_load_dword %0, %6, %7\n\ts_load_dword %1, %6, %8\n\ts_load_dword %2, %6, %9\n\t"
@@ -442,7 +407,6 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
                  : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "i"(kC), "i"(kC + 64), "i"(kC + 128), "i"(kC + 192), "i"(kC + 256),
                    "i"(kArgsOffset + (int)offsetof(Args, substeps)));
   }
-#endif
 #endif
 
   // ---- issue the loads of the env's working set (SoA, lane-contiguous) and of its action row ----
@@ -514,15 +478,11 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   }
 
   // ---- in-launch reset: this wave's pool of episode starts (qr_rng.h), sampled while the loads are in flight ----
+  // (Measured and NOT adopted, profiles/r02/ab_quad_builds.txt, columns q_spec / q_nohelp: sampling the pool speculatively in the
+  // same wave right after issuing its loads — 5.86-5.92 against 5.28 us per launch at 65 536 envs: the pool's inputs arrive only
+  // ~0.5 us after the wave's first instruction, so most of its ~0.6 us does not hide under the loads and EVERY wave pays it.)
   ResetPool<T> pool;
-  bool have_pool = false;
-#if QR_ABLATE != 3 && QR_SPEC_GRID > 0
-  if (auto_reset && gridDim.x <= QR_SPEC_GRID) {
-    make_pool<T>(pool, role, seed, gfirst, rcount_s, 0);
-    have_pool = true;
-  }
-#endif
-  QR_STAMP(1, have_pool ? (float)pool.q[0] + pool.v[0] : 0.0f);
+  QR_STAMP(1, 0.0f);
 
   Traj tr;
   const int goal_mode = TRAJ ? ka.goal_mode : QR_GOAL_EXTERNAL;  // wave-uniform
@@ -773,12 +733,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     bool any_done = trunc;
 #pragma unroll
     for (int g = 0; g < NAG; ++g) any_done = any_done | dn[g];
-#if QR_ABLATE == 4  // measurement build: the pool is sampled but no env is ever re-sampled
-    const bool need_reset = false;
-    if (have_pool) asm volatile("" ::"v"(pool.v[0]), "v"(pool.q[3]), "v"(pool.v[3]), "v"(pool.v[2]), "v"(pool.v[1]));
-#else
     const bool need_reset = auto_reset && any_done && active;
-#endif
     const int64_t row0 = (int64_t)t * N + first;
     // ---- reward / done of step t (they belong to the step that just ended, whatever the reset does next) ----
     if (active) {
@@ -856,31 +811,21 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       if (kLazyRole && !HELP) pool_role(role, randomise, eval_reset, c);
       for (int pass = pass0; 12 * pass < total; ++pass) {  // one pass unless more than 12 lanes reset at once
         const int slot = rank - 12 * pass;
-        if (!(have_pool && pass == 0)) make_pool<T>(pool, role, seed, gfirst, rcount_s + (uint32_t)t, pass);
-#if QR_ABLATE != 7
-#if QR_TAKE_VIA_LDS
+        make_pool<T>(pool, role, seed, gfirst, rcount_s + (uint32_t)t, pass);
         // through LDS (six 16-byte reads per taking lane) rather than 23 ds_bpermute with all their results in flight at
         // once: 128 instead of 142 VGPRs for the plain Quad-v0 kernel, i.e. four waves per SIMD instead of three
         pool_to_lds(own_pool, pool);
         tile_sync<B>();
         take_from_lds<T, X, TRAJ>(own_pool, need_reset && slot >= 0 && slot < 12, slot, w, r19);
         tile_sync<B>();
-#else
-        take_from_pool<T, X, TRAJ>(pool, need_reset && slot >= 0 && slot < 12, slot, w, r19);
-#endif
-#endif
       }
       if (need_reset) {
         // (with a params buffer the float32 words about to be stored are also what the following steps of a rollout use,
         // randomised or not: exactly what a one-step launch re-loads)
         w.nominal = a.params == nullptr;
-#if QR_ABLATE != 5
         if (a.params != nullptr) params_dirty = true;
-#endif
         // episode counter (stream id of qr_reset / qr_traj_start): fire-and-forget, nothing here waits for it
-#if QR_ABLATE != 6
         __hip_atomic_fetch_add(ka.episode + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
         steps = 0;
         if constexpr (TRAJ) {  // mark_traj_start + first get_desired of the episode (main.py:227-229)
           float th, tt, wb, b1d_dot[3];
@@ -903,7 +848,6 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       }
     }
     if (!early_store) pack_quat(w.q, qp);
-    have_pool = false;  // the speculative pool belongs to step 0's counter value
     QR_STAMP(5, (float)w.q[0] + (float)w.x[0] + w.prm[0]);
 #ifdef QR_STAMPS
     if (g_stamps != nullptr && lane == 0) g_stamps[(size_t)blockIdx.x * 8 + 7] = rmask;
@@ -1465,16 +1409,6 @@ static int do_rollout(const QrEnv* env, const float* action, const QrPolicyRollo
   a.reward = out->reward; a.reward_raw = out->reward_raw; a.done = out->done; a.truncated = out->truncated;
   a.n_steps = n_steps; a.substeps = substeps;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#if QR_DEV_COEFFS
-  {
-    static Coeffs last;
-    static bool have = false;
-    if (!have || memcmp(&last, &a.c, sizeof(Coeffs)) != 0) {
-      if (hipMemcpyToSymbol(HIP_SYMBOL(g_coeffs), &a.c, sizeof(Coeffs)) != hipSuccess) return QR_E_NULL;
-      last = a.c; have = true;
-    }
-  }
-#endif
   int rc = 0;
   QR_DISPATCH_LAYOUT(env->layout, (rc = launch_step<XV, QW>(a, env->kind, s)));
   return rc;

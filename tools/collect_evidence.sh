@@ -52,6 +52,7 @@ bash tools/rocprof_floor.sh > "$OUT/rocprof_dispatch_floor.txt" 2>&1
 $EV/valu_mb > "$OUT/valu_microbench.json" 2> "$OUT/valu_microbench.err"
 $EV/vmem_mb > "$OUT/vmem_width_microbench.json" 2> "$OUT/vmem_width_microbench.err"
 $EV/first_load_mb > "$OUT/first_load_microbench.json" 2> "$OUT/first_load_microbench.err"
+timeout 120 $EV/resident_mb > "$OUT/resident_pacing_microbench.json" 2> "$OUT/resident_pacing_microbench.err"
 python3 tools/ppo_rollout_bench.py > "$OUT/ppo_rollout.json" 2> "$OUT/ppo_rollout.err"
 fi
 ls "$OUT"
