@@ -599,6 +599,8 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 #if QR_ABLATE == 2  // measurement build: memory traffic only (no integration)
     w.x[0] += X(act[0]);
     pack_quat(w.q, qp);
+    uint8_t* const done_ptr = ka.done;
+    uint8_t* const trunc_ptr = ka.truncated;
 #else
     // ---- goal for this step from the pre-step state (main.py:145-147) ----
     if constexpr (TRAJ) {
