@@ -429,16 +429,17 @@ def main():
                          "traffic_source": (traffic or {}).get("source"),
                          "kernel": kname, "grid": grid, "block": block, "avg_launch_us": launch_us,
                          # the committed rocprofv3 --kernel-trace figure of the same command, for comparison: the tool costs
-                         # ~4.8 us per dispatch by itself (profiles/r02/rocprof_dispatch_floor.txt) and inflates kernels shorter
+                         # ~4.8 us per dispatch by itself (profiles/r03/rocprof_dispatch_floor.txt) and inflates kernels shorter
                          # than ~6 us; both clocks are listed, `achieved` uses this run's HIP events
                          "committed_profile": {k: (traffic or {}).get(k) for k in ("rocprofv3_kernel_mean_us", "rocprofv3_kernel_median_us",
                                                                                      "bench_py_us_per_step_under_rocprofv3", "valu")},
                          "algorithmic_bytes_per_env_step": algo, "layout_bytes_per_env_step": layout,
                          "achieved_layout_GBs": layout * N / (launch_us * 1e-6) / 1e9,
                          "note": "algorithmic bytes = SURVEY.md 8(d) (165 B + 24 B per-env params for Quad-v0); "
-                                 "avg_launch_us = ms_per_step: launch-to-launch time of back-to-back launches (includes the "
-                                 "~1.8 us boundary between dependent kernels); block 128 = a 64-lane stepping wavefront plus a "
-                                 "64-lane helper wavefront per 64-env tile (reset pool, Quad-v0 reward, observation rows)"},
+                                 "avg_launch_us = launch-to-launch time of back-to-back launches (an empty launch: 1.6 us; "
+                                 "x env_steps_per_launch for the rollout workloads, whose algorithmic bytes are the per-step rows plus 1/H of "
+                                 "the working set); block 128 = a 64-lane stepping wavefront plus a 64-lane helper wavefront per 64-env "
+                                 "tile (reset pool, Quad-v0 reward, observation rows); DESIGN.md 3.5, 5"},
         }
         if n_gpus == 1 and a.extras and a.workload == "step":
             # secondary figure: the other reset mode (no reset inside step = the reference's own semantics)
