@@ -442,6 +442,24 @@ def test_bench_gpus_2_without_a_launcher():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("workload,kind,horizon,per_step_bytes", [("rollout", "quad", 50, 21 + 168 / 50), ("rollout_actor", "coupled", 16, 129 + 232 / 16)])
+def test_bench_rollout_workloads(workload, kind, horizon, per_step_bytes):
+    """bench.py --workload rollout | rollout_actor: --steps counts env-steps (whole launches of `horizon`), the line is priced with
+    the fused launch's OWN algorithmic bytes (per-step rows + 1/H of the working set) and one clock feeds every figure."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--kind", kind, "--horizon", str(horizon),
+                        "--steps", str(4 * horizon + 1), "--warmup", "0", "--envs", "8192", "--cpu-seconds", "0", "--extras", "0"],
+                       env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["steps"] == 5 * horizon and d["config"]["env_steps_per_launch"] == horizon and d["config"]["workload_kind"] == workload
+    assert abs(d["roofline"]["algorithmic_bytes_per_env_step"] - per_step_bytes) < 1e-9
+    assert abs(d["roofline"]["avg_launch_us"] - d["ms_per_step"] * 1e3 * horizon) < 1e-9
+    assert abs(d["value"] - 8192 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert abs(d["roofline"]["achieved"] - per_step_bytes * 8192 / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["roofline"]["achieved"]
+
+
+@pytest.mark.gpu
 def test_readme_quick_start_runs():
     text = open(os.path.join(ROOT, "README.md")).read()
     block = re.search(r"```python\n(import torch\nfrom gym_rotor_amd import.*?)```", text, re.S).group(1)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): everything DESIGN.md §5 cites, into gpurun_out/<round>/ (copy to profiles/<round>/).
-#   tools/collect_evidence.sh r03 [profiles|bench|ab|all]
+#   tools/collect_evidence.sh r03 [profiles|bench|ab|tests|all]
 # The measurement-only builds are NOT pushed with the repo (.gpurunignore: build/evidence/): they are built here first.
 set -u
 RND=${1:-r03}; WHAT=${2:-all}
@@ -54,5 +54,10 @@ $EV/vmem_mb > "$OUT/vmem_width_microbench.json" 2> "$OUT/vmem_width_microbench.e
 $EV/first_load_mb > "$OUT/first_load_microbench.json" 2> "$OUT/first_load_microbench.err"
 timeout 120 $EV/resident_mb > "$OUT/resident_pacing_microbench.json" 2> "$OUT/resident_pacing_microbench.err"
 python3 tools/ppo_rollout_bench.py > "$OUT/ppo_rollout.json" 2> "$OUT/ppo_rollout.err"
+fi
+if [ "$WHAT" = all ] || [ "$WHAT" = tests ]; then
+# (4) the parity figures the GPU tests print, and the soak run of the final build
+python3 -m pytest tests -q -m gpu -s 2>&1 | grep -E "[0-9]e-[0-9]|passed|failed" | cut -c1-400 > "$OUT/parity_summary.txt"
+python3 tools/soak.py 100000 > "$OUT/soak.json" 2> "$OUT/soak.err"
 fi
 ls "$OUT"
