@@ -4,7 +4,7 @@ rate-adaptive substeps on / off in regime, substep counts, fused rollout, wrappe
 actions cycling through more than the Infinity Cache.  Per-launch time = hipGraph of K steps, median of
 R replays behind a lead-in replay (HIP events).  JSON to stdout.
 
-    python tools/evidence.py > profiles/r02/runtime_ab.json
+    python tools/evidence.py > profiles/r03/runtime_ab.json
 """
 import json
 import os

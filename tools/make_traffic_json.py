@@ -4,7 +4,7 @@ bench.py reads `roofline.traffic` from.  HBM bytes per launch = 2 x FETCH_SIZE +
 FETCH_SIZE is doubled because gfx950 tallies 128-byte requests as 64 B (the 256 MiB calibration
 clone in the same profile run reads 0.500x; WRITE_SIZE reads 1.000x).
 
-    python tools/make_traffic_json.py r02
+    python tools/make_traffic_json.py r03
 """
 import json
 import os
@@ -12,7 +12,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 CONFIGS = [  # summary file -> (kind, envs, layout, auto_reset, substeps[, workload, env-steps per launch])
     ("quad65536_summary.txt", "quad", 65536, "mixed", True, 1),
     ("quad65536_noreset_summary.txt", "quad", 65536, "mixed", False, 1),
