@@ -128,7 +128,9 @@ __device__ unsigned long long* g_stamps = nullptr;
 #define QR_HELPER_GRID_ROLLOUT (QR_HELPER_GRID < 1024 ? QR_HELPER_GRID : 1024)  // qr_rollout / qr_rollout_actor (two waves per SIMD)
 #endif
 #ifndef QR_HELPER_GRID_WRAP
-#define QR_HELPER_GRID_WRAP (QR_HELPER_GRID < 2560 ? QR_HELPER_GRID : 4096)  // the wrappers (r03/ab_helper_thresholds.txt: ahead of the plain launch up to 262 144 envs)
+#define QR_HELPER_GRID_WRAP (QR_HELPER_GRID < 2048 ? QR_HELPER_GRID : 2048)  // the wrappers: ahead of the plain launch up to 262 144 envs while the action rows come
+// from cache (r03/ab_helper_thresholds.txt, 8 slabs: 14.9 against 15.7 us), behind it beyond 131 072 envs when they stream from HBM (r03/ab_helper_wave.txt, 64 slabs:
+// 131 072 envs 9.4 against 9.1 us, 262 144 envs 18.4 against 16.5 — three stepping waves per SIMD hide less latency than four)
 #endif
 // ------------------------------------------------------------------------------------
 // Quad-v0 reward and termination (quad.py:274-318) from the post-step state

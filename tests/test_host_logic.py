@@ -210,7 +210,7 @@ def test_abi_argument_errors_under_sanitizers(tmp_path):
 def test_launch_geometry_rule_without_gpu():
     """qr_step_kernel_info (host-only) reports the launch the step launcher would use: one 64-lane wavefront per 64-env
     tile, plus a helper wavefront (128 threads per workgroup) exactly for: in-launch auto-reset, default layout, no rate
-    adaptivity in reach, and grids of <= 2560 tiles (Quad-v0) / <= 4096 (wrappers) / <= 1024 (rollouts); with the fused
+    adaptivity in reach, and grids of <= 2560 tiles (Quad-v0) / <= 2048 (wrappers) / <= 1024 (rollouts); with the fused
     goal generator only for one-step launches."""
     L = _lib()
     lib = L.load()
@@ -233,8 +233,8 @@ def test_launch_geometry_rule_without_gpu():
     assert info(0, 65536, AR) == ("qr::step_kernel<0,...>", 1024, 128)
     assert info(0, 65536 + 1, AR)[1:] == (1025, 128)                      # ragged tail: one more tile
     assert info(0, 163840, AR)[2] == 128 and info(0, 163840 + 64, AR)[2] == 64
-    assert info(1, 262144, AR)[2] == 128 and info(1, 262144 + 64, AR)[2] == 64
-    assert info(2, 32768, AR)[2] == 128 and info(2, 262144, AR)[2] == 128 and info(2, 524288, AR)[2] == 64
+    assert info(1, 131072, AR)[2] == 128 and info(1, 131072 + 64, AR)[2] == 64
+    assert info(2, 32768, AR)[2] == 128 and info(2, 131072, AR)[2] == 128 and info(2, 262144, AR)[2] == 64
     assert info(0, 65536, 0)[2] == 64                                      # no in-launch reset: nothing for a helper to sample
     assert info(0, 65536, AR, layout=1)[2] == 64 and info(0, 65536, AR, layout=2)[2] == 64
     assert info(0, 65536, AR, w_adapt=3.0)[2] == 64                        # rate adaptivity within reach of |W| < W_lim: the adaptive kernel
