@@ -57,6 +57,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+TRI = {"auto": None, "on": True, "off": False}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -81,6 +82,7 @@ def parse():
                         "launch, state in registers (SURVEY.md 8(d) config 2).  rollout_actor: the PPO collection loop with the actor inside "
                         "the step kernel (qr_rollout_actor; BASELINE configs[2]; --kind coupled|decoupled).  --steps counts env-steps in all three")
     p.add_argument("--horizon", type=int, default=0, help="env-steps per launch of the rollout workloads (default 100 / 32)")
+    p.add_argument("--helper", default="auto", choices=["auto", "on", "off"], help="launch rule override: a helper wavefront per tile (QR_FLAG_FORCE_HELPER / QR_FLAG_NO_HELPER)")
     a = p.parse_args()
     if a.workload == "rollout_actor" and a.kind == "quad":
         a.kind = "coupled"
@@ -266,7 +268,8 @@ def main():
         (HIP-event ms, wall ms) lists and a few facts about the final state."""
         H = a.horizon
         env = QuadVecEnv(a.kind, N, device=dev, seed=0, substeps=a.substeps, layout=a.layout, use_UDM=True,
-                         auto_reset=ar, env_offset=rank * N, **({"obs_rows": True} if a.workload == "rollout_actor" else {}))
+                         auto_reset=ar, env_offset=rank * N, helper=TRI[a.helper],
+                         **({"obs_rows": True} if a.workload == "rollout_actor" else {}))
 
         def fresh():  # the timed steps start from reset-distribution states (configs[1])
             env.reset("train")

@@ -93,7 +93,8 @@ struct Args {
   Coeffs c;
 };
 
-// Cache policy of the step kernel's stores (gfx940+ aux bits of the buffer / global stores: 1 = sc0, 2 = nt, 16 = sc1).
+// Cache policy of the step kernel's stores (gfx940+ aux bits of the buffer / global stores: 1 = sc0, 2 = nt, 16 = sc1; ONE value
+// per launch, applied to the SoA buffer stores as aux bits and to the row / reward / done stores by gstore<AUX> below).
 // Measured on MI355X (profiles/r03/ab_store_policy_all_kinds.txt, ab_load_order_store_policy.txt): with every store of a
 // launch written THROUGH (sc1) the launch-to-launch time of the helper-wave launches drops by 8-15 % (Quad-v0 65 536 envs
 // 4.41 -> 4.00 us, Coupled 5.97 -> 5.10, Decoupled 32 768 4.98 -> 4.31): a kernel that ends with clean L2s has nothing to
@@ -108,24 +109,41 @@ struct Args {
 #define QR_PLAIN_AUX 0   // everything else
 #endif
 
-// A store of a caller-facing output (any address, per lane) with the cache policy AUX (0: a plain store; otherwise written through).
+// A store of a caller-facing output (any address, per lane) with the cache policy AUX: 0 = a plain store; otherwise the SAME aux
+// bits the SoA buffer stores of the launch carry (SoA::store<AUX>), expressed the way the compiler offers them for flat global
+// stores — as the scope of a relaxed atomic store (gfx950 memory model: workgroup = sc0, agent = sc1, system = sc0 sc1):
+//   AUX 16 (sc1)      -> agent scope      (the product's write-through policy, QR_HELP_AUX)
+//   AUX 17 (sc0 sc1)  -> system scope
+//   AUX  1 (sc0)      -> workgroup scope
+// 16-byte stores have no atomic form: inline asm with the same bits.  The aux encoding and the sc0 / sc1 modifiers are gfx940+.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "qr_args.h: the store cache policies (sc0 / sc1 aux bits) are written for gfx950 (Makefile: ARCH)"
+#endif
 typedef float f4_t __attribute__((ext_vector_type(4)));
-template <int AUX = 0, typename V>
+#ifndef QR_GSTORE_EXTRA_BITS
+#define QR_GSTORE_EXTRA_BITS 0  // measurement builds only: 1 = sc0 on top of the launch's bits for these stores (round 3 wrote them at system
+#endif                          // scope, sc0 sc1, whatever AUX said; profiles/r04/ab_gstore_scope.txt)
+template <int AUX_IN = 0, typename V>
 __device__ __forceinline__ void gstore(V* p, V v) {
+  static_assert(AUX_IN == 0 || AUX_IN == 16 || AUX_IN == 17 || AUX_IN == 1, "store policy: 0 (plain), 16 (sc1), 17 (sc0 sc1) or 1 (sc0)");
+  constexpr int AUX = AUX_IN == 0 ? 0 : (AUX_IN | QR_GSTORE_EXTRA_BITS);
+  constexpr int kScope = AUX == 16 ? __HIP_MEMORY_SCOPE_AGENT : AUX == 17 ? __HIP_MEMORY_SCOPE_SYSTEM : __HIP_MEMORY_SCOPE_WORKGROUP;
   if constexpr (AUX == 0) {
     *p = v;
   } else if constexpr (sizeof(V) == 1) {
-    __hip_atomic_store(reinterpret_cast<uint8_t*>(p), __builtin_bit_cast(uint8_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<uint8_t*>(p), __builtin_bit_cast(uint8_t, v), __ATOMIC_RELAXED, kScope);
   } else if constexpr (sizeof(V) == 2) {
-    __hip_atomic_store(reinterpret_cast<uint16_t*>(p), __builtin_bit_cast(uint16_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<uint16_t*>(p), __builtin_bit_cast(uint16_t, v), __ATOMIC_RELAXED, kScope);
   } else if constexpr (sizeof(V) == 4) {
-    __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, kScope);
   } else if constexpr (sizeof(V) == 8) {
-    __hip_atomic_store(reinterpret_cast<uint64_t*>(p), __builtin_bit_cast(uint64_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(p), __builtin_bit_cast(uint64_t, v), __ATOMIC_RELAXED, kScope);
   } else {
     static_assert(sizeof(V) == 16, "1, 2, 4, 8 or 16 bytes");
     const f4_t x = __builtin_bit_cast(f4_t, v);
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(x) : "memory");
+    if constexpr (AUX == 16) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+    else if constexpr (AUX == 17) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(x) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(x) : "memory");
   }
 }
 

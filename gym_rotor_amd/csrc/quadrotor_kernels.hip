@@ -42,6 +42,7 @@
 //   this file      step / rollout kernel, auxiliary kernels, host launchers and the C-ABI
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <type_traits>
@@ -88,7 +89,8 @@ __device__ unsigned long long* g_stamps = nullptr;
 #endif
 
 #ifndef QR_DELTA_STAGES
-#define QR_DELTA_STAGES 1  // 0: the rate-adaptive instantiations use the plain stage arithmetic (A/B: profiles/r03/ab_delta_stages.txt)
+#define QR_DELTA_STAGES 1  // 0: the rate-adaptive instantiations use the plain stage arithmetic (numerics: tools/numerics_delta.py and the free-run rows of
+                           // profiles/r03/parity_summary.txt, 6.8e-6 -> 2.4e-6; cost: the "free run in regime" rows of profiles/r03/runtime_ab.json, 4.39 against 4.03 us)
 #endif
 #ifndef QR_EARLY_STORE_GRID
 #define QR_EARLY_STORE_GRID 4096  // grids up to this many waves store a resetting wave's settled lanes before it samples (65 536 envs 5.43 / 5.49 us, 1 M 39.4 / 37.4)
@@ -118,11 +120,12 @@ __device__ unsigned long long* g_stamps = nullptr;
 #define QR_HELP_REWARD 1        // ... and forms Quad-v0's reward (§3.3 item 2; profiles/r03/ab_quad_builds.txt column q_norew)
 #endif
 #ifndef QR_HELPER_GRID
-// Grids up to this many tiles run the one-step kernel with a helper wave per tile (HELP): while every wave of the
-// grid — stepping and helper — is resident at once.  Measured (bench.py, HELP / plain, us per launch): Quad-v0 65 536 envs
-// 4.55 / 5.46, 98 304 5.65 / 6.42, 131 072 6.13 / 6.81, 196 608 9.23 / 8.40; Coupled 65 536 6.71 / 7.72, 98 304 7.78 / 8.63,
-// 131 072 9.64 / 9.06; Decoupled 32 768 5.86 / 6.51, 98 304 7.83 / 8.63, 131 072 9.66 / 8.98.
-#define QR_HELPER_GRID 2560       // Quad-v0 (profiles/r03/ab_helper_thresholds.txt: 163 840 envs 7.3 against 8.3 us plain, 196 608 equal, 262 144 10.3 against 9.9)
+// Grids up to this many tiles run the one-step kernel with a helper wave per tile (HELP).  The limit is an EMPIRICAL crossover,
+// not a residency rule: 2560 tiles are 5120 waves, more than the 4096 wave slots the 120-VGPR kernel has at four waves per SIMD —
+// the helper waves are short-lived and the launch still wins there (profiles/r03/ab_helper_thresholds.txt, with the write-through
+// stores of DESIGN.md 3.5: Quad-v0 163 840 envs 7.3 against 8.3 us plain, 196 608 equal, 262 144 10.3 against 9.9).  The environment
+// variable QR_HELPER_GRID and the QR_FLAG_*_HELPER bits override it (see `tuning`).
+#define QR_HELPER_GRID 2560
 #endif
 #ifndef QR_HELPER_GRID_ROLLOUT
 #define QR_HELPER_GRID_ROLLOUT (QR_HELPER_GRID < 1024 ? QR_HELPER_GRID : 1024)  // qr_rollout / qr_rollout_actor (two waves per SIMD)
@@ -1226,24 +1229,58 @@ static int fill_env(Args& a, const QrEnv* e) {
 // what a bandwidth-bound launch needs, and barriers of 4-wave groups at 1-2 waves/SIMD stall.
 static inline int pick_block(int64_t) { return 64; }
 
+// The launch rule's thresholds.  The compiled-in defaults are crossovers measured on the pool's MI355X boxes (the comments at
+// QR_HELPER_GRID*); boxes differ by 7-10 % in what they stream, and the wrappers' crossover moves with where the action rows come
+// from, so every threshold can be overridden per process — environment variables of the same names, read once — and per env
+// through QrEnv.flags (QR_FLAG_FORCE_HELPER / QR_FLAG_NO_HELPER: what QuadVecEnv(autotune=True) sets after timing both
+// instantiations for ITS kind, size, box and action source).  No choice changes a result bit
+// (tests/test_gpu_parity.py: test_helper_wave_launch_equals_the_plain_one, test_launch_rule_overrides_change_no_bit).
+struct Tuning {
+  unsigned helper_grid, helper_grid_wrap, helper_grid_rollout;
+};
+static unsigned env_uint(const char* name, unsigned dflt) {
+  const char* v = getenv(name);
+  if (!v || !*v) return dflt;
+  char* end = nullptr;
+  const unsigned long x = strtoul(v, &end, 10);
+  return (end && *end == 0) ? (unsigned)x : dflt;
+}
+static const Tuning& tuning() {
+  static const Tuning t = [] {
+    Tuning x;
+    x.helper_grid = env_uint("QR_HELPER_GRID", QR_HELPER_GRID);
+    x.helper_grid_wrap = env_uint("QR_HELPER_GRID_WRAP", x.helper_grid < (unsigned)QR_HELPER_GRID_WRAP ? x.helper_grid : (unsigned)QR_HELPER_GRID_WRAP);
+    x.helper_grid_rollout = env_uint("QR_HELPER_GRID_ROLLOUT", x.helper_grid < (unsigned)QR_HELPER_GRID_ROLLOUT ? x.helper_grid : (unsigned)QR_HELPER_GRID_ROLLOUT);
+    return x;
+  }();
+  return t;
+}
+
 // Which instantiation a launch gets (shared by launch_kind and qr_step_kernel_info).
 static inline bool wants_adapt(const Args& a) {
   return a.c.inv_w_adapt > 0 && (!(a.flags & QR_FLAG_AUTO_RESET) || a.c.inv_w_adapt * a.c.W_lim * 2.5 > 1.0);
+}
+static inline bool helper_choice(const Args& a, unsigned tiles, unsigned limit) {  // (the instantiation exists: rule, or the env's override)
+  if (a.flags & QR_FLAG_NO_HELPER) return false;
+  if (a.flags & QR_FLAG_FORCE_HELPER) return true;
+  return tiles <= limit;
 }
 static inline bool wants_helper(const Args& a, int kind, int layout) {  // a helper wave per tile (HELP)
   const unsigned tiles = (unsigned)((a.n + 63) / 64);
   // (the multi-step instantiations hold the loop's state across steps: 181-216 VGPRs = two waves per SIMD, so a stepping
   // and a helper wave per tile are all resident only up to 1024 tiles; beyond, measured: Quad-v0 98 304 envs 3.52 against
   // 2.97 us per env-step plain, Coupled 5.06 against 3.74)
-  const unsigned limit = a.n_steps > 1 ? (unsigned)QR_HELPER_GRID_ROLLOUT : (unsigned)(kind == QR_KIND_QUAD ? QR_HELPER_GRID : QR_HELPER_GRID_WRAP);
+  const Tuning& tn = tuning();
+  const unsigned limit = a.n_steps > 1 ? tn.helper_grid_rollout : (kind == QR_KIND_QUAD ? tn.helper_grid : tn.helper_grid_wrap);
   return layout == QR_LAYOUT_MIXED && a.act_out == nullptr && a.goal_mode == QR_GOAL_EXTERNAL && !wants_adapt(a) &&
-         (a.flags & QR_FLAG_AUTO_RESET) && tiles <= limit;
+         (a.flags & QR_FLAG_AUTO_RESET) && helper_choice(a, tiles, limit);
 }
 
 static inline bool wants_helper_traj(const Args& a, int kind) {  // the same with the fused goal generator (one-step launches)
   const unsigned tiles = (unsigned)((a.n + 63) / 64);
+  const Tuning& tn = tuning();
   return a.act_out == nullptr && a.goal_mode != QR_GOAL_EXTERNAL && !wants_adapt(a) && (a.flags & QR_FLAG_AUTO_RESET) &&
-         tiles <= (unsigned)(kind == QR_KIND_QUAD ? QR_HELPER_GRID : QR_HELPER_GRID_WRAP);
+         helper_choice(a, tiles, kind == QR_KIND_QUAD ? tn.helper_grid : tn.helper_grid_wrap);
 }
 
 template <int KIND, typename XV, typename QW>
@@ -1266,7 +1303,7 @@ static void launch_kind(const Args& a, hipStream_t s) {
         // per tile (noise, reset pool, observation rows).  Measured, Coupled 65 536 envs, T = 32: 5.37 -> 4.51 us per step;
         // with the fused goal generator the same split measured SLOWER (5.65 -> 6.25 us per step, tools/ppo_rollout_bench.py;
         // both waves of a tile must be resident, which caps the kernel at 256 registers) and is not instantiated.
-        if (QR_HELP_POLICY && !general && !traj && (a.flags & QR_FLAG_AUTO_RESET) && grid.x <= (unsigned)QR_HELPER_GRID_ROLLOUT) {
+        if (QR_HELP_POLICY && !general && !traj && (a.flags & QR_FLAG_AUTO_RESET) && helper_choice(a, grid.x, tuning().helper_grid_rollout)) {
           hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 1, false, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
           return;
         }

@@ -110,6 +110,11 @@ class QuadVecEnv:
     final_obs       with auto_reset: also keep the TERMINAL observation rows of the envs that were
                     re-sampled in the last step (`final_observation()`; the reference's obs_next of
                     that transition, main.py:163-178) — what a learner bootstraps V(s') from
+    helper          launch-rule override (speed only, no result bit changes): None = the library's rule (a helper wavefront per
+                    64-env tile on small grids, thresholds measured on MI355X; the environment variables QR_HELPER_GRID /
+                    QR_HELPER_GRID_WRAP / QR_HELPER_GRID_ROLLOUT override them per process); True / False force / forbid it
+    autotune        time step() with and without the helper wavefront for THIS env (kind, size, box) at construction — see
+                    autotune_launch() — and keep the faster (sets `helper`)
     obs_rows        write float32 observation rows [N,D].  Always on for the wrappers.  For
                     kind='quad' the observation is the next state (quad.py:269-271): True writes
                     it as float32 [N,18] rows each step; False (default) writes nothing and
@@ -123,7 +128,8 @@ class QuadVecEnv:
                  UDM_percentage: float = 10.0, auto_reset: bool = False, max_episode_steps: int = 0,
                  env_offset: int = 0, want_raw_reward: bool = False, obs_rows: Optional[bool] = None,
                  field_stride: Optional[int] = None, goal_mode: Optional[int] = None, w_adapt: float = 16.0,
-                 constants: Optional[QuadConstants] = None, final_obs: bool = False):
+                 constants: Optional[QuadConstants] = None, final_obs: bool = False,
+                 helper: Optional[bool] = None, autotune: bool = False):
         if kind not in KINDS:
             raise ValueError(f"kind must be one of {KINDS}, got {kind!r}")
         if num_envs < 1:
@@ -148,6 +154,7 @@ class QuadVecEnv:
         self.use_UDM, self.UDM_percentage = bool(use_UDM), float(UDM_percentage)
         self.auto_reset, self.max_episode_steps = bool(auto_reset), int(max_episode_steps)
         self.env_offset, self.seed = int(env_offset), self._check_seed(seed)
+        self._helper = helper
         c = self.constants = constants or QuadConstants(UDM_percentage=UDM_percentage)
 
         # ---- attributes the reference's callers read (trajectory_generator.py:44-46,
@@ -229,6 +236,9 @@ class QuadVecEnv:
         self._cenv.coeffs = co
         self._sync_structs()
         self._closed = False
+        self.autotune_report = None
+        if autotune:
+            self.autotune_launch()
 
     # ------------------------------------------------------------------------------
     @staticmethod
@@ -255,6 +265,7 @@ class QuadVecEnv:
         e.episode, e.steps, e.reset_count = _ptr(self._episode), _ptr(self._steps), _ptr(self._reset_count)
         e.max_episode_steps = self.max_episode_steps
         e.flags = (_lib.FLAG_AUTO_RESET if self.auto_reset else 0) | (0 if self.use_UDM else _lib.FLAG_NO_UDM)
+        e.flags |= {None: 0, True: _lib.FLAG_FORCE_HELPER, False: _lib.FLAG_NO_HELPER}[self._helper]
         o.obs0, o.obs1, o.reward, o.reward_raw = _ptr(self._obs0), _ptr(self._obs1), _ptr(self._reward), _ptr(self._reward_raw)
         o.done, o.truncated = _ptr(self._done), (_ptr(self._trunc) if self._steps is not None else None)
         o.final_obs0, o.final_obs1 = _ptr(self._final0), _ptr(self._final1)
@@ -654,6 +665,62 @@ class QuadVecEnv:
     @property
     def episode_steps(self):
         return self._steps
+
+    def set_launch(self, helper: Optional[bool] = None):
+        """Pin (True / False) or release (None) the launch rule's choice — a helper wavefront per tile — for this env."""
+        self._helper = helper
+        self._sync_structs()
+
+    def autotune_launch(self, actions: Optional[torch.Tensor] = None, launches: int = 200, repeats: int = 3):
+        """Time step() under the launch-rule choices that exist for this env — the library's default, helper wavefront forced,
+        helper wavefront forbidden — and keep the fastest (set_launch).  The env's state, counters and RNG position are restored
+        afterwards: tuning changes no result.  `actions`: the [N, A] rows (or a list of them, cycled through) the caller will
+        step with; where they come from — cache or HBM — moves the wrappers' crossover, so pass the real source
+        when there is one; default: 8 random slabs.  `launches` timed launches per candidate (one hipGraph), best of `repeats`.
+        Returns {candidate: us per launch, "picked": name} (also kept as `autotune_report`)."""
+        dev, N = self.device, self.num_envs
+        saved, saved_choice = self.state_dict(), self._helper
+        if actions is None:
+            gen = torch.Generator(device=dev); gen.manual_seed(99)
+            acts = [torch.rand(N, self.action_dim, device=dev, generator=gen) * 2 - 1 for _ in range(8)]
+        else:
+            acts = [self._check_actions(a_) for a_ in (actions if isinstance(actions, (list, tuple)) else [actions])]
+        cands, seen, report = {"default": None, "helper": True, "no_helper": False}, {}, {}
+        for name, h in cands.items():
+            self.set_launch(h)
+            geom = self.kernel_info()[1:]
+            if geom in seen:        # the same instantiation as an earlier candidate
+                report[name] = report[seen[geom]]
+                continue
+            seen[geom] = name
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for k in range(10):
+                    self.step(acts[k % len(acts)])
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    for k in range(launches):
+                        self.step(acts[k % len(acts)])
+                best = float("inf")
+                for _ in range(repeats):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    g.replay(); e0.record(); g.replay(); e1.record()
+                    torch.cuda.synchronize(dev)
+                    best = min(best, e0.elapsed_time(e1) * 1e3 / launches)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            report[name] = best
+            del g
+        self.load_state_dict(saved)
+        pick = min(("helper", "no_helper"), key=lambda k: report[k])
+        if report["default"] <= report[pick] * 1.01:   # within noise of the rule's own choice: keep the rule
+            self.set_launch(saved_choice)
+            report["picked"] = "default"
+        else:
+            self.set_launch(cands[pick])
+            report["picked"] = pick
+        self.autotune_report = report
+        return report
 
     def kernel_info(self, n_steps=1):
         """(kernel family, workgroups, threads per workgroup) of the launch `step` (n_steps=1) / `rollout` uses."""

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define QR_ABI_VERSION 11
+#define QR_ABI_VERSION 12
 
 /* env kinds */
 #define QR_KIND_QUAD      0 /* QuadEnv            gym_rotor/envs/quad.py:19            */
@@ -77,6 +77,13 @@ extern "C" {
 #define QR_FLAG_AUTO_RESET   1u /* re-sample a done env inside the same launch (train distribution) */
 #define QR_FLAG_EVAL_RESET   2u /* resets use env_type='eval' (quad.py:352-356) instead of 'train' */
 #define QR_FLAG_NO_UDM       4u /* resets keep nominal parameters (use_UDM False / eval)            */
+/* Launch-rule overrides (speed only: no choice changes a result bit).  By default qr_step / qr_rollout(_actor) decide from the
+ * grid size whether every 64-env tile gets a second, helper wavefront, with thresholds measured on MI355X (environment variables
+ * QR_HELPER_GRID, QR_HELPER_GRID_WRAP, QR_HELPER_GRID_ROLLOUT override them per process, read once); these bits pin the choice
+ * per env — what an autotuner that timed both on ITS box, kind, size and action source sets.  Ignored where the instantiation
+ * does not exist (a helper wavefront needs QR_FLAG_AUTO_RESET, the default layout and no rate adaptivity in reach). */
+#define QR_FLAG_FORCE_HELPER   8u /* a helper wavefront per 64-env tile whatever the grid size      */
+#define QR_FLAG_NO_HELPER     16u /* never                                                          */
 
 /* Coefficients a caller may override (args_parse.py:23-35); qr_default_coeffs() fills the
  * reference defaults.  reward_min* are derived inside (quad.py:81-88). */

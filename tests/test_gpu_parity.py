@@ -582,6 +582,57 @@ def test_helper_wave_launch_equals_the_plain_one(kind):
     assert torch.equal(big.get_current_state()[lo:hi], part.get_current_state())
 
 
+@pytest.mark.parametrize("kind", KINDS)
+def test_launch_rule_overrides_change_no_bit(kind):
+    """QuadVecEnv(helper=True / False) (QR_FLAG_FORCE_HELPER / QR_FLAG_NO_HELPER) pins the launch rule's choice per env, and
+    autotune_launch() picks it by timing: the SAME batch — a ragged one, per-env goals, a time limit — stepped under either choice
+    gives the same bits (state, rows, rewards, dones, truncations, terminal observations, parameters, every counter), tuning
+    leaves no trace in the env, and the forced choice reaches beyond the rule's own limits in both directions."""
+    adim = 5 if kind == "decoupled" else 4
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    n, T = 64 * 700 + 17, 40
+    kw = dict(seed=11, auto_reset=True, obs_rows=True, max_episode_steps=25, final_obs=True)
+    a, b = _env(kind, n, helper=True, **kw), _env(kind, n, helper=False, **kw)
+    c = _env(kind, n, **kw)
+    assert a.kernel_info()[1:] == (701, 128) and b.kernel_info()[1:] == (701, 64) and c.kernel_info()[2] == 128
+    big = _env(kind, 64 * 5000, helper=True, auto_reset=True)
+    assert big.kernel_info()[1:] == (5000, 128) and _env(kind, 64 * 5000, auto_reset=True).kernel_info()[2] == 64
+    assert _env(kind, n, helper=True).kernel_info()[2] == 64      # no in-launch resets: no such instantiation, the bit is ignored
+    goal = torch.zeros(n, 12, device="cuda")
+    goal[:, 0:6] = (torch.rand(n, 6, device="cuda", generator=g) - 0.5) * 0.2
+    ang = torch.rand(n, device="cuda", generator=g) * 6.28
+    goal[:, 6], goal[:, 7] = torch.cos(ang), torch.sin(ang)
+    for e in (a, b, c):
+        e.reset("train")
+        _set_goal(e, goal)
+        if kind != "quad":
+            e.get_norm_error_state()
+    resets = 0
+    for t in range(T):
+        act = torch.rand(n, adim, device="cuda", generator=g) * 2 - 1
+        if t == 10:     # tuning in mid-flight: times both launches on this env's own buffers, then puts everything back
+            rep = c.autotune_launch(launches=50, repeats=2)
+            assert rep["picked"] in ("default", "helper", "no_helper") and rep["helper"] > 0 and rep["no_helper"] > 0
+        oa, ra, da, ta, _ = a.step(act)
+        ob, rb, db, tb, _ = b.step(act)
+        oc, rc, dc, tc, _ = c.step(act)
+        for x, y, z in zip(_obs_list(oa), _obs_list(ob), _obs_list(oc)):
+            assert torch.equal(x, y) and torch.equal(x, z), t
+        assert torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(ta, tb), t
+        assert torch.equal(ra, rc) and torch.equal(da, dc) and torch.equal(ta, tc), t
+        assert torch.equal(a._reward_raw, b._reward_raw)
+        rows = da.reshape(n, -1).any(dim=1) | ta
+        resets += int(rows.sum())
+        for x, y in zip(_obs_list(a.final_observation()), _obs_list(b.final_observation())):
+            assert torch.equal(x[rows], y[rows])
+    assert resets > n                                    # (the time limit alone ended every episode once)
+    for e in (b, c):
+        assert torch.equal(a.get_current_state(), e.get_current_state())
+        for name in ("_params", "_episode", "_steps", "_reset_count", "_integ"):
+            x, y = getattr(a, name), getattr(e, name)
+            assert (x is None and y is None) or torch.equal(x, y), name
+
+
 def _kill(env, kill):
     """Make the envs in `kill` terminate in the next step: x far outside the arena."""
     st = _np(env.get_current_state())

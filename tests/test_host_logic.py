@@ -242,6 +242,13 @@ def test_launch_geometry_rule_without_gpu():
     gm = int(re.search(r"#define QR_GOAL_MODE0\s+(\d+)", hdr).group(1))
     assert GOAL_EXTERNAL == 0 and info(1, 65536, AR, goal_mode=gm)[2] == 128 and info(1, 65536, AR, goal_mode=gm, n_steps=8)[2] == 64
     assert info(0, -5, AR)[0] == ""                                        # invalid descriptor
+    # the override bits pin the choice per env, beyond the rule's limits in both directions; ignored where no helper instantiation exists
+    flag = {n: int(re.search(r"#define QR_FLAG_%s\s+(\d+)u" % n, hdr).group(1)) for n in ("FORCE_HELPER", "NO_HELPER")}
+    assert info(0, 1 << 20, AR)[1:] == (16384, 64)
+    assert info(0, 1 << 20, AR | flag["FORCE_HELPER"])[1:] == (16384, 128) and info(0, 65536, AR | flag["NO_HELPER"])[1:] == (1024, 64)
+    assert info(2, 32768, AR | flag["NO_HELPER"])[2] == 64 and info(1, 1 << 19, AR | flag["FORCE_HELPER"], n_steps=8)[2] == 128
+    assert info(0, 65536, AR | flag["FORCE_HELPER"], layout=1)[2] == 64 and info(0, 65536, AR | flag["FORCE_HELPER"], w_adapt=3.0)[2] == 64
+    assert info(0, 65536, flag["FORCE_HELPER"])[2] == 64                   # no such instantiation without in-launch resets: ignored
 
 
 def test_no_cpu_fallback():

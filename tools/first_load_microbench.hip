@@ -48,7 +48,7 @@ static void run(hipStream_t s, int delay, int grid) {
   hipGraph_t g; hipGraphExec_t ge;
   const int K = 200;
   CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
-  for (int k = 0; k < K; ++k) hipLaunchKernelGGL((probe<NL, SC1>), dim3(grid), dim3(64), 0, s, buf, st, n, delay);
+  for (int k = 0; k < K; ++k) { hipLaunchKernelGGL((probe<NL, SC1>), dim3(grid), dim3(64), 0, s, buf, st, n, delay); CK(hipGetLastError()); }
   CK(hipStreamEndCapture(s, &g));
   CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

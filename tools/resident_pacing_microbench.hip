@@ -99,7 +99,7 @@ static int run(const char* name) {
   CK(hipMemset(actions, 0, (size_t)T * n * 16));
   hipGraph_t g; hipGraphExec_t ge;
   CK(hipStreamBeginCapture(s_prod, hipStreamCaptureModeGlobal));
-  for (int t = 0; t < T; ++t) hipLaunchKernelGGL(producer<FENCE>, dim3(n / 256), dim3(256), 0, s_prod, flags, counters, actions, t, n, 1.0f + t);
+  for (int t = 0; t < T; ++t) { hipLaunchKernelGGL(producer<FENCE>, dim3(n / 256), dim3(256), 0, s_prod, flags, counters, actions, t, n, 1.0f + t); CK(hipGetLastError()); }
   CK(hipStreamEndCapture(s_prod, &g));
   CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -115,7 +115,7 @@ static int run(const char* name) {
   CK(hipMemset(failed, 0, 4));
   for (int rep = 0; rep < 2; ++rep) {   // (b) every flag already set: the resident kernel free-runs (a rollout)
     CK(hipEventRecord(e0, s_env));
-    hipLaunchKernelGGL(resident<FENCE>, dim3(n / 128), dim3(128), 0, s_env, flags, actions, out, stamps, failed, T, n, work);
+    hipLaunchKernelGGL(resident<FENCE>, dim3(n / 128), dim3(128), 0, s_env, flags, actions, out, stamps, failed, T, n, work); CK(hipGetLastError());
     CK(hipEventRecord(e1, s_env)); CK(hipStreamSynchronize(s_env));
   }
   CK(hipEventElapsedTime(&ms, e0, e1));
@@ -125,7 +125,7 @@ static int run(const char* name) {
     CK(hipMemset(flags, 0, T * 4)); CK(hipMemset(counters, 0, T * 4)); CK(hipMemset(failed, 0, 4));
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, s_env));
-    hipLaunchKernelGGL(resident<FENCE>, dim3(n / 128), dim3(128), 0, s_env, flags, actions, out, stamps, failed, T, n, work);
+    hipLaunchKernelGGL(resident<FENCE>, dim3(n / 128), dim3(128), 0, s_env, flags, actions, out, stamps, failed, T, n, work); CK(hipGetLastError());
     CK(hipEventRecord(e1, s_env));
     CK(hipGraphLaunch(ge, s_prod));
     CK(hipStreamSynchronize(s_prod)); CK(hipStreamSynchronize(s_env));

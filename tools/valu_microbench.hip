@@ -1,5 +1,5 @@
 // valu_microbench.hip — issue cost of the vector instructions the step kernel is built from, on gfx950.
-// One wave per workgroup; grid = 1024 (one wave per SIMD) or 2048 / 4096 (two / four waves per SIMD).
+// One wave per workgroup; grid = 1024 (one wave per SIMD) or 2048 / 3072 / 4096 (two / three / four waves per SIMD).
 // Each kernel runs ITERS iterations of 16 independent accumulator chains of one instruction and
 // reports shader cycles (s_memtime) per wave-instruction, median over waves.
 //
@@ -11,6 +11,8 @@
 #include <vector>
 
 typedef float float2v __attribute__((ext_vector_type(2)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+#define LAUNCH(...) do { hipLaunchKernelGGL(__VA_ARGS__); CK(hipGetLastError()); } while (0)
 constexpr int ITERS = 2000;
 constexpr int CH = 16;
 
@@ -79,23 +81,23 @@ int main() {
                         {"v_fma_f64", bench_kernel<FmaF64>}, {"v_add_f64", bench_kernel<AddF64>}, {"v_mul_f64", bench_kernel<MulF64>},
                         {"v_rcp_f64", bench_kernel<RcpF64>}, {"v_rcp_f32", bench_kernel<RcpF32>}, {"v_cvt_f32_f64", bench_kernel<CvtDown>},
                         {"v_cvt_f64_f32", bench_kernel<CvtUp>}, {"v_mul_hi_u32", bench_kernel<MulHi>}, {"v_mul_lo_u32", bench_kernel<MulLo>}};
-  const int grids[] = {1024, 2048, 4096};
+  const int grids[] = {1024, 2048, 3072, 4096};
   float* out; uint64_t* cyc;
-  hipMalloc(&out, 4096 * 64 * sizeof(float));
-  hipMalloc(&cyc, 4096 * sizeof(uint64_t));
+  CK(hipMalloc(&out, 4096 * 64 * sizeof(float)));
+  CK(hipMalloc(&cyc, 4096 * sizeof(uint64_t)));
   std::vector<uint64_t> h(4096);
-  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   printf("{\"what\": \"cycles per wave-instruction (s_memtime, median over waves) and wall ns per instruction per SIMD; %d iters x %d independent chains, one wave per workgroup\", \"results\": [\n", ITERS, CH);
   bool first = true;
   for (const Case& c : cases) {
     for (int g : grids) {
-      for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(c.k, dim3(g), dim3(64), 0, 0, out, cyc, 1e-3f);
-      hipEventRecord(e0);
-      hipLaunchKernelGGL(c.k, dim3(g), dim3(64), 0, 0, out, cyc, 1e-3f);
-      hipEventRecord(e1);
-      hipDeviceSynchronize();
-      float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-      hipMemcpy(h.data(), cyc, g * sizeof(uint64_t), hipMemcpyDeviceToHost);
+      for (int rep = 0; rep < 3; ++rep) LAUNCH(c.k, dim3(g), dim3(64), 0, 0, out, cyc, 1e-3f);
+      CK(hipEventRecord(e0));
+      LAUNCH(c.k, dim3(g), dim3(64), 0, 0, out, cyc, 1e-3f);
+      CK(hipEventRecord(e1));
+      CK(hipDeviceSynchronize());
+      float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+      CK(hipMemcpy(h.data(), cyc, g * sizeof(uint64_t), hipMemcpyDeviceToHost));
       std::sort(h.begin(), h.begin() + g);
       const double per = (double)h[g / 2] / ((double)ITERS * CH);
       const double waves_per_simd = g / 1024.0;
@@ -105,12 +107,12 @@ int main() {
     }
   }
   // launch floor: back-to-back empty kernels, 1024 workgroups
-  for (int rep = 0; rep < 20; ++rep) hipLaunchKernelGGL(k_empty, dim3(1024), dim3(64), 0, 0, out, cyc, 1.0f);
-  hipEventRecord(e0);
-  for (int rep = 0; rep < 1000; ++rep) hipLaunchKernelGGL(k_empty, dim3(1024), dim3(64), 0, 0, out, cyc, 1.0f);
-  hipEventRecord(e1);
-  hipDeviceSynchronize();
-  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+  for (int rep = 0; rep < 20; ++rep) LAUNCH(k_empty, dim3(1024), dim3(64), 0, 0, out, cyc, 1.0f);
+  CK(hipEventRecord(e0));
+  for (int rep = 0; rep < 1000; ++rep) LAUNCH(k_empty, dim3(1024), dim3(64), 0, 0, out, cyc, 1.0f);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
   printf("],\n\"empty_kernel_1024wg_eager_us_per_launch\": %.3f}\n", ms);
   return 0;
 }

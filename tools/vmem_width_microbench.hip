@@ -15,8 +15,11 @@
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+// every launch is checked — also inside a stream capture, where a launch that violates the kernel's launch bounds fails
+// at once and would otherwise leave an EMPTY graph that "runs" in 0.02 us (round 3 reported two such rows as measurements)
+#define LAUNCH(...) do { hipLaunchKernelGGL(__VA_ARGS__); CK(hipGetLastError()); } while (0)
 
-__global__ __launch_bounds__(128) void empty_kernel(float* p) { if (p == nullptr) p[0] = 0; }
+__global__ __launch_bounds__(512) void empty_kernel(float* p) { if (p == nullptr) p[0] = 0; }
 
 // ---- SoA, narrow accesses: the round-2 layout ----
 __global__ __launch_bounds__(64) void soa_kernel(float* __restrict__ pv, double* __restrict__ ar, const float* __restrict__ prm,
@@ -108,9 +111,9 @@ int main() {
   hipStream_t s; CK(hipStreamCreate(&s));
   printf("{\n \"what\": \"us per launch, chain of 200 dependent launches in one hipGraph, median of 9 (HIP events)\"");
   float* dummy; CK(hipMalloc(&dummy, 1024));
-  const int shapes[][2] = {{1, 64}, {256, 64}, {1024, 64}, {1024, 128}, {512, 256}, {256, 256}, {2048, 64}, {4096, 64}, {16384, 64}};
+  const int shapes[][2] = {{1, 64}, {256, 64}, {1024, 64}, {1024, 128}, {512, 256}, {256, 256}, {256, 512}, {2048, 64}, {3072, 64}, {4096, 64}, {16384, 64}};
   for (auto& sh : shapes) {
-    const double us = time_chain(s, [&](int) { hipLaunchKernelGGL(empty_kernel, dim3(sh[0]), dim3(sh[1]), 0, s, dummy); });
+    const double us = time_chain(s, [&](int) { LAUNCH(empty_kernel, dim3(sh[0]), dim3(sh[1]), 0, s, dummy); });
     printf(",\n \"empty %dx%d\": %.3f", sh[0], sh[1], us);
   }
   for (int n : {65536, 131072, 262144, 1048576}) {
@@ -121,17 +124,17 @@ int main() {
     CK(hipMalloc(&act, (size_t)NA * n * 16)); CK(hipMalloc(&done, n)); CK(hipMalloc(&rew, (size_t)n * 4));
     CK(hipMemset(pv, 0, (size_t)6 * n * 4)); CK(hipMemset(ar, 0, (size_t)6 * n * 8)); CK(hipMemset(prm, 0, (size_t)6 * n * 4));
     CK(hipMemset(act, 0, (size_t)NA * n * 16));
-    double us = time_chain(s, [&](int k) { hipLaunchKernelGGL(soa_kernel, dim3(tiles), dim3(64), 0, s, pv, ar, prm, act + (size_t)(k % NA) * n, done, rew, n); });
+    double us = time_chain(s, [&](int k) { LAUNCH(soa_kernel, dim3(tiles), dim3(64), 0, s, pv, ar, prm, act + (size_t)(k % NA) * n, done, rew, n); });
     printf(",\n \"soa narrow (19 loads, 14 stores) %d\": %.3f", n, us);
     // blocked: state 72 B/env = [tile][4][64] float4 + [n] double; params [n] float4 + [n] float2
     float4* st; double* st8; float4* p4; float2* p2;
     CK(hipMalloc(&st, (size_t)n * 64)); CK(hipMalloc(&st8, (size_t)n * 8)); CK(hipMalloc(&p4, (size_t)n * 16)); CK(hipMalloc(&p2, (size_t)n * 8));
     CK(hipMemset(st, 0, (size_t)n * 64)); CK(hipMemset(st8, 0, (size_t)n * 8)); CK(hipMemset(p4, 0, (size_t)n * 16)); CK(hipMemset(p2, 0, (size_t)n * 8));
-    us = time_chain(s, [&](int k) { hipLaunchKernelGGL(blk_kernel, dim3(tiles), dim3(64), 0, s, st, st8, p4, p2, act + (size_t)(k % NA) * n, done, rew, n); });
+    us = time_chain(s, [&](int k) { LAUNCH(blk_kernel, dim3(tiles), dim3(64), 0, s, st, st8, p4, p2, act + (size_t)(k % NA) * n, done, rew, n); });
     printf(",\n \"blocked wide (8 loads, 7 stores) %d\": %.3f", n, us);
     float4* rec; float2* out2;
     CK(hipMalloc(&rec, (size_t)n * 96)); CK(hipMalloc(&out2, (size_t)n * 8)); CK(hipMemset(rec, 0, (size_t)n * 96));
-    us = time_chain(s, [&](int k) { hipLaunchKernelGGL(rec_kernel, dim3(tiles), dim3(64), 0, s, rec, act + (size_t)(k % NA) * n, out2, n); });
+    us = time_chain(s, [&](int k) { LAUNCH(rec_kernel, dim3(tiles), dim3(64), 0, s, rec, act + (size_t)(k % NA) * n, out2, n); });
     printf(",\n \"record wide (7 loads, 6 stores) %d\": %.3f", n, us);
     CK(hipFree(pv)); CK(hipFree(ar)); CK(hipFree(prm)); CK(hipFree(act)); CK(hipFree(done)); CK(hipFree(rew));
     CK(hipFree(st)); CK(hipFree(st8)); CK(hipFree(p4)); CK(hipFree(p2)); CK(hipFree(rec)); CK(hipFree(out2));
