@@ -40,6 +40,10 @@ Secondary figures under `config` (rank 0, --extras 1): the other reset mode, the
 and `policy_rollout_coupled_T32` — BASELINE configs[2]'s PPO collection loop with the actor inside the
 step kernel (qr_rollout_actor).
 
+Other runs, one flag each: `--config 2|3|4` = BASELINE.json configs[2..4] in their per-GPU shape (CoupledWrapper
+65 536; DecoupledWrapper 32 768 per GPU; Quad-v0 131 072 per GPU x 10 substeps), `--scaling strong` = a fixed global batch (the
+preset's named total, or --global-envs) cut into 64-aligned shards over the ranks, reported as `"scaling": "strong"`.
+
 `cpu_baseline` (rank 0, N=1 only) times the oracle's reference-style single-env path (NumPy RHS
 + scipy DOP853 + ensure_SO3, reset-on-done; oracle/quad_oracle.py) on one host core for ~12 s.
 """
@@ -58,6 +62,11 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 TRI = {"auto": None, "on": True, "off": False}
+# BASELINE.json configs[1..4] in their per-GPU shape (configs[0] is the reference's CPU run: `cpu_baseline`)
+PRESETS = {1: dict(kind="quad", envs=65536, substeps=1, total=65536, slabs=64, name="configs[1]: Quad-v0 batched 65 536 envs, 1xMI355X"),
+           2: dict(kind="coupled", envs=65536, substeps=1, total=65536, slabs=64, name="configs[2]: CoupledWrapper 65 536 envs + reward/done"),
+           3: dict(kind="decoupled", envs=32768, substeps=1, total=262144, slabs=64, name="configs[3]: DecoupledWrapper two-agent, 262 144 envs over 8 GPUs = 32 768 per GPU"),
+           4: dict(kind="quad", envs=131072, substeps=10, total=1048576, slabs=32, name="configs[4]: Quad-v0 1 048 576 envs over 8 GPUs = 131 072 per GPU, 10 substeps")}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -83,7 +92,22 @@ def parse():
                         "the step kernel (qr_rollout_actor; BASELINE configs[2]; --kind coupled|decoupled).  --steps counts env-steps in all three")
     p.add_argument("--horizon", type=int, default=0, help="env-steps per launch of the rollout workloads (default 100 / 32)")
     p.add_argument("--helper", default="auto", choices=["auto", "on", "off"], help="launch rule override: a helper wavefront per tile (QR_FLAG_FORCE_HELPER / QR_FLAG_NO_HELPER)")
+    p.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                   help="preset = BASELINE.json configs[k] in its per-GPU shape: 1 Quad-v0 65 536 envs (the default run); 2 CoupledWrapper 65 536; "
+                        "3 DecoupledWrapper 32 768 per GPU (262 144 over 8 GPUs); 4 Quad-v0 131 072 per GPU x 10 substeps (1 048 576 over 8 GPUs). "
+                        "Sets --kind / --envs / --substeps (and the named total for --scaling strong)")
+    p.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                   help="weak: --envs per GPU, the global batch grows with --gpus (the driver's contract).  strong: a FIXED global batch — "
+                        "--global-envs, default the preset's named total or --envs — cut into 64-aligned shards over the ranks (shard_range)")
+    p.add_argument("--global-envs", type=int, default=0, help="global batch of --scaling strong")
     a = p.parse_args()
+    if a.config:
+        preset = PRESETS[a.config]
+        a.kind, a.envs, a.substeps = preset["kind"], preset["envs"], preset["substeps"]
+        if a.action_batches == 64:   # (default) keep the action slabs streaming from HBM without outgrowing it
+            a.action_batches = preset["slabs"]
+    if a.scaling == "strong" and a.global_envs <= 0:
+        a.global_envs = PRESETS[a.config]["total"] if a.config else a.envs
     if a.workload == "rollout_actor" and a.kind == "quad":
         a.kind = "coupled"
     if a.horizon <= 0:
@@ -251,9 +275,14 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     _ensure_library(dist, local_rank)
-    from gym_rotor_amd import ALGO_BYTES, QuadVecEnv
+    from gym_rotor_amd import ALGO_BYTES, QuadVecEnv, shard_range
     from gym_rotor_amd.constants import ALGO_BYTES_PARAMS
-    N = a.envs
+    if a.scaling == "strong":      # a fixed global batch, this rank's 64-aligned shard of it (no collective on the step path either way)
+        G = a.global_envs
+        lo, hi = shard_range(G, rank, world)
+        N, env_offset = hi - lo, lo
+    else:                          # weak: --envs per GPU
+        N, env_offset, G = a.envs, rank * a.envs, a.envs * world
     auto_reset = a.auto_reset
     on_dev = dist is None or backend == "nccl"
 
@@ -268,7 +297,7 @@ def main():
         (HIP-event ms, wall ms) lists and a few facts about the final state."""
         H = a.horizon
         env = QuadVecEnv(a.kind, N, device=dev, seed=0, substeps=a.substeps, layout=a.layout, use_UDM=True,
-                         auto_reset=ar, env_offset=rank * N, helper=TRI[a.helper],
+                         auto_reset=ar, env_offset=env_offset, helper=TRI[a.helper],
                          **({"obs_rows": True} if a.workload == "rollout_actor" else {}))
 
         def fresh():  # the timed steps start from reset-distribution states (configs[1])
@@ -408,18 +437,20 @@ def main():
                                "action sampling inside the step kernel"}[a.workload]
         out = {
             "metric": "quadrotor env-steps/sec at 65 536 envs; 1/2/4/8 MI355X + CPU ref",
-            "value": N * n_gpus / (ms_per_step * 1e-3), "unit": "env-steps/s", "n_gpus": n_gpus, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "value": G / (ms_per_step * 1e-3), "unit": "env-steps/s", "n_gpus": n_gpus, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": {"mixed": "mixed f32/f64", "f64": "f64", "f32": "f32"}[a.layout], "data": "synthetic",
             "config": {"workload": (f"BASELINE.json configs[1]: Quad-v0 batched {N} envs per GPU, random actions, fp32 I/O, "
                                     + ("terminated envs re-sampled in the launch" if auto_reset else "free run from one reset")
                                     if a.kind == "quad" else f"{a.kind} wrapper, {N} envs per GPU, random actions, fp32 I/O") + wl,
                        "workload_kind": a.workload, "env_steps_per_launch": H,
-                       "kind": a.kind, "envs_per_gpu": N, "global_envs": N * n_gpus, "substeps": a.substeps,
+                       "baseline_config": (PRESETS[a.config]["name"] if a.config else None),
+                       "kind": a.kind, "envs_per_gpu": N, "global_envs": G, "substeps": a.substeps,
                        "integrator": "RK4 per substep on (v, unit quaternion, W): W and the q accumulation in float64, stage quaternions in "
                                      "float32; substeps x ceil(max|W|/16 rad/s) per wavefront", "state_layout": a.layout, "io_dtype": "f32",
                        "auto_reset": auto_reset, "done_rate_last_step": done_rate, "launch_mode": a.mode,
-                       "parallelism": f"env-shard x{n_gpus}, no collective", "state_finite": finite,
+                       "parallelism": f"env-shard x{n_gpus}, no collective" + (f" (strong scaling: {G} envs cut at multiples of 64; rank 0 holds {N})"
+                                                                                       if a.scaling == "strong" else ""), "state_finite": finite,
                        "n_ranks_rccl": n_ranks_rccl},
             "timing": {"clock": "HIP events on the launch stream around the K steps of one repetition; median over repetitions, max over ranks",
                        "repetitions": reps, "timed_ms_total": float(sum(dev_ms)) * copies, "lead_in_steps_untimed": n_lead,
@@ -436,6 +467,10 @@ def main():
                          # than ~6 us; both clocks are listed, `achieved` uses this run's HIP events
                          "committed_profile": {k: (traffic or {}).get(k) for k in ("rocprofv3_kernel_mean_us", "rocprofv3_kernel_median_us",
                                                                                      "bench_py_us_per_step_under_rocprofv3", "valu")},
+                         # the SAME algorithmic bytes on the committed profile's clock (rocprofv3 --kernel-trace mean of this configuration
+                         # under profiles/): what follows from profiles/ alone; null when no profile of this configuration is committed
+                         "frac_profile_clock": (algo * N * H / (traffic["rocprofv3_kernel_mean_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                                                if traffic and traffic.get("rocprofv3_kernel_mean_us") else None),
                          "algorithmic_bytes_per_env_step": algo, "layout_bytes_per_env_step": layout,
                          "achieved_layout_GBs": layout * N / (launch_us * 1e-6) / 1e9,
                          "note": "algorithmic bytes = SURVEY.md 8(d) (165 B + 24 B per-env params for Quad-v0); "

@@ -17,6 +17,7 @@ KIND_QUAD, KIND_COUPLED, KIND_DECOUPLED = 0, 1, 2
 KIND_ID = {"quad": KIND_QUAD, "coupled": KIND_COUPLED, "decoupled": KIND_DECOUPLED}
 FLAG_AUTO_RESET, FLAG_EVAL_RESET, FLAG_NO_UDM = 1, 2, 4
 FLAG_FORCE_HELPER, FLAG_NO_HELPER = 8, 16   # launch-rule overrides (speed only)
+FLAG_CALLER_RESETS = 32                     # the caller resets every done env before stepping it again
 ABI_VERSION = 12
 GOAL_EXTERNAL, GOAL_MODE0, GOAL_MODE1, GOAL_MODE6 = 0, 1, 2, 3
 GOAL_ID = {None: 0, 0: 1, 1: 2, 6: 3}  # TrajectoryGenerator mode -> QR_GOAL_*
@@ -26,7 +27,7 @@ ERRORS = {-1: "QR_E_NULL: a required pointer is NULL", -2: "QR_E_KIND: bad env k
           -3: "QR_E_SIZE: bad num_envs / substeps / n_steps / coefficients", -4: "QR_E_ALIGN: buffer not 16-byte aligned"}
 
 # every symbol include/quadrotor_hip.h declares
-SYMBOLS = ("qr_step", "qr_rollout", "qr_rollout_actor", "qr_error_obs", "qr_reset", "qr_get_state", "qr_set_state",
+SYMBOLS = ("qr_step", "qr_rollout", "qr_rollout_actor", "qr_error_obs", "qr_reset", "qr_get_state", "qr_set_state", "qr_check_state",
            "qr_traj_start", "qr_get_desired", "qr_gae",
            "qr_default_coeffs", "qr_abi_version", "qr_step_kernel_info")
 
@@ -110,6 +111,8 @@ def load():
     lib.qr_get_state.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p]
     lib.qr_set_state.restype = C.c_int
     lib.qr_set_state.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.qr_check_state.restype = C.c_int
+    lib.qr_check_state.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.qr_traj_start.restype = C.c_int
     lib.qr_traj_start.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p, C.c_void_p]
     lib.qr_get_desired.restype = C.c_int

@@ -5,7 +5,11 @@ loops and the reference's algos/ (TD3/SAC/PPO) work unchanged on top of the HIP 
     4th return False; 5th {} (QuadEnv.step, gym_rotor/envs/quad.py:142-168).
 
 Each adapter owns a QuadVecEnv(num_envs=1); every call crosses to the GPU and syncs, so this
-is for compatibility/eval, not throughput.
+is for compatibility/eval, not throughput — and therefore defaults to the REFERENCE-GRADE arithmetic:
+layout='f64' (all-float64 state and RK4) with 4 substeps, one-step error 3.5e-11 against the reference's
+DOP853 instead of the batched default's 1e-7 (float32 words of x, v), 1800-step closed-loop flights within
+1e-8 (tests/test_closedloop_td3.py::test_compat_adapter_replays_the_eight_shaped_flight).  Pass layout= /
+substeps= to get the batched engine's own arithmetic.
 """
 from __future__ import annotations
 
@@ -23,6 +27,8 @@ class _SingleEnv:
     def __init__(self, render_mode: Optional[str] = None, **kwargs):
         if self._kind == "quad":
             kwargs.setdefault("obs_rows", True)
+        kwargs.setdefault("layout", "f64")     # speed is irrelevant for one env: the reference-grade mode
+        kwargs.setdefault("substeps", 4)
         self.vec = QuadVecEnv(kind=self._kind, num_envs=1, **kwargs)
         v = self.vec
         for name in ("dt", "freq", "g", "x_lim", "v_lim", "W_lim", "euler_lim", "eIx_lim", "eIb1_lim", "sat_sigma",

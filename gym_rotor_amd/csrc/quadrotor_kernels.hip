@@ -1045,6 +1045,7 @@ __global__ __launch_bounds__(64) void set_state_kernel(const Args a) {
     if (a.status) atomicAdd(a.status, 1);
     return;
   }
+  if (a.store_goal) return;  // (qr_check_state: the same decision, nothing written)
 #pragma unroll
   for (int j = 0; j < 4; ++j) w.q[j] = (QW)q[j];
   store_state<XV, QW>(a, (int64_t)blockIdx.x * 64, threadIdx.x, w);
@@ -1257,8 +1258,9 @@ static const Tuning& tuning() {
 }
 
 // Which instantiation a launch gets (shared by launch_kind and qr_step_kernel_info).
+// (in regime for sure: done envs are re-sampled — in the launch, or by the caller before the next step (QR_FLAG_CALLER_RESETS))
 static inline bool wants_adapt(const Args& a) {
-  return a.c.inv_w_adapt > 0 && (!(a.flags & QR_FLAG_AUTO_RESET) || a.c.inv_w_adapt * a.c.W_lim * 2.5 > 1.0);
+  return a.c.inv_w_adapt > 0 && (!(a.flags & (QR_FLAG_AUTO_RESET | QR_FLAG_CALLER_RESETS)) || a.c.inv_w_adapt * a.c.W_lim * 2.5 > 1.0);
 }
 static inline bool helper_choice(const Args& a, unsigned tiles, unsigned limit) {  // (the instantiation exists: rule, or the env's override)
   if (a.flags & QR_FLAG_NO_HELPER) return false;
@@ -1538,6 +1540,19 @@ int qr_set_state(const QrEnv* env, const double* rows, const uint8_t* mask, int3
   if (int rc = qr::fill_env(a, env)) return rc;
   if (!rows) return QR_E_NULL;
   a.rows_in = rows; a.mask = mask; a.status = rejected;
+  const unsigned grid = (unsigned)((a.n + 63) / 64);
+  if (grid == 0) return 0;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  QR_DISPATCH_LAYOUT(env->layout, (qr::launch_set_state<XV, QW>(a, grid, s)));
+  return (int)hipGetLastError();
+}
+
+int qr_check_state(const QrEnv* env, const double* rows, const uint8_t* mask, int32_t* rejected, void* stream) {
+  qr::Args a{};
+  if (int rc = qr::fill_env(a, env)) return rc;
+  if (!rows || !rejected) return QR_E_NULL;
+  a.rows_in = rows; a.mask = mask; a.status = rejected;
+  a.store_goal = 1;  // dry run: count, write nothing
   const unsigned grid = (unsigned)((a.n + 63) / 64);
   if (grid == 0) return 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

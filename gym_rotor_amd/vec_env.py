@@ -99,6 +99,11 @@ class QuadVecEnv:
     use_UDM         per-env domain randomisation at reset (quad.py:359-404)
     auto_reset      re-sample terminated/truncated envs inside the step launch; the returned
                     observation is then the first observation of the new episode
+    reset_on_done   (without auto_reset) a promise: the caller resets every env that step() reports terminated / truncated
+                    before stepping it again — the reference's own training loop (main.py:183-186, 212-230).  No env then
+                    starts a step outside the termination bounds, the rate-adaptive path cannot trigger, and step() runs the
+                    kernel compiled without it: the same arithmetic, bit for bit, as with auto_reset, 8 % faster than the
+                    free-run default.  Leave False for free runs / evaluation flights that fly on after termination
     max_episode_steps  >0 sets truncated when an episode reaches that many steps
     env_offset      global index of local env 0 (multi-GPU sharding; part of the RNG key)
     goal_mode       None: goals come from set_goal_state() (hover default).  0 / 1 / 6: the reference's
@@ -129,7 +134,7 @@ class QuadVecEnv:
                  env_offset: int = 0, want_raw_reward: bool = False, obs_rows: Optional[bool] = None,
                  field_stride: Optional[int] = None, goal_mode: Optional[int] = None, w_adapt: float = 16.0,
                  constants: Optional[QuadConstants] = None, final_obs: bool = False,
-                 helper: Optional[bool] = None, autotune: bool = False):
+                 helper: Optional[bool] = None, autotune: bool = False, reset_on_done: bool = False):
         if kind not in KINDS:
             raise ValueError(f"kind must be one of {KINDS}, got {kind!r}")
         if num_envs < 1:
@@ -155,6 +160,9 @@ class QuadVecEnv:
         self.auto_reset, self.max_episode_steps = bool(auto_reset), int(max_episode_steps)
         self.env_offset, self.seed = int(env_offset), self._check_seed(seed)
         self._helper = helper
+        self.reset_on_done = bool(reset_on_done)
+        if self.reset_on_done and auto_reset:
+            raise ValueError("reset_on_done is the caller's promise for auto_reset=False; with auto_reset=True the launch resets itself")
         c = self.constants = constants or QuadConstants(UDM_percentage=UDM_percentage)
 
         # ---- attributes the reference's callers read (trajectory_generator.py:44-46,
@@ -266,6 +274,7 @@ class QuadVecEnv:
         e.max_episode_steps = self.max_episode_steps
         e.flags = (_lib.FLAG_AUTO_RESET if self.auto_reset else 0) | (0 if self.use_UDM else _lib.FLAG_NO_UDM)
         e.flags |= {None: 0, True: _lib.FLAG_FORCE_HELPER, False: _lib.FLAG_NO_HELPER}[self._helper]
+        e.flags |= _lib.FLAG_CALLER_RESETS if self.reset_on_done else 0
         o.obs0, o.obs1, o.reward, o.reward_raw = _ptr(self._obs0), _ptr(self._obs1), _ptr(self._reward), _ptr(self._reward_raw)
         o.done, o.truncated = _ptr(self._done), (_ptr(self._trunc) if self._steps is not None else None)
         o.final_obs0, o.final_obs1 = _ptr(self._final0), _ptr(self._final1)
@@ -577,39 +586,47 @@ class QuadVecEnv:
         """Inject states (and optionally integrator terms / parameters): [N,18] / [N,8] / [N,6]; with
         `mask` only the masked envs change (state, integ and params alike).  R goes through the
         reference's ensure_SO3 rule and is stored as a unit quaternion.  A row whose attitude block
-        has no nearest rotation (det R <= 0, NaN/Inf) is rejected: that env keeps its state, and ValueError is
-        raised BEFORE any integrator terms / parameters are applied (to any env) — the other rows' states are set."""
+        has no nearest rotation (det R <= 0, NaN/Inf) makes the WHOLE call fail: the rows are validated first
+        (qr_check_state: the kernel's own test, nothing written) and ValueError is raised before any state,
+        integrator term or parameter of any env has changed."""
         s = torch.as_tensor(state, device=self.device).to(torch.float64).contiguous()
         if tuple(s.shape) != (self.num_envs, 18):
             raise ValueError(f"state must be [{self.num_envs}, 18]")
         m = None if mask is None else torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
         if m is not None and tuple(m.shape) != (self.num_envs,):
             raise ValueError("mask must be a [num_envs] tensor")
+        sel = None if m is None else m.bool()[None, :]
+
+        def rows_for(dst_fields, rows, what):   # shape checks BEFORE anything is written
+            src = torch.as_tensor(rows, device=self.device).to(torch.float32)
+            if tuple(src.shape) != (self.num_envs, dst_fields):
+                raise ValueError(f"{what} must be [{self.num_envs}, {dst_fields}]")
+            return src.t()
+
+        integ_src = rows_for(8, integ, "integ") if (integ is not None and self._integ is not None) else None
+        params_src = rows_for(6, params, "params") if params is not None else None
         self._rejected.zero_()
         with self._on_device():
-            _lib.check(self._lib.qr_set_state(C.byref(self._cenv), s.data_ptr(), _ptr(m), self._rejected.data_ptr(), self._stream()), "qr_set_state")
-        self._last_obs = None
+            _lib.check(self._lib.qr_check_state(C.byref(self._cenv), s.data_ptr(), _ptr(m), self._rejected.data_ptr(), self._stream()), "qr_check_state")
         bad = int(self._rejected.item())  # off the hot path: one host sync per injection
         if bad:
             raise ValueError(f"set_state: {bad} row(s) rejected — the attitude block has det R <= 0 or non-finite entries "
-                             "(no nearest rotation); those envs keep their previous state, and no integrator terms / "
-                             "parameters were applied")
-        sel = None if m is None else m.bool()[None, :]
+                             "(no nearest rotation); nothing was applied: every env keeps its state, integrator terms and parameters")
+        with self._on_device():
+            _lib.check(self._lib.qr_set_state(C.byref(self._cenv), s.data_ptr(), _ptr(m), self._rejected.data_ptr(), self._stream()), "qr_set_state")
+        self._last_obs = None
 
-        def put(dst, rows):
-            src = torch.as_tensor(rows, device=self.device).to(torch.float32).t()
-            if tuple(src.shape) != tuple(dst.shape):
-                raise ValueError(f"expected [{self.num_envs}, {dst.shape[0]}] rows")
+        def put(dst, src):
             dst.copy_(src if sel is None else torch.where(sel, src, dst))
 
-        if integ is not None and self._integ is not None:
-            put(self._integ, integ)
-        if params is not None:
+        if integ_src is not None:
+            put(self._integ, integ_src)
+        if params_src is not None:
             if self._params is None:
                 self._params = self._soa(6, torch.float32)
                 self._params.copy_(torch.tensor(self.constants.nominal_params, dtype=torch.float32, device=self.device)[:, None].expand(6, self.num_envs))
                 self._cenv.params = self._params.data_ptr()
-            put(self._params, params)
+            put(self._params, params_src)
 
     def final_observation(self):
         """Terminal observation rows of the envs re-sampled by the LAST step() (final_obs=True): rows of
@@ -634,7 +651,9 @@ class QuadVecEnv:
         sd = dict(sd)
         self._policy_steps = int(sd.pop("policy_steps", 0))
         if "seed" in sd:
-            self.seed = self._check_seed(sd.pop("seed"))
+            # (checkpoints written before seeds were range-checked may hold a negative / >= 2^63 seed, which the env then masked
+            # into the Philox key's 63 usable bits itself: do the same, so that such a checkpoint still loads and resumes its stream)
+            self.seed = self._check_seed(int(sd.pop("seed")) & (2 ** 63 - 1))
             self._cenv.seed = self.seed
         last = sd.pop("last_obs", None)
         self._last_obs = None

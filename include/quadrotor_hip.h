@@ -77,6 +77,12 @@ extern "C" {
 #define QR_FLAG_AUTO_RESET   1u /* re-sample a done env inside the same launch (train distribution) */
 #define QR_FLAG_EVAL_RESET   2u /* resets use env_type='eval' (quad.py:352-356) instead of 'train' */
 #define QR_FLAG_NO_UDM       4u /* resets keep nominal parameters (use_UDM False / eval)            */
+#define QR_FLAG_CALLER_RESETS 32u /* WITHOUT QR_FLAG_AUTO_RESET: the caller promises the reference's own loop (main.py:183-186,
+                                    212-230): every env a step reports done is reset (qr_reset / qr_set_state) before it is stepped
+                                    again.  Then no env ever starts a step outside the termination bounds, rate adaptivity
+                                    (QrCoeffs.w_adapt) cannot trigger, and the launcher takes the kernel compiled without it — the
+                                    same arithmetic, bit for bit, as with QR_FLAG_AUTO_RESET (4.03 instead of 4.39 us per 65 536-env
+                                    launch).  A caller that steps done envs on anyway only loses the adaptivity: fixed substeps. */
 /* Launch-rule overrides (speed only: no choice changes a result bit).  By default qr_step / qr_rollout(_actor) decide from the
  * grid size whether every 64-env tile gets a second, helper wavefront, with thresholds measured on MI355X (environment variables
  * QR_HELPER_GRID, QR_HELPER_GRID_WRAP, QR_HELPER_GRID_ROLLOUT override them per process, read once); these bits pin the choice
@@ -268,6 +274,11 @@ int qr_get_state(const QrEnv* env, double* rows, void* stream);
  * REJECTED (that env keeps its previous state) and counted in *rejected (device int32, optional,
  * zero it before the call; the host wrapper raises when it is non-zero). */
 int qr_set_state(const QrEnv* env, const double* rows, const uint8_t* mask, int32_t* rejected, void* stream);
+
+/* Dry run of qr_set_state: counts in *rejected (device int32, required, zero it before the call) the rows qr_set_state would
+ * reject — the same test on the same data — and writes NOTHING.  Lets a caller that injects states together with other
+ * per-env data (integrator terms, parameters) refuse the whole injection before any of it is applied. */
+int qr_check_state(const QrEnv* env, const double* rows, const uint8_t* mask, int32_t* rejected, void* stream);
 
 /* Replaces TrajectoryGenerator.mark_traj_start(state) (utils/trajectory_generator.py:176-204)
  * plus the episode-start branch of calculate_desired (mode 0 :141-148: b1d = Rz(theta) b1_proj,

@@ -259,10 +259,33 @@ def test_set_state_raises_before_applying_integrators_and_params():
     env.reset("train")
     s = _np(env.get_current_state())
     s[5, 6:15] = 0.0
-    integ0, prm0 = env._integ.clone(), env._params.clone()
+    s[:, 0] += 0.25                                  # (every OTHER row is a valid, different state)
+    integ0, prm0, st0 = env._integ.clone(), env._params.clone(), env.get_current_state()
     with pytest.raises(ValueError, match="1 row"):
         env.set_state(s, integ=np.ones((n, 8)), params=np.full((n, 6), 2.0))
-    assert torch.equal(env._integ, integ0) and torch.equal(env._params, prm0)
+    # validated first (qr_check_state, a dry run of the kernel's own test): NOTHING changed — not even the valid rows' states
+    assert torch.equal(env._integ, integ0) and torch.equal(env._params, prm0) and torch.equal(env.get_current_state(), st0)
+    with pytest.raises(ValueError, match="integ must be"):
+        env.set_state(_np(st0), integ=np.ones((n, 7)))
+    assert torch.equal(env.get_current_state(), st0)
+    s[5] = _np(st0)[5]
+    env.set_state(s, integ=np.ones((n, 8)))           # the same injection with the bad row repaired goes through
+    assert torch.allclose(env.get_current_state()[:, 0], st0[:, 0] + torch.where(torch.arange(n, device="cuda") == 5, 0.0, 0.25).double(), atol=1e-6)
+    assert bool((env._integ == 1).all())
+
+
+def test_legacy_checkpoint_seed_is_masked_not_refused():
+    """A checkpoint from before seeds were range-checked may carry a negative or >= 2^63 seed (the env masked it into the key
+    itself then): load_state_dict maps it the same way instead of refusing the checkpoint."""
+    env = _env("quad", 128, seed=5)
+    env.reset("train")
+    sd = env.state_dict()
+    for legacy in (-3, 2 ** 63 + 17):
+        sd["seed"] = legacy
+        env.load_state_dict(sd)
+        assert env.seed == legacy & (2 ** 63 - 1) and env._cenv.seed == env.seed
+        env.reset("train")                      # the stream keyed by the masked seed is usable
+        assert bool(torch.isfinite(env.get_current_state()).all())
 
 
 def test_torch_custom_op_policy_rollout_and_gae():

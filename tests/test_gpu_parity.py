@@ -122,8 +122,11 @@ def test_trajectory_golden_1000_steps(kind, layout, mode, golden):
         n_done_diff += int(dd.sum())
         worst_rwd = max(worst_rwd, float(np.abs(_np(rwd).astype(np.float64) - d["rewards"][t])[~dd].max()))
     print(f"{kind}/{layout}/{mode}: state {worst:.2e} obs {worst_obs:.2e} reward {worst_rwd:.2e} done-diffs {n_done_diff}")
-    assert worst <= 1e-5
-    assert worst_obs <= 1e-5
+    # The north-star bar is 1e-5; the GUARD is 8e-6: the default layout's thinnest margin is here (coupled free run, observation
+    # words of x, v at the float32 ulp: 7.25e-6 measured on three boxes in rounds 3-4) and an instruction-saving edit of the
+    # stage arithmetic must not eat what is left of it unnoticed.
+    assert worst <= 8e-6
+    assert worst_obs <= 8e-6
     assert worst_rwd <= 1e-5
     assert n_done_diff <= 2
 
@@ -437,7 +440,7 @@ def test_trajectory_vs_oracle_256_envs_1000_steps(kind, layout, tol_state, tol_o
     ro = env.rollout(torch.from_numpy(acts).cuda())      # one launch, bit-identical to 1000 steps
     got = _np(env.get_current_state())
     s, integ = state, np.zeros((n, 8))
-    worst_obs, where = 0.0, None
+    worst_obs, where, worst_elem = 0.0, None, 0.0
     for t in range(T):
         o = orc.step_batch(kind, s, acts[t].astype(np.float64), params, None, integ)
         s, integ = o["state"], o["integ"]
@@ -448,11 +451,15 @@ def test_trajectory_vs_oracle_256_envs_1000_steps(kind, layout, tol_state, tol_o
                 # (relative to the row's own scale: far out of regime |x| reaches 150 m, where ONE float32 ulp of an
                 # observation word is 1.5e-5 — SURVEY.md 8(d)'s "obs <= 1e-5 abs" is a statement about in-regime rows, |.| <= 1)
                 e = np.abs(g - r) / np.maximum(np.abs(r).max(-1, keepdims=True), 1.0)
+                # (... and every element against ITS OWN magnitude at the looser 1e-4: the row-scale figure alone would let the
+                # small words of a far-out row — attitude, eW — drift by 1e-3 unnoticed)
+                worst_elem = max(worst_elem, float((np.abs(g - r) / np.maximum(np.abs(r), 1.0)).max()))
                 if e.max() > worst_obs:
                     worst_obs, where = float(e.max()), (t, k) + tuple(int(i) for i in np.unravel_index(e.argmax(), e.shape))
     err = grouped_rel_err(got, s)
-    print(f"256 envs x 1000 steps {kind}/{layout}: final-state grouped error {err:.2e}, obs {worst_obs:.2e} at (t, obs, env, col) = {where}")
-    assert err <= tol_state and worst_obs <= tol_obs
+    print(f"256 envs x 1000 steps {kind}/{layout}: final-state grouped error {err:.2e}, obs {worst_obs:.2e} at (t, obs, env, col) = {where}, "
+          f"per element {worst_elem:.2e}")
+    assert err <= tol_state and worst_obs <= tol_obs and worst_elem <= 1e-4
 
 
 @pytest.mark.parametrize("kind", KINDS)
@@ -508,6 +515,42 @@ def test_adaptive_kernel_in_regime(kind):
         else:
             assert grouped_rel_err(out[0][0], out[1][0]) <= 1e-6 and not np.array_equal(out[0][0], out[1][0])   # (measured 2.3e-7)
             assert np.abs(out[0][1] - out[1][1]).max() <= 1e-5 and (out[0][2] != out[1][2]).mean() <= 1e-3
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_reset_on_done_promise_takes_the_plain_kernel(kind):
+    """QuadVecEnv(reset_on_done=True) (QR_FLAG_CALLER_RESETS) is the caller's promise of the reference's own loop — reset every env
+    that step() reports done before stepping it again (main.py:183-186) — under which no env leaves the regime and the launcher
+    runs the kernel compiled WITHOUT rate adaptivity: the same bits as an env with w_adapt = 0 driven by the same loop (and hence
+    as the in-launch-reset mode's arithmetic), through ~1000 masked resets; the default (free-run) env beside them runs the
+    rate-adaptive delta-form kernel: the same flight to ~1e-9 per step, not the same bits."""
+    n, T = 2000, 150
+    A = orc.ACTION_DIM[kind]
+    g = torch.Generator(device="cuda"); g.manual_seed(12)
+    envs = [_env(kind, n, seed=4, reset_on_done=True), _env(kind, n, seed=4, w_adapt=0.0), _env(kind, n, seed=4)]
+    for e in envs:
+        e.reset("train")
+        if kind != "quad":
+            e.get_norm_error_state()
+    resets = 0
+    for t in range(T):
+        act = torch.rand(n, A, device="cuda", generator=g) * 2 - 1
+        outs = [e.step(act) for e in envs]
+        (oa, ra, da, _, _), (ob, rb, db, _, _), (oc, rc, dc, _, _) = outs
+        assert torch.equal(ra, rb) and torch.equal(da, db)
+        for x, y in zip(_obs_list(oa), _obs_list(ob)):
+            assert (x is None and y is None) or torch.equal(x, y)
+        mask = da.reshape(n, -1).any(dim=1)
+        resets += int(mask.sum())
+        if bool(mask.any()):
+            for e in envs:          # the promise, kept: done envs start a new episode before the next step
+                e.reset("train", mask=mask | dc.reshape(n, -1).any(dim=1))
+    assert resets > 500
+    sa, sb, sc = (_np(e.get_current_state()) for e in envs)
+    assert np.array_equal(sa, sb)
+    assert grouped_rel_err(sa, sc) <= 1e-6 and not np.array_equal(sa, sc)
+    with pytest.raises(ValueError):
+        _env(kind, 8, auto_reset=True, reset_on_done=True)
 
 
 def test_one_million_envs_ten_substeps_and_shard_equivalence():

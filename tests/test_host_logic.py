@@ -402,6 +402,30 @@ def test_bench_multi_rank_control_flow():
     assert "cpu_baseline" not in d                           # N = 1 only
 
 
+def test_bench_presets_and_scaling_flags_without_gpu(monkeypatch):
+    """bench.py's argument layer (no GPU): --config k sets BASELINE.json configs[k]'s per-GPU shape, --scaling strong takes the
+    preset's named total (or --global-envs, or --envs) as the fixed global batch."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+
+    def parse(*argv):
+        monkeypatch.setattr(sys, "argv", ["bench.py", *argv])
+        return bench.parse()
+
+    a = parse()
+    assert (a.kind, a.envs, a.substeps, a.scaling, a.config) == ("quad", 65536, 1, "weak", 0)
+    a = parse("--config", "3")
+    assert (a.kind, a.envs, a.substeps, a.scaling) == ("decoupled", 32768, 1, "weak")
+    a = parse("--config", "4", "--scaling", "strong")
+    assert (a.kind, a.envs, a.substeps, a.global_envs) == ("quad", 131072, 10, 1048576) and a.action_batches == 32
+    a = parse("--config", "3", "--scaling", "strong", "--gpus", "8")
+    assert a.global_envs == 262144
+    assert parse("--scaling", "strong").global_envs == 65536 and parse("--scaling", "strong", "--envs", "4096").global_envs == 4096
+    assert parse("--scaling", "strong", "--global-envs", "777").global_envs == 777
+    assert parse("--config", "2").kind == "coupled" and parse("--config", "1").envs == 65536
+
+
 def test_bench_gpus_n_spawns_its_own_ranks_without_gpu(monkeypatch):
     """`bench.py --gpus 4` with no WORLD_SIZE: the ranks are started as child processes through torch.distributed.run
     (same arguments, 127.0.0.1 rendezvous) and the children's exit code is the caller's; under a launcher nothing is spawned."""
@@ -446,6 +470,33 @@ def test_bench_gpus_2_without_a_launcher():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2 * d["config"]["envs_per_gpu"] == 131072
     assert d["dtype"] == "mixed f32/f64" and "cpu_baseline" not in d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags,want", [
+    (["--scaling", "strong"], dict(scaling="strong", kind="quad", global_envs=65536, envs_per_gpu=32768, substeps=1, baseline=None)),
+    (["--config", "3"], dict(scaling="weak", kind="decoupled", global_envs=65536, envs_per_gpu=32768, substeps=1, baseline="configs[3]")),
+    (["--config", "4", "--scaling", "strong"], dict(scaling="strong", kind="quad", global_envs=1048576, envs_per_gpu=524288, substeps=10, baseline="configs[4]")),
+    (["--config", "2", "--scaling", "strong", "--global-envs", "100000"], dict(scaling="strong", kind="coupled", global_envs=100000, envs_per_gpu=50048, substeps=1, baseline="configs[2]")),
+])
+def test_bench_presets_and_strong_scaling_with_2_ranks(flags, want):
+    """SURVEY.md 8(e)'s other runs, one flag each, through the same 2-rank path as above (the ranks share this box's GPU over gloo):
+    `--config k` = BASELINE.json configs[k] in its per-GPU shape, `--scaling strong` = a fixed global batch cut into 64-aligned
+    shards (shard_range), reported as such; `value` is always the GLOBAL batch over the max-over-ranks time."""
+    import json
+    env = dict(os.environ, QR_BENCH_BACKEND="gloo", PYTHONPATH=ROOT)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "4", "--extras", "0"] + flags,
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and d["scaling"] == want["scaling"] and c["kind"] == want["kind"] and c["substeps"] == want["substeps"]
+    assert c["global_envs"] == want["global_envs"] and c["envs_per_gpu"] == want["envs_per_gpu"]
+    assert (c["baseline_config"] or "").startswith(want["baseline"] or "") and (want["baseline"] is not None or c["baseline_config"] is None)
+    assert abs(d["value"] - want["global_envs"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"] and c["state_finite"]
 
 
 @pytest.mark.gpu

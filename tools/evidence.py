@@ -54,6 +54,11 @@ for n in (65536, 1048576):
         env = QuadVecEnv("quad", n, device=dev, auto_reset=False, w_adapt=wa)
         out[f"quad {n} free run in regime, w_adapt={wa:g}"] = per_launch_us(env, fresh_each=True)
         del env
+# ... and with the caller's promise to reset on done (QR_FLAG_CALLER_RESETS): the plain kernel without in-launch resets
+for n in (65536, 1048576):
+    env = QuadVecEnv("quad", n, device=dev, auto_reset=False, reset_on_done=True)
+    out[f"quad {n} free run in regime, reset_on_done=True (w_adapt=16)"] = per_launch_us(env, fresh_each=True)
+    del env
 # substeps
 for n in (131072, 1048576):
     for sub in (1, 2, 10):

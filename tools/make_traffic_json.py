@@ -66,6 +66,21 @@ for cfg in CONFIGS:
     if mb:
         toks = mb.group(1).split()
         prof["sq_counters_raw"] = {toks[i]: float(toks[i + 1]) for i in range(0, len(toks) - 1, 2)}
+    if mi and ka:
+        # What a VALU instruction really costs (round 4: profiles/r04/ab_persist.txt).  The "2 cycles per wave64 instruction" above is
+        # the PACKED-fp32 peak; the repaired microbenchmark's wall clock (profiles/r04/valu_microbench.json, 4 waves per SIMD) gives
+        # 1.39 ns per v_fma_f32, 2.12 ns per v_fma_f64, ~1.9 ns per conversion / integer multiply per SIMD — 1.55 ns for the substep's
+        # mix (34 f64 + 132 f32).  Two readings of how VALU-bound a launch is, both printed:
+        #   valu_time_frac_microbench = VALU wave-instructions x 1.55 ns / (1024 SIMDs x launch duration)
+        #   valu_active_frac          = SQ_ACTIVE_INST_VALU (one count per instruction = 4 clocks of its SIMD) x 4 / (1024 SIMDs x duration x 2.4 GHz)
+        dur_s = int(ka.group(1)) * 1e-9
+        v = prof["valu"]
+        v["valu_time_frac_microbench"] = round(v["waves_per_launch"] * v["valu_insts_per_wave"] * 1.55e-9 / (1024 * dur_s), 4)
+        act = prof.get("sq_counters_raw", {}).get("SQ_ACTIVE_INST_VALU")
+        if act:
+            v["valu_active_frac"] = round(act * 4 / (1024 * dur_s * 2.4e9), 4)
+        v["issue_slots_used_frac_note"] = ("issue_slots_used_frac prices an instruction at 2 clocks (the packed-fp32 peak) and UNDERCOUNTS: see "
+                                           "valu_time_frac_microbench / valu_active_frac")
     out.append({**prof, "kind": kind, "envs": envs, "layout": layout, "auto_reset": ar, "substeps": sub, "workload": workload,
                 "env_steps_per_launch": horizon, "FETCH_SIZE_KB_raw": fetch,
                 "WRITE_SIZE_KB": write, "bytes_per_launch": b, "bytes_per_env_step": round(b / envs / horizon, 1),
