@@ -527,7 +527,7 @@ def test_reset_on_done_promise_takes_the_plain_kernel(kind):
     n, T = 2000, 150
     A = orc.ACTION_DIM[kind]
     g = torch.Generator(device="cuda"); g.manual_seed(12)
-    envs = [_env(kind, n, seed=4, reset_on_done=True), _env(kind, n, seed=4, w_adapt=0.0), _env(kind, n, seed=4)]
+    envs = [_env(kind, n, seed=4, obs_rows=True, reset_on_done=True), _env(kind, n, seed=4, obs_rows=True, w_adapt=0.0), _env(kind, n, seed=4, obs_rows=True)]
     for e in envs:
         e.reset("train")
         if kind != "quad":
@@ -539,7 +539,7 @@ def test_reset_on_done_promise_takes_the_plain_kernel(kind):
         (oa, ra, da, _, _), (ob, rb, db, _, _), (oc, rc, dc, _, _) = outs
         assert torch.equal(ra, rb) and torch.equal(da, db)
         for x, y in zip(_obs_list(oa), _obs_list(ob)):
-            assert (x is None and y is None) or torch.equal(x, y)
+            assert torch.equal(x, y)
         mask = da.reshape(n, -1).any(dim=1)
         resets += int(mask.sum())
         if bool(mask.any()):
@@ -668,7 +668,7 @@ def test_launch_rule_overrides_change_no_bit(kind):
         resets += int(rows.sum())
         for x, y in zip(_obs_list(a.final_observation()), _obs_list(b.final_observation())):
             assert torch.equal(x[rows], y[rows])
-    assert resets > n                                    # (the time limit alone ended every episode once)
+    assert resets >= n                                   # (the time limit alone ended every episode once)
     for e in (b, c):
         assert torch.equal(a.get_current_state(), e.get_current_state())
         for name in ("_params", "_episode", "_steps", "_reset_count", "_integ"):

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Do two builds of the library compute the same bits?  Each build (QR_LIB) steps the same Quad-v0 batch with in-launch
-resets in its own subprocess and prints a digest of state, parameters, rewards, dones, episode and tile counters.
+"""Do two builds of the library compute the same bits?  Each build (QR_LIB) steps the same batch (QR_AB_KIND, default quad; 65 536
+envs) with in-launch resets in its own subprocess and prints a digest of state, integrators, parameters, observation rows, rewards,
+dones, terminal observations, episode and tile counters.
 
-    python tools/ab_equal.py build/ab/A.so build/ab/B.so        (GPU box)
+    [QR_AB_KIND=coupled] python tools/ab_equal.py build/ab/A.so build/ab/B.so        (GPU box)
 """
 import os
 import subprocess
@@ -13,14 +14,22 @@ CHILD = r'''
 import hashlib, sys, torch
 sys.path.insert(0, %r)
 from gym_rotor_amd import QuadVecEnv
-env = QuadVecEnv("quad", 65536, device="cuda", seed=3, auto_reset=True)
+import os
+kind = os.environ.get("QR_AB_KIND", "quad")
+env = QuadVecEnv(kind, 65536, device="cuda", seed=3, auto_reset=True, obs_rows=True, final_obs=True, want_raw_reward=True)
 env.reset("train")
+if kind != "quad":
+    env.get_norm_error_state()
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 h = hashlib.sha256()
 for t in range(300):
-    _, r, d, _, _ = env.step(torch.rand(65536, 4, device="cuda", generator=g) * 2 - 1)
-    if t %% 50 == 49:
-        for x in (env.get_current_state(), env._params, r, d, env._episode, env._reset_count):
+    o, r, d, _, _ = env.step(torch.rand(65536, env.action_dim, device="cuda", generator=g) * 2 - 1)
+    if t %% 10 == 9:
+        obs = [o] if isinstance(o, torch.Tensor) else list(o)
+        fin = env.final_observation()
+        fin = [fin] if isinstance(fin, torch.Tensor) else list(fin)
+        rows = d.reshape(65536, -1).any(dim=1)
+        for x in [env.get_current_state(), env._params, r, env._reward_raw, d, env._episode, env._reset_count] + obs + [f[rows] for f in fin] + ([env._integ] if env._integ is not None else []):
             h.update(x.cpu().numpy().tobytes())
 print(h.hexdigest(), int(env._episode.sum()))
 ''' % ROOT
