@@ -1,9 +1,9 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): everything DESIGN.md §5 cites, into gpurun_out/<round>/ (copy to profiles/<round>/).
-#   tools/collect_evidence.sh r03 [profiles|bench|ab|tests|all]
+#   tools/collect_evidence.sh r04 [profiles|bench|ab|tests|all]
 # The measurement-only builds are NOT pushed with the repo (.gpurunignore: build/evidence/): they are built here first.
 set -u
-RND=${1:-r03}; WHAT=${2:-all}
+RND=${1:-r04}; WHAT=${2:-all}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$RND
 EV=build/evidence
@@ -39,6 +39,7 @@ b decoupled262144 --kind decoupled --envs 262144 --action-batches 32 --steps 300
 b coupled1M --kind coupled --envs 1048576 --action-batches 16 --steps 100 ; b decoupled1M --kind decoupled --envs 1048576 --action-batches 16 --steps 100
 b rollout_quad65536_T100 --workload rollout --horizon 100 --steps 2000
 b rollout_actor_coupled65536_T32 --workload rollout_actor --kind coupled --horizon 32 --steps 960
+b config2 --config 2 ; b config3 --config 3 ; b config4 --config 4
 python3 bench.py --cpu-seconds 12 > "$OUT/bench_full_line.json" 2>> "$OUT/bench.err"
 python3 bench.py --steps 20 --warmup 5 --cpu-seconds 12 > "$OUT/bench_full_line_steps20.json" 2>> "$OUT/bench.err"
 fi
@@ -54,6 +55,8 @@ $EV/vmem_mb > "$OUT/vmem_width_microbench.json" 2> "$OUT/vmem_width_microbench.e
 $EV/first_load_mb > "$OUT/first_load_microbench.json" 2> "$OUT/first_load_microbench.err"
 timeout 120 $EV/resident_mb > "$OUT/resident_pacing_microbench.json" 2> "$OUT/resident_pacing_microbench.err"
 python3 tools/ppo_rollout_bench.py > "$OUT/ppo_rollout.json" 2> "$OUT/ppo_rollout.err"
+python3 tools/autotune_table.py > "$OUT/autotune_table.txt" 2> "$OUT/autotune_table.err"
+bash tools/resource_usage.sh > "$OUT/resource_usage.txt" 2>/dev/null
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = tests ]; then
 # (4) the parity figures the GPU tests print, and the soak run of the final build

@@ -101,8 +101,11 @@ int main() {
       std::sort(h.begin(), h.begin() + g);
       const double per = (double)h[g / 2] / ((double)ITERS * CH);
       const double waves_per_simd = g / 1024.0;
-      printf("%s{\"instr\": \"%s\", \"waves_per_simd\": %.0f, \"cycles_per_wave_instr\": %.2f, \"cycles_per_instr_per_simd\": %.2f, \"kernel_us\": %.1f}",
-             first ? "" : ",\n", c.name, waves_per_simd, per, per / waves_per_simd, ms * 1e3);
+      // wall clock: the kernel's duration over the instructions one SIMD issued (its waves' ITERS x CH each) — the figure to price a
+      // VALU-bound launch with; the s_memtime "cycles" above tick at their own rate (NOT the 2.4 GHz shader clock)
+      printf("%s{\"instr\": \"%s\", \"waves_per_simd\": %.0f, \"cycles_per_wave_instr\": %.2f, \"cycles_per_instr_per_simd\": %.2f, \"kernel_us\": %.1f, "
+             "\"wall_ns_per_instr_per_simd\": %.3f}",
+             first ? "" : ",\n", c.name, waves_per_simd, per, per / waves_per_simd, ms * 1e3, ms * 1e6 / (waves_per_simd * ITERS * CH));
       first = false;
     }
   }
