@@ -19,8 +19,8 @@ FLAG_AUTO_RESET, FLAG_EVAL_RESET, FLAG_NO_UDM = 1, 2, 4
 FLAG_FORCE_HELPER, FLAG_NO_HELPER = 8, 16   # launch-rule overrides (speed only)
 FLAG_CALLER_RESETS = 32                     # the caller resets every done env before stepping it again
 ABI_VERSION = 12
-GOAL_EXTERNAL, GOAL_MODE0, GOAL_MODE1, GOAL_MODE6 = 0, 1, 2, 3
-GOAL_ID = {None: 0, 0: 1, 1: 2, 6: 3}  # TrajectoryGenerator mode -> QR_GOAL_*
+GOAL_EXTERNAL, GOAL_MODE0, GOAL_MODE1, GOAL_MODE6, GOAL_MODE2, GOAL_MODE3, GOAL_MODE4, GOAL_MODE5 = 0, 1, 2, 3, 4, 5, 6, 7
+GOAL_ID = {None: 0, 0: 1, 1: 2, 6: 3, 2: 4, 3: 5, 4: 6, 5: 7}  # TrajectoryGenerator mode -> QR_GOAL_*
 LAYOUT_ID = {"mixed": 0, "f64": 1, "f32": 2}
 
 ERRORS = {-1: "QR_E_NULL: a required pointer is NULL", -2: "QR_E_KIND: bad env kind",

@@ -1,5 +1,5 @@
 // qr_traj.h — part of the gfx950 quadrotor step library (included by quadrotor_kernels.hip, in this order).
-// Goal generation (utils/trajectory_generator.py modes 0/1/6) and the SoA buffer accessor.
+// Goal generation (utils/trajectory_generator.py modes 0..6) and the SoA buffer accessor.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -16,25 +16,39 @@ namespace qr {
 // control flow, and as an array hipcc kept two of its words in scratch memory.
 // ------------------------------------------------------------------------------------
 struct Traj {
-  float calls = 0.0f, theta_init = 0.0f, p2 = 0.0f, p3 = 0.0f, x0 = 0.0f, x1 = 0.0f, x2 = 0.0f;
-  __device__ __forceinline__ float get(int f) const { return f == 0 ? calls : f == 1 ? theta_init : f == 2 ? p2 : f == 3 ? p3 : f == 4 ? x0 : f == 5 ? x1 : f == 6 ? x2 : 0.0f; }
+  float calls = 0.0f, theta_init = 0.0f, p2 = 0.0f, p3 = 0.0f, x0 = 0.0f, x1 = 0.0f, x2 = 0.0f, p7 = 0.0f;
+  __device__ __forceinline__ float get(int f) const { return f == 0 ? calls : f == 1 ? theta_init : f == 2 ? p2 : f == 3 ? p3 : f == 4 ? x0 : f == 5 ? x1 : f == 6 ? x2 : p7; }
   __device__ __forceinline__ void set(int f, float v) {
     if (f == 0) calls = v; else if (f == 1) theta_init = v; else if (f == 2) p2 = v; else if (f == 3) p3 = v;
-    else if (f == 4) x0 = v; else if (f == 5) x1 = v; else if (f == 6) x2 = v;
+    else if (f == 4) x0 = v; else if (f == 5) x1 = v; else if (f == 6) x2 = v; else p7 = v;
   }
 };
+
+// Modes 2-5 (take-off, landing, stay, circle: trajectory_generator.py:279-416) are STATEFUL: the reference object carries xd, vd, b1d,
+// b1d_dot, Wd and five flags from call to call (a mode writes only the components it moves; manual mode returns before Wd is
+// recomputed).  Here xd, vd, b1d, Wd persist in the env's goal buffer (QrEnv.goal: required for these modes), b1d_dot in traj words
+// 2 and 7, the flags in word 3, x_init (= circle centre) in words 4..6.  Constants of the reference's __init__ (:81-94):
+constexpr float kTakeoffEndHeight = -0.5f, kTakeoffVelocity = -0.05f, kLandingVelocity = 1.0f, kLandingCutoffHeight = -0.25f;
+constexpr float kCircleRadius = 0.7f, kCircleLinearV = 0.4f, kCircleW = 0.4f, kNumCircles = 2.0f;
+enum : int { kTrajStarted = 1, kTrajComplete = 2, kTrajManual = 4, kTrajManualInit = 8, kTrajLanded = 16 };
 
 // mark_traj_start(state) (:176-204) + the episode-start branch of calculate_desired:
 //   mode 0 (:141-148): b1d = Rz(theta) b1_proj, theta ~ U(+-25 deg)
 //   mode 1 (:253-266): x_init = x, t_traj ~ U(2,5), smooth = -ln(0.001)/t_traj, w_b1d ~ U(+-0.15 pi)
 template <typename T, typename X>
-__device__ __forceinline__ void traj_start(const Work<T, X>& w, Traj& tr, int goal_mode, float theta_b1d, float t_traj, float w_b1d) {
+__device__ __forceinline__ void traj_start(Work<T, X>& w, Traj& tr, int goal_mode, float theta_b1d, float t_traj, float w_b1d) {
   const T qw = w.q[0], qx = w.q[1], qy = w.q[2], qz = w.q[3];
   const float b1x = (float)(T(1) - T(2) * (qy * qy + qz * qz)), b1y = (float)(T(2) * (qx * qy + qw * qz));
   const float theta_init = atan2_fast(b1y, b1x);  // update_initial_state (:199-204)
   tr.calls = 0.0f;
   tr.theta_init = theta_init;
-  if (goal_mode == QR_GOAL_MODE0) {
+  tr.p7 = 0.0f;
+  if (goal_mode >= QR_GOAL_MODE2) {  // modes 2-5: no draws; flags cleared, x_init = x (:176-204), and the persistent fields of a FRESH generator
+    tr.p2 = 0.0f; tr.p3 = 0.0f;       // (xd = vd = Wd = 0, b1d = e1, b1d_dot = 0: __init__ :54-55, 67-68 — the reference object would carry the
+    tr.x0 = (float)w.x[0]; tr.x1 = (float)w.x[1]; tr.x2 = (float)w.x[2];   //  previous episode's b1d_dot into this one)
+#pragma unroll
+    for (int f = 0; f < 12; ++f) w.goal[f] = f == 6 ? 1.0f : 0.0f;
+  } else if (goal_mode == QR_GOAL_MODE0) {
     float sn, cs;
     sincos_small(theta_init + theta_b1d, sn, cs);  // Rz(theta) (cos th_i, sin th_i, 0)
     tr.p2 = cs; tr.p3 = sn;
@@ -60,7 +74,81 @@ template <typename T, typename X>
 __device__ __forceinline__ void traj_goal(Work<T, X>& w, Traj& tr, int goal_mode, const Coeffs& c, float (&b1d_dot)[3]) {
   tr.calls += 1.0f;  // update_current_time (:224-229): t = t + dt on every call
   float b1d[3];
-  if (goal_mode == QR_GOAL_MODE0) {  // set_desired_states_to_zero + the b1d drawn at episode start
+  bool keep_wd = false;  // (modes 2-5 in manual mode: calculate_desired returns before the Wd computation, :137-139)
+  if (goal_mode >= QR_GOAL_MODE2) {  // take-off / landing / stay / circle on the persistent fields (see the constants above)
+    const float dtf = 2.0f * c.hdt, t = tr.calls * dtf;
+    int fl = (int)tr.p3;
+    const float xc[3] = {(float)w.x[0], (float)w.x[1], (float)w.x[2]}, vc[3] = {(float)w.v[0], (float)w.v[1], (float)w.v[2]};
+    // get_current_b1 (:215-218): (cos theta, sin theta, 0), theta = atan2(b1[1], b1[0]) — the first column of R(q), flattened and normalised
+    const T qw = w.q[0], qx = w.q[1], qy = w.q[2], qz = w.q[3];
+    const float b1x = (float)(T(1) - T(2) * (qy * qy + qz * qz)), b1y = (float)(T(2) * (qx * qy + qw * qz));
+    const float hinv = __builtin_amdgcn_rsqf(fmaxf(fmaf(b1x, b1x, b1y * b1y), 1e-30f));
+    const float hx = b1x * hinv, hy = b1y * hinv;
+    float xd[3] = {w.goal[0], w.goal[1], w.goal[2]}, vd[3] = {w.goal[3], w.goal[4], w.goal[5]};
+    float bx = w.goal[6], by = w.goal[7], bdx = tr.p2, bdy = tr.p7;
+    auto to_current = [&]() {  // set_desired_states_to_current (:209-212)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { xd[j] = xc[j]; vd[j] = vc[j]; }
+      bx = hx; by = hy;
+    };
+    if (fl & kTrajManual) {  // manual() (:232-250): hold the position taken over at the switch, zero velocity, the heading of the switch
+      if (!(fl & kTrajManualInit)) { to_current(); fl |= kTrajManualInit; }
+      vd[0] = vd[1] = vd[2] = 0.0f;
+      keep_wd = true;
+    } else if (goal_mode == QR_GOAL_MODE2) {  // takeoff (:279-309)
+      if (!(fl & kTrajStarted)) {
+        xd[0] = xc[0]; xd[1] = xc[1]; xd[2] = 0.0f; vd[0] = vd[1] = vd[2] = 0.0f;
+        bx = hx; by = hy;
+        fl |= kTrajStarted;
+      }
+      const float t_traj = (kTakeoffEndHeight - tr.x2) / kTakeoffVelocity;
+      if (t < t_traj) {
+        xd[2] = fmaf(kTakeoffVelocity, t, tr.x2);
+      } else {
+        const float d0 = xd[0] - xc[0], d1 = xd[1] - xc[1], d2 = xd[2] - xc[2];
+        if (fmaf(d0, d0, fmaf(d1, d1, d2 * d2)) < 0.04f * 0.04f) {  // waypoint_reached (:312-318)
+          xd[2] = kTakeoffEndHeight; vd[2] = 0.0f;
+          fl |= kTrajComplete | kTrajManual;  // mark_traj_end(True)
+        }
+      }
+    } else if (goal_mode == QR_GOAL_MODE3) {  // land (:321-349)
+      if (!(fl & kTrajStarted)) { to_current(); fl |= kTrajStarted; }
+      const float t_traj = (kLandingCutoffHeight - tr.x2) / kLandingVelocity;
+      if (t < t_traj) {
+        xd[2] = fmaf(kLandingVelocity, t, tr.x2);
+      } else if (xc[2] > kLandingCutoffHeight) {
+        xd[2] = kLandingCutoffHeight; vd[2] = 0.0f;
+        fl |= kTrajComplete | kTrajLanded;  // mark_traj_end(False)
+      } else {
+        xd[2] = kLandingCutoffHeight; vd[2] = kLandingVelocity;
+      }
+    } else if (goal_mode == QR_GOAL_MODE4) {  // stay (:352-357)
+      if (!(fl & kTrajStarted)) { to_current(); fl |= kTrajStarted; }
+      fl |= kTrajComplete | kTrajManual;
+    } else {  // circle (:360-416): run-up along +x, num_circles circles about the start position, then manual
+      if (!(fl & kTrajStarted)) { to_current(); fl |= kTrajStarted; }
+      constexpr float run_up = kCircleRadius / kCircleLinearV;
+      constexpr float t_traj = run_up + kNumCircles * 2.0f * (float)kPi / kCircleW;
+      // (run_up = 350 dt EXACTLY; the reference's accumulated float64 t is 1.7499999999999847 at that call — still the run-up)
+      if (t < run_up * 1.000001f) {
+        xd[0] = fmaf(kCircleLinearV, t, tr.x0); vd[0] = kCircleLinearV;
+      } else if (t < t_traj) {
+        float sn, cs;
+        sincos_small(kCircleW * (t - run_up), sn, cs);
+        xd[0] = fmaf(kCircleRadius, cs, tr.x0); vd[0] = -kCircleRadius * kCircleW * sn;
+        xd[1] = fmaf(kCircleRadius, sn, tr.x1); vd[1] = kCircleRadius * kCircleW * cs;
+        bx = -cs; by = -sn;                                   // heading angle th + pi
+        bdx = kCircleW * sn; bdy = -kCircleW * cs;
+      } else {
+        fl |= kTrajComplete | kTrajManual;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { w.goal[j] = xd[j]; w.goal[3 + j] = vd[j]; }
+    b1d[0] = bx; b1d[1] = by; b1d[2] = 0.0f;
+    b1d_dot[0] = bdx; b1d_dot[1] = bdy; b1d_dot[2] = 0.0f;
+    tr.p2 = bdx; tr.p7 = bdy; tr.p3 = (float)fl;
+  } else if (goal_mode == QR_GOAL_MODE0) {  // set_desired_states_to_zero + the b1d drawn at episode start
 #pragma unroll
     for (int j = 0; j < 6; ++j) w.goal[j] = 0.0f;
     b1d[0] = tr.p2; b1d[1] = tr.p3; b1d[2] = 0.0f;
@@ -119,8 +207,10 @@ const float xi[3] = {tr.x0, tr.x1, tr.x2};
   const T oc0 = b1c[1] * b1cd[2] - b1c[2] * b1cd[1];
   const T oc1 = b1c[2] * b1cd[0] - b1c[0] * b1cd[2];
   const T oc2 = b1c[0] * b1cd[1] - b1c[1] * b1cd[0];
-  w.goal[9] = 0.0f; w.goal[10] = 0.0f;
-  w.goal[11] = (float)(R[6] * oc0 + R[7] * oc1 + R[8] * oc2);
+  if (!keep_wd) {
+    w.goal[9] = 0.0f; w.goal[10] = 0.0f;
+    w.goal[11] = (float)(R[6] * oc0 + R[7] * oc1 + R[8] * oc2);
+  }
 }
 
 __device__ __forceinline__ float sq3(const float* v) { return v[0] * v[0] + v[1] * v[1] + v[2] * v[2]; }

@@ -494,7 +494,12 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   if constexpr (TRAJ) {
     const SoA<float> traj(ka.traj, 8, L);
 #pragma unroll
-    for (int f = 0; f < 7; ++f) tr.set(f, traj.load(f, ufirst, ll));
+    for (int f = 0; f < 8; ++f) tr.set(f, traj.load(f, ufirst, ll));
+    if (goal_mode >= QR_GOAL_MODE2) {  // the stateful modes: xd, vd, b1d, Wd persist in the goal buffer (required for them)
+      const SoA<float> goal(goal_ptr, 12, L);
+#pragma unroll
+      for (int f = 0; f < 12; ++f) w.goal[f] = goal.load(f, ufirst, ll);
+    }
   }
 #if QR_TOUCH_COEFFS && defined(__HIP_DEVICE_COMPILE__)
   // (steps_ptr is back => s_waitcnt lgkmcnt(0) has been passed => the dummy words have landed: their registers are free)
@@ -923,9 +928,14 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     if constexpr (TRAJ) {
       const SoA<float> traj(ka.traj, 8, L);
       traj.store<AUX>(0, ufirst, lane, tr.calls);
-      if (traj_dirty) {  // the rest changes only at a reset
+      if (traj_dirty || goal_mode >= QR_GOAL_MODE2) {  // the rest changes only at a reset — or, in the stateful modes, with any call
 #pragma unroll
-        for (int f = 1; f < 7; ++f) traj.store<AUX>(f, ufirst, lane, tr.get(f));
+        for (int f = 1; f < 8; ++f) traj.store<AUX>(f, ufirst, lane, tr.get(f));
+      }
+      if (goal_mode >= QR_GOAL_MODE2) {
+        const SoA<float> goal(goal_ptr, 12, L);
+#pragma unroll
+        for (int f = 0; f < 12; ++f) goal.store<AUX>(f, ufirst, lane, w.goal[f]);
       }
     }
     if (params_dirty) {
@@ -1075,6 +1085,11 @@ __global__ __launch_bounds__(64) void traj_start_kernel(const Args a) {
   const SoA<float> traj(a.traj, 8, a.ld);
 #pragma unroll
   for (int f = 0; f < 8; ++f) traj.store(f, (unsigned)first, lane, tr.get(f));
+  if (a.goal_mode >= QR_GOAL_MODE2) {  // the stateful modes: the persistent fields of a fresh generator
+    const SoA<float> goal(a.goal, 12, a.ld);
+#pragma unroll
+    for (int f = 0; f < 12; ++f) goal.store(f, (unsigned)first, lane, w.goal[f]);
+  }
 }
 
 // get_desired for the current state: rows [N][15] = xd, vd, b1d, b1d_dot, Wd
@@ -1092,10 +1107,20 @@ __global__ __launch_bounds__(64) void get_desired_kernel(const Args a) {
   const SoA<float> traj(a.traj, 8, a.ld);
   Traj tr;
 #pragma unroll
-  for (int f = 0; f < 7; ++f) tr.set(f, traj.load(f, (unsigned)first, lane));
+  for (int f = 0; f < 8; ++f) tr.set(f, traj.load(f, (unsigned)first, lane));
+  const bool stateful = a.goal_mode >= QR_GOAL_MODE2;  // modes 2-5: xd, vd, b1d, Wd persist in the goal buffer
+  if (stateful) {
+    const SoA<float> goal(a.goal, 12, a.ld);
+#pragma unroll
+    for (int f = 0; f < 12; ++f) w.goal[f] = goal.load(f, (unsigned)first, lane);
+  }
   float b1d_dot[3];
   traj_goal(w, tr, a.goal_mode, a.c, b1d_dot);
   traj.store(0, (unsigned)first, lane, tr.calls);
+  if (stateful) {
+#pragma unroll
+    for (int f = 1; f < 8; ++f) traj.store(f, (unsigned)first, lane, tr.get(f));
+  }
   if (a.goal_rows) {
     float* o = a.goal_rows + i * 15;
 #pragma unroll
@@ -1103,7 +1128,7 @@ __global__ __launch_bounds__(64) void get_desired_kernel(const Args a) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) { o[9 + j] = b1d_dot[j]; o[12 + j] = w.goal[9 + j]; }
   }
-  if (a.store_goal && a.goal) {
+  if ((a.store_goal || stateful) && a.goal) {
     const SoA<float> goal(a.goal, 12, a.ld);
 #pragma unroll
     for (int f = 0; f < 12; ++f) goal.store(f, (unsigned)first, lane, w.goal[f]);
@@ -1206,8 +1231,9 @@ static int fill_env(Args& a, const QrEnv* e) {
   if (e->kind < 0 || e->kind > 2 || e->layout < 0 || e->layout > 2) return QR_E_KIND;
   if (e->num_envs < 0 || (e->field_stride != 0 && (e->field_stride < e->num_envs || (e->field_stride & 3)))) return QR_E_SIZE;
   if ((e->field_stride > 0 ? e->field_stride : e->num_envs) > (int64_t)0x7fffffff / (12 * 8)) return QR_E_SIZE;  // SoA buffers < 2 GiB (32-bit buffer offsets)
-  if (e->goal_mode < 0 || e->goal_mode > 3) return QR_E_KIND;
+  if (e->goal_mode < 0 || e->goal_mode > QR_GOAL_MODE5) return QR_E_KIND;
   if (e->goal_mode != QR_GOAL_EXTERNAL && !e->traj) return QR_E_NULL;
+  if (e->goal_mode >= QR_GOAL_MODE2 && !e->goal) return QR_E_NULL;  // the stateful modes keep xd, vd, b1d, Wd there
   if (!e->pos_vel || !e->att_rate) return QR_E_NULL;
   const QrCoeffs& q = e->coeffs;
   if (!(q.m_nominal > 0 && q.d_nominal > 0 && q.J1_nominal > 0 && q.J3_nominal > 0 && q.c_tf_nominal > 0 && q.c_tw_nominal > 0 &&

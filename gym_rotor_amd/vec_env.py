@@ -106,10 +106,10 @@ class QuadVecEnv:
                     free-run default.  Leave False for free runs / evaluation flights that fly on after termination
     max_episode_steps  >0 sets truncated when an episode reaches that many steps
     env_offset      global index of local env 0 (multi-GPU sharding; part of the RNG key)
-    goal_mode       None: goals come from set_goal_state() (hover default).  0 / 1 / 6: the reference's
+    goal_mode       None: goals come from set_goal_state() (hover default).  0..6: the reference's
                     TrajectoryGenerator mode 0 (idle/warm-up: xd = vd = 0, b1d drawn per episode),
-                    1 (hovering: exponential approach of the origin + yaw rate) or 6 (eight-shaped
-                    curve; parameters eight_* of QuadConstants) is evaluated
+                    1 (hovering: exponential approach of the origin + yaw rate), 2 (take-off), 3 (landing),
+                    4 (stay), 5 (circle) or 6 (eight-shaped curve; parameters eight_* of QuadConstants) is evaluated
                     INSIDE the step launch from the pre-step state, as main.py:145-147 does on the
                     host every step; see mark_traj_start() / get_desired()
     final_obs       with auto_reset: also keep the TERMINAL observation rows of the envs that were
@@ -202,9 +202,12 @@ class QuadVecEnv:
             self._params.copy_(torch.tensor(c.nominal_params, dtype=torch.float32, device=dev)[:, None].expand(6, N))
         self._goal = None  # default hover goal until set_goal_state is called (quad.py:98-101)
         if goal_mode not in _lib.GOAL_ID:
-            raise ValueError("goal_mode must be None, 0, 1 or 6 (TrajectoryGenerator modes fused into the step)")
+            raise ValueError("goal_mode must be None or 0..6 (TrajectoryGenerator modes fused into the step)")
         self.goal_mode = goal_mode
         self._traj = None if goal_mode is None else self._soa(8, torch.float32)
+        if goal_mode in (2, 3, 4, 5):   # the stateful modes keep the generator's xd, vd, b1d, Wd in the goal buffer
+            self._goal = self._soa(12, torch.float32)
+            self._goal[6] = 1.0
         self._episode = torch.zeros(N, dtype=torch.int32, device=dev)
         # stream position of the in-launch reset, one counter per 64-env tile (quadrotor_hip.h: reset_count)
         self._reset_count = torch.zeros((N + 63) // 64, dtype=torch.int32, device=dev)
@@ -546,7 +549,7 @@ class QuadVecEnv:
         (theta_b1d ~ U(+-25 deg)) / mode 1 (t_traj ~ U(2,5) s, w_b1d ~ U(+-0.15 pi) rad/s), from the
         current state.  Pass the draws ([N] tensors) to inject them; default: the env's RNG."""
         if self.goal_mode is None:
-            raise RuntimeError("mark_traj_start needs goal_mode 0 or 1")
+            raise RuntimeError("mark_traj_start needs a goal_mode (0..6)")
         m = None if mask is None else torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
         draws = None
         if theta_b1d is not None or t_traj is not None or w_b1d is not None:
@@ -564,7 +567,7 @@ class QuadVecEnv:
         for the current state (rows of envs outside `mask` are left zero); advances the generator's
         clock by dt like every reference call.  store_goal=True also does set_goal_state()."""
         if self.goal_mode is None:
-            raise RuntimeError("get_desired needs goal_mode 0 or 1")
+            raise RuntimeError("get_desired needs a goal_mode (0..6)")
         rows = torch.zeros(self.num_envs, 15, dtype=torch.float32, device=self.device)
         m = None if mask is None else torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
         if store_goal and self._goal is None:

@@ -72,6 +72,13 @@ extern "C" {
 #define QR_GOAL_MODE1    2 /* TrajectoryGenerator mode 1: exponential approach of the origin + yaw rate */
 #define QR_GOAL_MODE6    3 /* TrajectoryGenerator mode 6: eight-shaped (Lissajous) curve (:418-505); after
                               eight_count periods the last goal is held (the reference switches to manual) */
+/* The STATEFUL modes (:279-416): the generator object carries xd, vd, b1d, b1d_dot, Wd and its flags from call to call (a mode
+ * writes only the components it moves; after completion it switches to manual mode, which holds position and heading and no
+ * longer recomputes Wd).  They need QrEnv.goal: xd, vd, b1d, Wd persist THERE; b1d_dot, the flags and x_init in QrEnv.traj. */
+#define QR_GOAL_MODE2    4 /* mode 2 take-off: climb at 0.05 m/s from the start position to the height -0.5 m, then manual    */
+#define QR_GOAL_MODE3    5 /* mode 3 landing: descend at 1 m/s to the motor cut-off height -0.25 m                            */
+#define QR_GOAL_MODE4    6 /* mode 4 stay: hold the current position and heading (manual mode from the second call on)        */
+#define QR_GOAL_MODE5    7 /* mode 5 circle: 1.75 s run-up along +x, two circles of radius 0.7 m at 0.4 rad/s, then manual    */
 
 /* flags */
 #define QR_FLAG_AUTO_RESET   1u /* re-sample a done env inside the same launch (train distribution) */
@@ -143,10 +150,12 @@ typedef struct QrEnv {
   float*   goal;       /* [12][N] xd,vd,b1d,Wd (quad.py:413-418); NULL = hover default     */
   float*   traj;       /* [8][N]  goal-generator state, required when goal_mode != QR_GOAL_EXTERNAL:
                           0 #get_desired calls since mark_traj_start (t = calls*dt), 1 theta_init,
-                          2,3 b1d x,y (mode 0) | w_b1d, smooth_term (mode 1), 4..6 x_init, 7 unused */
+                          2,3 b1d x,y (mode 0) | w_b1d, smooth_term (mode 1) | b1d_dot x, flags (modes 2-5),
+                          4..6 x_init, 7 b1d_dot y (modes 2-5) */
   int32_t  goal_mode;  /* QR_GOAL_EXTERNAL (0), or a utils/trajectory_generator.py mode fused into
                           the step: QR_GOAL_MODE0 idle/warm-up (:141-148), QR_GOAL_MODE1 hovering (:252-277),
-                          QR_GOAL_MODE6 eight-shaped curve (:418-505) */
+                          QR_GOAL_MODE6 eight-shaped curve (:418-505), QR_GOAL_MODE2..5 take-off / landing / stay /
+                          circle (:279-416; these need `goal`) */
   int32_t  reserved0;
   int32_t* episode;    /* [N]     episode counter (RNG stream id); required for resets     */
   int32_t* steps;      /* [N]     steps since reset; NULL = no time-limit bookkeeping      */

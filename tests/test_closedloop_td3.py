@@ -15,8 +15,11 @@ from conftest import grouped_rel_err
 from oracle import quad_oracle as orc
 from oracle import traj_oracle as trj
 
-CASES = [(fw, m) for fw in ("modul", "mono") for m in (0, 1, 6)]
+CASES = [(fw, m) for fw in ("modul", "mono") for m in (0, 1, 6, 2, 3, 4, 5)]
 KIND = {"modul": "decoupled", "mono": "coupled"}
+# modes 2-5 (take-off, landing, stay, circle: the generator's stateful modes) live in their own fixture files
+# (tools/gen_golden.py td3modes), flown by the same shipped actors from start positions that reach every branch
+STATEFUL = (2, 3, 4, 5)
 
 
 def _np(t):
@@ -24,7 +27,7 @@ def _np(t):
 
 
 def _case(golden, fw, mode):
-    d = golden(f"closedloop_td3_{fw}")
+    d = golden(f"closedloop_td3_{fw}" + ("_modes2345" if mode in STATEFUL else ""))
     g = {k[len(f"m{mode}_"):]: d[k] for k in d if k.startswith(f"m{mode}_")}
     g["params"] = d["params"]
     return d, g
@@ -33,8 +36,18 @@ def _case(golden, fw, mode):
 def test_fixture_records_the_validation_of_the_actors(golden):
     for fw in ("modul", "mono"):
         d = golden(f"closedloop_td3_{fw}")
+        d2 = golden(f"closedloop_td3_{fw}_modes2345")
         assert float(d["flightlog_action_max_err"]) <= 1e-6      # the shimmed actors against the reference-owned log
-        assert list(d["modes"]) == [0, 1, 6]
+        assert float(d2["flightlog_action_max_err"]) == float(d["flightlog_action_max_err"]) and int(d2["tiebreak_salt"]) == int(d["tiebreak_salt"])
+        assert list(d["modes"]) == [0, 1, 6] and list(d2["modes"]) == [2, 3, 4, 5]
+        for m in STATEFUL:
+            assert not d2[f"m{m}_dones"].any() and np.abs(d2[f"m{m}_actions"]).max() <= 1.0
+        # the flights reach every branch of the stateful modes: the take-off arrives (MODUL: then manual mode) or hovers short of the
+        # way-point (MONO), the landing reaches the cut-off height, the circle completes its two turns and hands over to manual mode
+        g2, g5 = d2["m2_goals"], d2["m5_goals"]
+        assert abs(g2[-1, 2] + 0.5) < 0.01 and g2[0, 2] > -0.31          # (which branch each flight ended in: the oracle test's flags)
+        assert d2["m3_goals"][-1, 2] == -0.25 and d2["m3_goals"][-1, 5] == 0.0
+        assert np.abs(g5[400:6000, 0:2] - g5[0, 0:2]).max() > 0.65 and np.abs(g5[-1, 3:6]).max() == 0.0
         for m in (0, 1, 6):
             assert not d[f"m{m}_dones"].any()                    # the shipped policies keep the vehicle flying
             assert np.abs(d[f"m{m}_actions"]).max() <= 1.0
@@ -55,9 +68,10 @@ def test_oracle_replays_the_shipped_policy_flights(fw, mode, golden):
     goal12 = np.concatenate([first[0:9], first[12:15]])[None]
     integ = _advance(kind, state, goal12, np.zeros((1, 8)))     # the first observation's side effect on the integrators
     worst = worst_obs = 0.0
+    worst_goal = 0.0
     for t in range(T):
         goal = np.concatenate(trj.get_desired_batch(tr, state[0]), 1)[0]
-        assert np.abs(goal - g["goals"][t]).max() <= 1e-10
+        worst_goal = max(worst_goal, float(np.abs(goal - g["goals"][t]).max()))
         goal12 = np.concatenate([g["goals"][t][0:9], g["goals"][t][12:15]])[None]
         out = orc.step_batch(kind, state, g["actions"][t][None].astype(np.float64), g["params"], goal12, integ)
         state, integ = out["state"], out["integ"]
@@ -66,7 +80,32 @@ def test_oracle_replays_the_shipped_policy_flights(fw, mode, golden):
         assert not out["done"].any()
         assert np.abs(out["reward"][0] - g["rewards"][t]).max() <= 1e-6
         worst = max(worst, grouped_rel_err(state, g["states"][t + 1][None]))
-    assert worst <= 1e-9 and worst_obs <= 2e-7, (worst, worst_obs)
+    # (the goals are formed from the ORACLE's own state, which drifts from the reference's by the closed loop's 1e-10 .. 1e-9: Wd and,
+    # in the stateful modes, the positions taken over at a switch inherit that; on the reference's states the goal oracle is exact,
+    # see test_stateful_goal_modes_oracle_is_exact_on_the_reference_states)
+    # (the 6900-step circle flight: the recorded actions drive the state open loop through the unstable double integrator: 6e-8 by the end)
+    long_flight = T > 2000
+    assert worst <= (1e-7 if long_flight else 1e-9) and worst_obs <= 2e-7, (worst, worst_obs)
+    assert worst_goal <= (1e-7 if long_flight else 1e-8 if mode in STATEFUL else 1e-10), worst_goal
+    if mode in STATEFUL:  # the flags the flight ended with: every branch of the stateful modes was taken somewhere
+        want = {("modul", 2): (True, True), ("mono", 2): (False, False), 3: (True, False), 4: (True, True), 5: (True, True)}
+        assert (bool(tr["complete"][0]), bool(tr["manual"][0])) == want.get((fw, mode), want.get(mode))
+        assert bool(tr["landed"][0]) == (mode == 3)
+
+
+@pytest.mark.parametrize("fw", ["modul", "mono"])
+@pytest.mark.parametrize("mode", STATEFUL)
+def test_stateful_goal_modes_oracle_is_exact_on_the_reference_states(fw, mode, golden):
+    """The goal oracle's restatement of the generator's stateful modes (take-off, landing, stay, circle: persistent xd / vd / b1d /
+    b1d_dot / Wd, five flags, manual mode's early return) fed with the reference's own states: all 15 goal words of every call
+    to 1e-15 — including the stale b1d_dot and the frozen Wd the reference carries through manual mode."""
+    _, g = _case(golden, fw, mode)
+    tr = trj.traj_start_batch(g["init_state"], mode)
+    first = np.concatenate(trj.get_desired_batch(tr, g["init_state"]), 1)[0]
+    assert np.abs(first - g["first_goal"]).max() <= 1e-15
+    for t in range(len(g["actions"])):
+        goal = np.concatenate(trj.get_desired_batch(tr, g["states"][t]), 1)[0]
+        assert np.abs(goal - g["goals"][t]).max() <= 1e-15, t
 
 
 @pytest.mark.gpu
@@ -93,7 +132,13 @@ def test_gpu_replays_the_shipped_policy_flights(fw, mode, layout, golden):
         assert np.abs(_np(o)[0] - g[f"first_obs{k}"]).max() <= 3e-6
     acts = torch.from_numpy(g["actions"]).cuda()
     worst = worst_obs = worst_rwd = 0.0
+    # (the 6900-step circle flight: 34.5 s of recorded actions driving the state open loop amplify a one-step error of 3.5e-11 to 3e-4
+    # by the end — the oracle itself drifts 6e-8 over it.  The flight is therefore re-synchronised to the reference's state every 500
+    # steps: the generator's state, the integral terms and every branch decision still run through all 6900 calls.)
+    resync = 500 if T > 2000 else 0
     for t in range(T):
+        if resync and t and t % resync == 0:
+            env.set_state(g["states"][t][None])
         obs, rwd, done, _, _ = env.step(acts[t:t + 1])
         obs = [obs] if isinstance(obs, torch.Tensor) else list(obs)
         for k, o in enumerate(obs):

@@ -944,8 +944,9 @@ def test_long_episode_integrators_into_the_clip():
 
 
 def test_set_state_rejects_rows_without_a_nearest_rotation():
-    """det R <= 0 (a reflection) or non-finite attitude entries have no nearest rotation: qr_set_state leaves those
-    envs untouched, counts them, and the host wrapper raises; every other env is still updated."""
+    """det R <= 0 (a reflection) or non-finite attitude entries have no nearest rotation.  The C-ABI's qr_set_state leaves those
+    envs untouched, counts them and updates every other env; qr_check_state makes the same count and writes nothing; the host
+    wrapper validates with it first and raises before ANY env has changed."""
     n = 200
     env = _env("quad", n, layout="f64")
     env.reset("train")
@@ -959,7 +960,17 @@ def test_set_state_rejects_rows_without_a_nearest_rotation():
     s[199, 8] = np.nan
     with pytest.raises(ValueError, match="3 row"):
         env.set_state(s)
+    assert np.array_equal(_np(env.get_current_state()), before)   # validated first (qr_check_state): nothing changed
+    # the C-ABI entry points themselves: the dry run counts and writes nothing, the real call skips exactly the counted rows
+    import ctypes as C
+    rows, rej = torch.from_numpy(s).cuda(), torch.zeros(1, dtype=torch.int32, device="cuda")
+    assert env._lib.qr_check_state(C.byref(env._cenv), rows.data_ptr(), None, rej.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert int(rej.item()) == 3 and np.array_equal(_np(env.get_current_state()), before)
+    rej.zero_()
+    assert env._lib.qr_set_state(C.byref(env._cenv), rows.data_ptr(), None, rej.data_ptr(), None) == 0
+    torch.cuda.synchronize()
     after = _np(env.get_current_state())
-    assert np.array_equal(after[bad], before[bad])                # rejected rows: previous state kept
+    assert int(rej.item()) == 3 and np.array_equal(after[bad], before[bad])                # rejected rows: previous state kept
     assert np.allclose(after[~bad, 0], s[~bad, 0]) and np.isfinite(after).all()
     env.set_state(s, mask=torch.from_numpy(~bad).cuda())          # masked out: not looked at

@@ -141,6 +141,11 @@ def test_abi_argument_errors_without_gpu():
     assert lib.qr_step(C.byref(e2), 0x3000, 1, C.byref(o2), None) == -3      # stride < N
     e2.field_stride, e2.goal_mode = 0, 2
     assert lib.qr_step(C.byref(e2), 0x3000, 1, C.byref(o2), None) == -1      # fused goals without traj buffer
+    e2.goal_mode, e2.traj = 4, 0x7000
+    assert lib.qr_get_desired(C.byref(e2), None, 0x8000, 0, None) == -1      # a stateful mode (take-off) without the goal buffer it persists in
+    e2.goal_mode = 8
+    assert lib.qr_get_desired(C.byref(e2), None, 0x8000, 0, None) == -2      # no such mode
+    e2.goal_mode, e2.traj = 2, None
     # qr_rollout_actor: argument checks before any launch
     e3, o3, pol = L.QrEnv(), L.QrStepOut(), L.QrPolicyRollout()
     lib.qr_default_coeffs(C.byref(e3.coeffs))

@@ -9,6 +9,8 @@ OUT=$ROOT/gpurun_out/$RND
 EV=build/evidence
 mkdir -p "$OUT"
 cd "$ROOT"
+# the product library is rebuilt HERE from the pushed sources, whatever .so rode along (round 4 once measured a stale one)
+make -B -C gym_rotor_amd/csrc > "$OUT/product_build.log" 2>&1 || { echo "product build FAILED"; tail -5 "$OUT/product_build.log"; exit 1; }
 if [ "$WHAT" = all ] || [ "$WHAT" = ab ]; then
   make -C gym_rotor_amd/csrc evidence-libs > "$OUT/evidence_libs_build.log" 2>&1 || { echo "evidence-libs build FAILED"; tail -5 "$OUT/evidence_libs_build.log"; }
 fi

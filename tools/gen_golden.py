@@ -26,6 +26,8 @@ Files written (see tests/golden/README.md for the field lists):
   closedloop_td3_{mono,modul}.npz   (`python tools/gen_golden.py td3`) the reference's eval loop (main.py:270-345) with the SHIPPED
                            TD3-EMLP actors (models/*.pth) in TrajectoryGenerator modes 0 / 1 / 6: realistic, non-random actions
                            incl. eight-shaped-curve tracking.  Needs tools/_plum_shim (see there).
+  closedloop_td3_{mono,modul}_modes2345.npz   (`python tools/gen_golden.py td3modes`) the same loop in TrajectoryGenerator modes 2 (take-off), 3 (landing),
+                           4 (stay) and 5 (circle), from start positions that reach every branch of the generator
 """
 import os
 import sys
@@ -729,7 +731,7 @@ def build_shipped_actors():
     return {"MODUL": [a0, a1], "MONO": [am]}, report
 
 
-def gen_closedloop_td3(framework, actors, report, modes=((0, 600), (1, 1000), (6, 1800))):
+def gen_closedloop_td3(framework, actors, report, modes=((0, 600), (1, 1000), (6, 1800)), suffix="", init_x=None):
     """main.py's eval loop (:290-345) with the shipped actor(s): eval reset, mark_traj_start, per step get_desired(current
     state) -> set_goal_state -> actor(obs) -> step.  One env per mode; the generator's draws are injected and recorded."""
     import torch
@@ -754,6 +756,8 @@ def gen_closedloop_td3(framework, actors, report, modes=((0, 600), (1, 1000), (6
             return np.array([queue.pop(0)])
 
         init = state_in(orc.sample_reset_state(rng, 1, "eval"))[0]       # eval reset: |x| <= 0.4, yaw only (quad.py:352-356)
+        if init_x is not None and mode in init_x:                        # (modes 2-5: a start position from which every branch is flown)
+            init[0:3] = f32r(init_x[mode])
         states = np.zeros((T + 1, 18)); goals = np.zeros((T, 15)); actions = np.zeros((T, A), np.float32)
         rewards = np.zeros((T, nag)); dones = np.zeros((T, nag), bool)
         obs_in = [np.zeros((T, d), np.float32) for d in obs_dims]; obs_out = [np.zeros((T, d), np.float32) for d in obs_dims]
@@ -795,10 +799,10 @@ def gen_closedloop_td3(framework, actors, report, modes=((0, 600), (1, 1000), (6
                     tag + "goals": goals, tag + "actions": actions, tag + "rewards": rewards, tag + "dones": dones})
         for k in range(len(obs_dims)):
             out[tag + f"first_obs{k}"] = first_obs[k]; out[tag + f"obs_in{k}"] = obs_in[k]; out[tag + f"obs{k}"] = obs_out[k]
-        ex = np.abs(states[-200:, 0:3] - goals[-200:, 0:3].mean(0)).max() if mode != 6 else np.abs(states[:T, 0:3] - goals[:, 0:3]).max()
+        ex = np.abs(states[-200:, 0:3] - goals[-200:, 0:3].mean(0)).max() if mode in (0, 1) else np.abs(states[:T, 0:3] - goals[:, 0:3]).max()
         print(f"closedloop_td3_{framework.lower()} mode {mode}: {T} steps, max|x - xd| {'over the flight' if mode == 6 else 'last 200 steps'} {ex:.3f} m, "
               f"|x| max {np.abs(states[:, 0:3]).max():.2f}, reward mean {rewards.mean(0)}")
-    np.savez_compressed(os.path.join(OUT, f"closedloop_td3_{framework.lower()}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"closedloop_td3_{framework.lower()}{suffix}.npz"), **out)
 
 
 def gen_flightlog(rows=3600):
@@ -813,6 +817,16 @@ if __name__ == "__main__":
         shipped, rep = build_shipped_actors()
         for fw in ("MODUL", "MONO"):
             gen_closedloop_td3(fw, shipped[fw], rep)
+        sys.exit(0)
+    if ARGV[:1] == ["td3modes"]:  # TrajectoryGenerator modes 2-5 (take-off, landing, stay, circle) flown by the shipped actors
+        # start positions chosen so that every branch of the generator is reached inside the arena (|x| < 1): take-off from 0.2 m
+        # below the take-off height (t_traj = 4 s, then the way-point test, then manual mode); landing from 0.35 m above the motor
+        # cut-off height (ramp 0.1 s, then the descent branch until x3 > -0.25, then "landed"); circle centred 0.1 m off the origin
+        # (1.75 s run-up, two circles of 0.7 m radius: 33.2 s, then manual mode)
+        shipped, rep = build_shipped_actors()
+        init_x = {2: [0.1, -0.15, -0.3], 3: [-0.2, 0.1, -0.6], 4: [0.3, 0.2, -0.1], 5: [-0.1, 0.05, -0.2]}
+        for fw in ("MODUL", "MONO"):
+            gen_closedloop_td3(fw, shipped[fw], rep, modes=((2, 1300), (3, 500), (4, 300), (5, 6900)), suffix="_modes2345", init_x=init_x)
         sys.exit(0)
     if ARGV[:1] == ["actor"]:  # only the actor files
         gen_actor()
