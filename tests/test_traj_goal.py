@@ -226,7 +226,7 @@ def test_fused_goal_auto_reset_runs_and_matches_manual():
     """auto_reset + goal_mode: the in-launch episode start (reset draw -> mark_traj_start ->
     first get_desired -> first obs) equals doing the same by hand from the post-reset state."""
     n = 2048
-    for mode in (0, 1):
+    for mode in (0, 1, 2, 3, 4, 5):
         env = _mk("coupled", n, mode, seed=4, auto_reset=True)
         env.reset("train")
         g = torch.Generator(device="cuda"); g.manual_seed(1)
@@ -238,7 +238,10 @@ def test_fused_goal_auto_reset_runs_and_matches_manual():
                 hits += hit.sum()
                 chk = _mk("coupled", n, mode, seed=0)
                 chk.load_state_dict(env.state_dict())         # state, params, traj state after the reset
-                chk._traj[0].fill_(0.0)                       # calls = 0: redo the episode's first call
+                if mode >= 2:                                 # the stateful modes (no draws): mark_traj_start again — flags, persistent goal —
+                    chk.mark_traj_start(mask=torch.from_numpy(hit).cuda())   # and redo the episode's first call from there
+                else:
+                    chk._traj[0].fill_(0.0)                   # calls = 0: redo the episode's first call (same draws)
                 chk._integ.zero_()
                 chk.get_desired(store_goal=True)
                 first = chk.get_norm_error_state()[0]
@@ -248,11 +251,12 @@ def test_fused_goal_auto_reset_runs_and_matches_manual():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 6, 2, 3, 4, 5])
 def test_rollout_equals_steps_with_fused_goal(mode):
-    """K-step rollout with the goal generator fused is bit-identical to K single steps."""
+    """K-step rollout with the goal generator fused is bit-identical to K single steps — also in the generator's stateful modes
+    (2-5), whose persistent fields then live in registers across the steps instead of going through the goal buffer."""
     from gym_rotor_amd import QuadVecEnv
-    n, T = 900, 9
+    n, T = 900, 9 if mode in (0, 1) else 70
     envs = [QuadVecEnv("decoupled", n, device="cuda", goal_mode=mode, seed=8, auto_reset=True) for _ in range(2)]
     for e in envs:
         e.reset("train")
@@ -268,5 +272,13 @@ def test_rollout_equals_steps_with_fused_goal(mode):
         assert torch.equal(outs[t][2], ro["reward"][t]) and torch.equal(outs[t][3], ro["terminated"][t])
     assert torch.equal(envs[0].get_current_state(), envs[1].get_current_state())
     assert torch.equal(envs[0]._traj, envs[1]._traj)
+    if mode in (2, 3, 4, 5):
+        assert torch.equal(envs[0]._goal, envs[1]._goal)
+        flags = envs[0]._traj[3].to(torch.int32)
+        assert bool((flags & 1).all())                         # every env's trajectory has started ...
+        if mode == 4:
+            assert bool(((flags & 4) != 0).all())              # ... "stay" is in manual mode from its second call on
+        if mode == 3:
+            assert bool(((flags & 16) != 0).any())             # ... some landings have reached the cut-off height
     with pytest.raises(RuntimeError):
         envs[0].set_goal_state(np.zeros(3), np.zeros(3), np.array([1.0, 0, 0]))
