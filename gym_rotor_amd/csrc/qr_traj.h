@@ -35,7 +35,9 @@ enum : int { kTrajStarted = 1, kTrajComplete = 2, kTrajManual = 4, kTrajManualIn
 // mark_traj_start(state) (:176-204) + the episode-start branch of calculate_desired:
 //   mode 0 (:141-148): b1d = Rz(theta) b1_proj, theta ~ U(+-25 deg)
 //   mode 1 (:253-266): x_init = x, t_traj ~ U(2,5), smooth = -ln(0.001)/t_traj, w_b1d ~ U(+-0.15 pi)
-template <typename T, typename X>
+// STATEFUL selects which family the caller compiled in: the stateless modes 0 / 1 / 6, or the stateful 2-5 (a separate set of step-kernel
+// instantiations: with both in one kernel the stateless fused launches paid 8-22 % for code they never run, profiles/r04/ab_fused_goal_modes.txt).
+template <bool STATEFUL, typename T, typename X>
 __device__ __forceinline__ void traj_start(Work<T, X>& w, Traj& tr, int goal_mode, float theta_b1d, float t_traj, float w_b1d) {
   const T qw = w.q[0], qx = w.q[1], qy = w.q[2], qz = w.q[3];
   const float b1x = (float)(T(1) - T(2) * (qy * qy + qz * qz)), b1y = (float)(T(2) * (qx * qy + qw * qz));
@@ -43,7 +45,7 @@ __device__ __forceinline__ void traj_start(Work<T, X>& w, Traj& tr, int goal_mod
   tr.calls = 0.0f;
   tr.theta_init = theta_init;
   tr.p7 = 0.0f;
-  if (goal_mode >= QR_GOAL_MODE2) {  // modes 2-5: no draws; flags cleared, x_init = x (:176-204), and the persistent fields of a FRESH generator
+  if constexpr (STATEFUL) {  // modes 2-5: no draws; flags cleared, x_init = x (:176-204), and the persistent fields of a FRESH generator
     tr.p2 = 0.0f; tr.p3 = 0.0f;       // (xd = vd = Wd = 0, b1d = e1, b1d_dot = 0: __init__ :54-55, 67-68 — the reference object would carry the
     tr.x0 = (float)w.x[0]; tr.x1 = (float)w.x[1]; tr.x2 = (float)w.x[2];   //  previous episode's b1d_dot into this one)
 #pragma unroll
@@ -70,12 +72,12 @@ __device__ __forceinline__ void traj_draws(uint32_t r19, float& theta_b1d, float
 
 // get_desired(state, mode) (:113-173) for the state in w: advances the call counter, fills
 // w.goal = (xd, vd, b1d, Wd) and returns b1d_dot.
-template <typename T, typename X>
+template <bool STATEFUL, typename T, typename X>
 __device__ __forceinline__ void traj_goal(Work<T, X>& w, Traj& tr, int goal_mode, const Coeffs& c, float (&b1d_dot)[3]) {
   tr.calls += 1.0f;  // update_current_time (:224-229): t = t + dt on every call
   float b1d[3];
   bool keep_wd = false;  // (modes 2-5 in manual mode: calculate_desired returns before the Wd computation, :137-139)
-  if (goal_mode >= QR_GOAL_MODE2) {  // take-off / landing / stay / circle on the persistent fields (see the constants above)
+  if constexpr (STATEFUL) {  // take-off / landing / stay / circle on the persistent fields (see the constants above)
     const float dtf = 2.0f * c.hdt, t = tr.calls * dtf;
     int fl = (int)tr.p3;
     const float xc[3] = {(float)w.x[0], (float)w.x[1], (float)w.x[2]}, vc[3] = {(float)w.v[0], (float)w.v[1], (float)w.v[2]};

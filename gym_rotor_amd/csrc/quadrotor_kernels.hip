@@ -194,8 +194,9 @@ struct PostLds {
 // ------------------------------------------------------------------------------------
 // The fused step / rollout kernel
 // ------------------------------------------------------------------------------------
-// TRAJ = the goal generator (trajectory_generator.py modes 0/1) is fused into the step; a
-// separate instantiation so that the default path carries none of its registers.  ADAPT = the
+// TRAJ != 0 = the goal generator (utils/trajectory_generator.py) is fused into the step; separate instantiations
+// so that the default path carries none of its registers: 1 = the stateless modes 0 / 1 / 6, 2 = the stateful modes 2-5
+// (take-off, landing, stay, circle: persistent goal fields loaded / stored with the working set).  ADAPT = the
 // rate-adaptive substep count (QrCoeffs::w_adapt); launch_kind() picks the plain instantiation
 // whenever adaptivity provably cannot trigger.
 // POLICY != 0 = qr_rollout_actor: the action of every step comes from the actor(s) evaluated on the
@@ -208,7 +209,7 @@ struct PostLds {
 // a lone wave issues one VALU instruction per ~5.6 cycles, two waves on a SIMD one per ~2.9 (tools/valu_microbench.hip),
 // so the helper runs in issue slots that are otherwise empty, and the stepping wave's reset block shrinks from
 // ~230 instructions (Philox, role scaling, attitude, 24 cross-lane reads) to six LDS reads.
-template <int KIND, typename XV, typename QW, int B, bool TRAJ, bool ADAPT, int POLICY = 0, bool SINGLE = false, bool HELP = false>
+template <int KIND, typename XV, typename QW, int B, int TRAJ, bool ADAPT, int POLICY = 0, bool SINGLE = false, bool HELP = false>
 __global__ __launch_bounds__(B + (HELP ? 64 : 0), ((HELP && POLICY) ? 2 : (TRAJ || POLICY) ? 1 : 2))  // (HELP: both waves of every tile resident)
 void step_kernel(void* pos_vel, void* att_rate, const float* action, float* params, float* integ, int32_t* reset_count,
                  int32_t n_envs, int32_t ld_envs, const Args a_in) {
@@ -491,11 +492,12 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 
   Traj tr;
   const int goal_mode = TRAJ ? ka.goal_mode : QR_GOAL_EXTERNAL;  // wave-uniform
+  constexpr bool kStateful = TRAJ == 2;
   if constexpr (TRAJ) {
     const SoA<float> traj(ka.traj, 8, L);
 #pragma unroll
-    for (int f = 0; f < 8; ++f) tr.set(f, traj.load(f, ufirst, ll));
-    if (goal_mode >= QR_GOAL_MODE2) {  // the stateful modes: xd, vd, b1d, Wd persist in the goal buffer (required for them)
+    for (int f = 0; f < (kStateful ? 8 : 7); ++f) tr.set(f, traj.load(f, ufirst, ll));
+    if constexpr (kStateful) {  // xd, vd, b1d, Wd persist in the goal buffer (required for these modes)
       const SoA<float> goal(goal_ptr, 12, L);
 #pragma unroll
       for (int f = 0; f < 12; ++f) w.goal[f] = goal.load(f, ufirst, ll);
@@ -615,7 +617,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     // ---- goal for this step from the pre-step state (main.py:145-147) ----
     if constexpr (TRAJ) {
       float b1d_dot[3];
-      traj_goal(w, tr, goal_mode, c, b1d_dot);
+      traj_goal<kStateful>(w, tr, goal_mode, c, b1d_dot);
     }
     QR_STAMP(2, (float)w.q[0] + (float)w.x[0] + act[0] + w.prm[0] + (float)w.W[2]);
     // ---- action_wrapper ----
@@ -810,7 +812,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       uint32_t r19 = 0;
       int pass0 = 0;
       if constexpr (HELP) {  // pass 0 comes from the helper wave
-        take_from_lds<T, X, TRAJ>(pool_lds[(SINGLE || POLICY) ? 0 : (t & 1)], need_reset && rank < 12, rank, w, r19);
+        take_from_lds<T, X, TRAJ != 0>(pool_lds[(SINGLE || POLICY) ? 0 : (t & 1)], need_reset && rank < 12, rank, w, r19);
         pass0 = 1;
         if (total > 12) {  // more than 12 lanes reset at once (rare): this wave samples the further passes itself
           pool_role(role, randomise, eval_reset, c);
@@ -828,7 +830,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         // once: 128 instead of 142 VGPRs for the plain Quad-v0 kernel, i.e. four waves per SIMD instead of three
         pool_to_lds(own_pool, pool);
         tile_sync<B>();
-        take_from_lds<T, X, TRAJ>(own_pool, need_reset && slot >= 0 && slot < 12, slot, w, r19);
+        take_from_lds<T, X, TRAJ != 0>(own_pool, need_reset && slot >= 0 && slot < 12, slot, w, r19);
         tile_sync<B>();
       }
       if (need_reset) {
@@ -842,8 +844,8 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         if constexpr (TRAJ) {  // mark_traj_start + first get_desired of the episode (main.py:227-229)
           float th, tt, wb, b1d_dot[3];
           traj_draws(r19, th, tt, wb);
-          traj_start(w, tr, goal_mode, th, tt, wb);
-          traj_goal(w, tr, goal_mode, c, b1d_dot);
+          traj_start<kStateful>(w, tr, goal_mode, th, tt, wb);
+          traj_goal<kStateful>(w, tr, goal_mode, c, b1d_dot);
           traj_dirty = true;
         }
         if constexpr (KIND != QR_KIND_QUAD) {
@@ -928,11 +930,11 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     if constexpr (TRAJ) {
       const SoA<float> traj(ka.traj, 8, L);
       traj.store<AUX>(0, ufirst, lane, tr.calls);
-      if (traj_dirty || goal_mode >= QR_GOAL_MODE2) {  // the rest changes only at a reset — or, in the stateful modes, with any call
+      if (traj_dirty || kStateful) {  // the rest changes only at a reset — or, in the stateful modes, with any call
 #pragma unroll
-        for (int f = 1; f < 8; ++f) traj.store<AUX>(f, ufirst, lane, tr.get(f));
+        for (int f = 1; f < (kStateful ? 8 : 7); ++f) traj.store<AUX>(f, ufirst, lane, tr.get(f));
       }
-      if (goal_mode >= QR_GOAL_MODE2) {
+      if constexpr (kStateful) {
         const SoA<float> goal(goal_ptr, 12, L);
 #pragma unroll
         for (int f = 0; f < 12; ++f) goal.store<AUX>(f, ufirst, lane, w.goal[f]);
@@ -1081,7 +1083,8 @@ __global__ __launch_bounds__(64) void traj_start_kernel(const Args a) {
     traj_draws(d.r[19], th, tt, wb);
   }
   Traj tr;
-  traj_start(w, tr, a.goal_mode, th, tt, wb);
+  if (a.goal_mode >= QR_GOAL_MODE2) traj_start<true>(w, tr, a.goal_mode, th, tt, wb);
+  else traj_start<false>(w, tr, a.goal_mode, th, tt, wb);
   const SoA<float> traj(a.traj, 8, a.ld);
 #pragma unroll
   for (int f = 0; f < 8; ++f) traj.store(f, (unsigned)first, lane, tr.get(f));
@@ -1115,7 +1118,8 @@ __global__ __launch_bounds__(64) void get_desired_kernel(const Args a) {
     for (int f = 0; f < 12; ++f) w.goal[f] = goal.load(f, (unsigned)first, lane);
   }
   float b1d_dot[3];
-  traj_goal(w, tr, a.goal_mode, a.c, b1d_dot);
+  if (stateful) traj_goal<true>(w, tr, a.goal_mode, a.c, b1d_dot);
+  else traj_goal<false>(w, tr, a.goal_mode, a.c, b1d_dot);
   traj.store(0, (unsigned)first, lane, tr.calls);
   if (stateful) {
 #pragma unroll
@@ -1307,7 +1311,7 @@ static inline bool wants_helper(const Args& a, int kind, int layout) {  // a hel
 static inline bool wants_helper_traj(const Args& a, int kind) {  // the same with the fused goal generator (one-step launches)
   const unsigned tiles = (unsigned)((a.n + 63) / 64);
   const Tuning& tn = tuning();
-  return a.act_out == nullptr && a.goal_mode != QR_GOAL_EXTERNAL && !wants_adapt(a) && (a.flags & QR_FLAG_AUTO_RESET) &&
+  return a.act_out == nullptr && a.goal_mode != QR_GOAL_EXTERNAL && a.goal_mode < QR_GOAL_MODE2 && !wants_adapt(a) && (a.flags & QR_FLAG_AUTO_RESET) &&
          helper_choice(a, tiles, kind == QR_KIND_QUAD ? tn.helper_grid : tn.helper_grid_wrap);
 }
 
@@ -1336,7 +1340,8 @@ static void launch_kind(const Args& a, hipStream_t s) {
           return;
         }
       }
-      if (traj && general) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true, 2>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+      if (a.goal_mode >= QR_GOAL_MODE2) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, 2, true, 2>), grid, dim3(64), 0, s, QR_STEP_ARGS);  // stateful goal modes: the general actor form
+      else if (traj && general) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true, 2>), grid, dim3(64), 0, s, QR_STEP_ARGS);
       else if (traj) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true, 1>), grid, dim3(64), 0, s, QR_STEP_ARGS);
       else if (general) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 2>), grid, dim3(64), 0, s, QR_STEP_ARGS);
       else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 1>), grid, dim3(64), 0, s, QR_STEP_ARGS);
@@ -1349,7 +1354,10 @@ static void launch_kind(const Args& a, hipStream_t s) {
   const bool help_traj = kHasSingle && a.n_steps == 1 && wants_helper_traj(a, KIND);  // (fused goal generator: one-step launches only)
   if constexpr (kHasSingle) {
     if (a.n_steps == 1) {
-      if (a.goal_mode != QR_GOAL_EXTERNAL) {
+      if (a.goal_mode >= QR_GOAL_MODE2) {  // the generator's stateful modes (take-off, landing, stay, circle): their own instantiations
+        if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, 2, true, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+        else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, 2, false, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+      } else if (a.goal_mode != QR_GOAL_EXTERNAL) {
         if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
         else if (help_traj) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, false, 0, true, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
         else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, false, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
@@ -1360,7 +1368,10 @@ static void launch_kind(const Args& a, hipStream_t s) {
       return;
     }
   }
-  if (a.goal_mode != QR_GOAL_EXTERNAL) {
+  if (a.goal_mode >= QR_GOAL_MODE2) {
+    if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, 2, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+    else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, 2, false>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+  } else if (a.goal_mode != QR_GOAL_EXTERNAL) {
     if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
     else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, false>), grid, dim3(64), 0, s, QR_STEP_ARGS);
   } else if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);

@@ -16,7 +16,7 @@ for f in re.split(r'\n(?=_ZN2qr11step_kernel\S*:)', txt):
         continue
     body = f.split('.Lfunc_end')[0]
     insts = [l for l in body.splitlines() if l.startswith('\t') and not l.startswith('\t.') and not l.startswith('\t;')]
-    tag = re.search(r'ILi(\d)E(\w)(\w)Li64ELb(\d)ELb(\d)ELi(\d)ELb(\d)ELb(\d)E', m.group(1))
+    tag = re.search(r'ILi(\d)E(\w)(\w)Li64EL[bi](\d)ELb(\d)ELi(\d)ELb(\d)ELb(\d)E', m.group(1))
     name = "kind=%s %s%s TRAJ=%s ADAPT=%s POLICY=%s SINGLE=%s HELP=%s" % tag.groups() if tag else m.group(1)
     print(name, '| insts', len(insts), 'writelane', body.count('v_writelane'), 'readlane', body.count('v_readlane'),
           'scratch', body.count('scratch_'), 'vload', len(re.findall(r'(buffer|global)_load', body)),

@@ -19,7 +19,7 @@ for l in sys.stdin:
 LAY = {("f", "d"): "mixed", ("d", "d"): "f64", ("f", "f"): "f32"}
 for r in rows:
     n = r["name"]
-    m = re.match(r"_ZN2qr11step_kernelILi(\d)E(\w)(\w)Li64ELb(\d)ELb(\d)ELi(\d)ELb(\d)ELb(\d)E", n)
+    m = re.match(r"_ZN2qr11step_kernelILi(\d)E(\w)(\w)Li64EL[bi](\d)ELb(\d)ELi(\d)ELb(\d)ELb(\d)E", n)
     if m:
         n = "step_kernel<kind=%s,%s,TRAJ=%s,ADAPT=%s,POLICY=%s,SINGLE=%s,HELP=%s>" % (m.group(1), LAY.get((m.group(2), m.group(3)), "?"), *m.groups()[3:])
     else:
