@@ -85,7 +85,8 @@ def _out_struct(obs0, obs1, reward, reward_raw, done, truncated, final_obs0, fin
     return o
 
 
-_ENV_MUT = ("pos_vel", "att_rate", "integ", "params", "traj", "episode", "steps", "reset_count")
+# (goal: written by the fused goal generator's stateful modes 2-5, whose xd / vd / b1d / Wd persist there)
+_ENV_MUT = ("pos_vel", "att_rate", "integ", "params", "goal", "traj", "episode", "steps", "reset_count")
 _OUT_MUT = ("obs0", "obs1", "reward", "reward_raw", "done", "truncated", "final_obs0", "final_obs1")
 
 
@@ -175,12 +176,13 @@ def qr_reset(pos_vel: torch.Tensor, att_rate: torch.Tensor, integ: Optional[torc
         _lib.check(_lib.load().qr_reset(C.byref(e), _p(mask), _stream(pos_vel)), "qr_reset")
 
 
-@torch.library.custom_op(f"{_NS}::qr_traj_start", mutates_args=("traj",))
-def qr_traj_start(pos_vel: torch.Tensor, att_rate: torch.Tensor, traj: torch.Tensor, episode: Optional[torch.Tensor],
+@torch.library.custom_op(f"{_NS}::qr_traj_start", mutates_args=("traj", "goal"))
+def qr_traj_start(pos_vel: torch.Tensor, att_rate: torch.Tensor, traj: torch.Tensor, goal: Optional[torch.Tensor], episode: Optional[torch.Tensor],
                   mask: Optional[torch.Tensor], draws: Optional[torch.Tensor], cfg: List[int], coeffs: List[float]) -> None:
     """TrajectoryGenerator.mark_traj_start for masked envs from the current state (qr_traj_start); draws [3, N] injects
-    theta_b1d, t_traj, w_b1d, default: the env's stream (seed, global env id, episode)."""
-    e = _env_struct(pos_vel, att_rate, None, None, None, traj, episode, None, None, cfg, coeffs)
+    theta_b1d, t_traj, w_b1d, default: the env's stream (seed, global env id, episode).  goal: the env's goal buffer — required
+    (and reset to a fresh generator's xd = vd = Wd = 0, b1d = e1) in the stateful modes 2-5, untouched otherwise."""
+    e = _env_struct(pos_vel, att_rate, None, None, goal, traj, episode, None, None, cfg, coeffs)
     with torch.cuda.device(pos_vel.device):
         _lib.check(_lib.load().qr_traj_start(C.byref(e), _p(mask), _p(draws), _stream(pos_vel)), "qr_traj_start")
 
@@ -271,7 +273,7 @@ def reset(env, env_type: str = "train", mask: Optional[torch.Tensor] = None) -> 
     rcfg[2] = (rcfg[2] & ~3) | (2 if env_type == "eval" else 0)  # clear QR_FLAG_AUTO_RESET, select QR_FLAG_EVAL_RESET
     torch.ops.gym_rotor_amd.qr_reset(t[0], t[1], env._integ, env._params, env._episode, env._steps, mask, rcfg, co)
     if env.goal_mode is not None:
-        torch.ops.gym_rotor_amd.qr_traj_start(t[0], t[1], env._traj, env._episode, mask, None, cfg, co)
+        torch.ops.gym_rotor_amd.qr_traj_start(t[0], t[1], env._traj, env._goal, env._episode, mask, None, cfg, co)
     env._last_obs = None
 
 

@@ -135,13 +135,14 @@ def _twin(kind, n, **kw):
 
 
 def _same_env_state(a, b):
-    for k in ("_pos_vel", "_att_rate", "_integ", "_params", "_traj", "_episode", "_steps", "_reset_count"):
+    for k in ("_pos_vel", "_att_rate", "_integ", "_params", "_goal", "_traj", "_episode", "_steps", "_reset_count"):
         x, y = getattr(a, k), getattr(b, k)
         assert (x is None) == (y is None) and (x is None or torch.equal(x, y)), k
 
 
 @pytest.mark.parametrize("kind,kw", [("quad", dict(auto_reset=True, obs_rows=True, max_episode_steps=30)),
                                      ("coupled", dict(auto_reset=True, goal_mode=0, final_obs=True)),
+                                     ("decoupled", dict(auto_reset=True, goal_mode=5, final_obs=True)),   # a stateful goal mode: the op mutates `goal` too
                                      ("decoupled", dict(auto_reset=True, max_episode_steps=25, final_obs=True, w_adapt=12.0)),
                                      ("coupled", dict(auto_reset=False, layout="f64", substeps=2))])
 def test_torch_custom_ops_match_the_env_bit_for_bit(kind, kw):
