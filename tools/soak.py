@@ -46,4 +46,30 @@ for kind, n in (("quad", 65536), ("coupled", 65536), ("decoupled", 32768)):
             po = env.rollout_actor(actors, 32)
             assert bool(torch.isfinite(po["obs0"]).all()) and bool(torch.isfinite(po["logprob"]).all())
         res[kind]["policy_steps"] = max(1, total // 3200) * 32 * n
+# the fused goal generator, every TrajectoryGenerator mode (0-6; 2-5 = the stateful ones), with a time limit: steps and rollouts alternating
+gsteps = max(200, total // 10)
+for gm in range(7):
+    n = 16384
+    env = QuadVecEnv("decoupled", n, device=dev, auto_reset=True, goal_mode=gm, max_episode_steps=700, seed=9)
+    env.reset("train")
+    env.get_desired(store_goal=True)
+    env.get_norm_error_state()
+    g = torch.Generator(device=dev); g.manual_seed(2)
+    acts = (torch.rand(K, n, 5, device=dev, generator=g) * 2 - 1) * 0.4
+    steps = 0
+    while steps < gsteps:
+        if (steps // K) % 2 == 0:
+            for t in range(K):
+                env.step(acts[t])
+        else:
+            env.rollout(acts)
+        steps += K
+        assert bool(torch.isfinite(env.get_current_state()).all()) and bool(torch.isfinite(env._traj).all())
+        if gm in (2, 3, 4, 5):
+            assert bool(torch.isfinite(env._goal).all())
+            fl = env._traj[3].to(torch.int32)
+            assert bool(((fl >= 0) & (fl < 32) & ((fl & 1) == 1)).all())           # started; only the five flag bits
+            assert bool((((fl & 8) == 0) | ((fl & 4) != 0)).all())                  # manual_init only in manual mode
+            assert bool((env._goal[8] == 0).all()) and float((env._goal[6] ** 2 + env._goal[7] ** 2 - 1).abs().max()) < 1e-5   # b1d a unit heading
+    res[f"decoupled goal_mode {gm}"] = {"env_steps": steps * n}
 print(json.dumps(res))
