@@ -696,7 +696,8 @@ class QuadVecEnv:
     def autotune_launch(self, actions: Optional[torch.Tensor] = None, launches: int = 200, repeats: int = 3):
         """Time step() under the launch-rule choices that exist for this env — the library's default, helper wavefront forced,
         helper wavefront forbidden — and keep the fastest (set_launch).  The env's state, counters and RNG position are restored
-        afterwards: tuning changes no result.  `actions`: the [N, A] rows (or a list of them, cycled through) the caller will
+        afterwards: tuning changes no later result (the env's own OUTPUT buffers — what the last step() returned — are overwritten
+        by the timed launches: copy what you still need before tuning in mid-flight).  `actions`: the [N, A] rows (or a list of them, cycled through) the caller will
         step with; where they come from — cache or HBM — moves the wrappers' crossover, so pass the real source
         when there is one; default: 8 random slabs.  `launches` timed launches per candidate (one hipGraph), best of `repeats`.
         Returns {candidate: us per launch, "picked": name} (also kept as `autotune_report`)."""
