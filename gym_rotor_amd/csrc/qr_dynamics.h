@@ -505,21 +505,44 @@ template <> struct KindTraits<QR_KIND_QUAD>      { static constexpr int A = 4, D
 template <> struct KindTraits<QR_KIND_COUPLED>   { static constexpr int A = 4, D0 = 23, D1 = 0, NAG = 1; };
 template <> struct KindTraits<QR_KIND_DECOUPLED> { static constexpr int A = 5, D0 = 15, D1 = 3, NAG = 2; };
 
+// What the action map needs of the env's PARAMETERS only (quad.py:389-404 and the reciprocals): constant between two resets of an
+// env, so a rollout forms it once per episode instead of once per env-step (~35 instructions, a v_rcp_f64 among them, off the
+// stepping wave's path per step).  The same expressions on the same float32 parameter words as a one-step launch: the same bits.
+template <typename T>
+struct ActConsts {
+  T min_force, max_force, avrg_act, scale_act, d, ctf, J3;
+  T cm;        // 1 / m
+  T iJ1, iJ3;  // 1 / J1, 1 / J3
+  T A1;        // (J1 - J3) / J1
+};
+
+template <typename T, typename X>
+__device__ __forceinline__ void act_consts(const Work<T, X>& w, const Coeffs& c, ActConsts<T>& k) {
+  const Phys<T> ph(w, c);
+  k.min_force = ph.min_force; k.max_force = ph.max_force; k.avrg_act = ph.avrg_act; k.scale_act = ph.scale_act;
+  k.d = ph.d; k.ctf = ph.ctf; k.J3 = ph.J3;
+  // 1/m, 1/J1, 1/J3 from ONE reciprocal (of their product): a v_rcp_f64 + Newton steps is ~9 VALU slots
+  const T mJ1 = ph.m * ph.J1, r = recip(mJ1 * ph.J3);
+  const T rJ3 = r * ph.J3;
+  k.iJ3 = r * mJ1; k.iJ1 = rJ3 * ph.m;
+  k.cm = rJ3 * ph.J1;
+  k.A1 = (ph.J1 - ph.J3) * k.iJ1;
+}
+
 // action_wrapper of the three kinds (quad.py:225-242, coupled:44-53, decoupled:49-59 + 68-73)
 template <int KIND, typename T, typename X>
-__device__ __forceinline__ void action_map(const float* a, const Work<T, X>& w, const Coeffs& c, Dyn<T>& p) {
-  const Phys<T> ph(w, c);
+__device__ __forceinline__ void action_map(const float* a, const Work<T, X>& w, const ActConsts<T>& k, const Coeffs& c, Dyn<T>& p) {
   T f, M1, M2, M3;
   if constexpr (KIND == QR_KIND_QUAD) {
     T t[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) t[j] = clampT(ph.scale_act * T(a[j]) + ph.avrg_act, ph.min_force, ph.max_force);
+    for (int j = 0; j < 4; ++j) t[j] = clampT(k.scale_act * T(a[j]) + k.avrg_act, k.min_force, k.max_force);
     f = ((t[0] + t[1]) + t[2]) + t[3];
-    M1 = ph.d * (t[3] - t[1]);
-    M2 = ph.d * (t[0] - t[2]);
-    M3 = ph.ctf * ((t[1] - t[0]) + (t[3] - t[2]));
+    M1 = k.d * (t[3] - t[1]);
+    M2 = k.d * (t[0] - t[2]);
+    M3 = k.ctf * ((t[1] - t[0]) + (t[3] - t[2]));
   } else {
-    f = clampT(T(4) * (ph.scale_act * T(a[0]) + ph.avrg_act), T(4) * ph.min_force, T(4) * ph.max_force);
+    f = clampT(T(4) * (k.scale_act * T(a[0]) + k.avrg_act), T(4) * k.min_force, T(4) * k.max_force);
     if constexpr (KIND == QR_KIND_COUPLED) {
       M1 = T(a[1]); M2 = T(a[2]); M3 = T(a[3]);
     } else {  // M1 = b1.tau + J3 W3 W2, M2 = b2.tau - J3 W3 W1 from (R, W) at step start
@@ -530,18 +553,15 @@ __device__ __forceinline__ void action_map(const float* a, const Work<T, X>& w, 
       const T b2x = two * fma_sd(qx, qy, qw, qz), b2y = fma_1m2(fma_ss(qx, qx, qz, qz)), b2z = two * fma_ss(qy, qz, qw, qx);
       const T b1t = fmaT(b1x, t1, fmaT(b1y, t2, b1z * t3));
       const T b2t = fmaT(b2x, t1, fmaT(b2y, t2, b2z * t3));
-      const T j3w3 = ph.J3 * w.W[2];
+      const T j3w3 = k.J3 * w.W[2];
       M1 = fmaT(j3w3, w.W[1], b1t);
       M2 = fmaT(-j3w3, w.W[0], b2t);
       M3 = T(a[4]);
     }
   }
-  // 1/m, 1/J1, 1/J3 from ONE reciprocal (of their product): a v_rcp_f64 + Newton steps is ~9 VALU slots
-  const T mJ1 = ph.m * ph.J1, r = recip(mJ1 * ph.J3);
-  const T iJ3 = r * mJ1, rJ3 = r * ph.J3, iJ1 = rJ3 * ph.m;
-  p.c = f * (rJ3 * ph.J1);
-  p.A1 = (ph.J1 - ph.J3) * iJ1;
-  p.U1 = M1 * iJ1; p.U2 = M2 * iJ1; p.U3 = M3 * iJ3;
+  p.c = f * k.cm;
+  p.A1 = k.A1;
+  p.U1 = M1 * k.iJ1; p.U2 = M2 * k.iJ1; p.U3 = M3 * k.iJ3;
   p.g = T(c.g);
 }
 

@@ -119,6 +119,9 @@ __device__ unsigned long long* g_stamps = nullptr;
 #ifndef QR_HELP_REWARD
 #define QR_HELP_REWARD 1        // ... and forms Quad-v0's reward (§3.3 item 2; profiles/r03/ab_quad_builds.txt column q_norew)
 #endif
+#ifndef QR_HOIST_ACT
+#define QR_HOIST_ACT 1          // rollouts form the parameter part of the action map once per episode, not per env-step (profiles/r04/ab_hoist_act.txt)
+#endif
 #ifndef QR_HELPER_GRID
 // Grids up to this many tiles run the one-step kernel with a helper wave per tile (HELP).  The limit is an EMPIRICAL crossover,
 // not a residency rule: 2560 tiles are 5120 waves, more than the 4096 wave slots the 120-VGPR kernel has at four waves per SIMD —
@@ -537,6 +540,15 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     tile_sync<B>();
   }
 
+  // What the action map needs of the PARAMETERS only (masses, inertias, their reciprocals: qr_dynamics.h, ActConsts) changes only
+  // when an env is re-sampled: a rollout forms it here and again behind a reset, not in every env-step.  (Not with the policy in
+  // the loop: those kernels are at their register limit; not for Decoupled, whose rollout kernel is 1 % SLOWER with the 22 more
+  // registers held across the loop.  Measured, profiles/r04/ab_hoist_act.txt: Quad-v0 65 536 envs 1.492 -> 1.469 us per env-step,
+  // 262 144 envs 4.515 -> 4.354 = 60.2 G env-steps/s; Coupled 2.321 -> 2.289.)
+  constexpr bool kHoistAct = QR_HOIST_ACT && !SINGLE && !POLICY && KIND != QR_KIND_DECOUPLED;
+  ActConsts<T> ac;
+  if constexpr (kHoistAct) act_consts(w, c, ac);
+
   for (int t = 0; t < n_steps; ++t) {
     float act[A];
     if constexpr (POLICY) {
@@ -622,7 +634,8 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     QR_STAMP(2, (float)w.q[0] + (float)w.x[0] + act[0] + w.prm[0] + (float)w.W[2]);
     // ---- action_wrapper ----
     Dyn<T> dyn;
-    action_map<KIND, T, X>(act, w, c, dyn);
+    if constexpr (!kHoistAct) act_consts(w, c, ac);
+    action_map<KIND, T, X>(act, w, ac, c, dyn);
     if constexpr (SINGLE && !HELP) {  // (plain one-step launch: the loaded parameters are dead from here on — a re-sampled
 #pragma unroll                        //  env stores the ones it takes from the pool — so their registers need not survive)
       for (int f = 0; f < 6; ++f) w.prm[f] = 0.0f;
@@ -860,6 +873,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         }
         if (early_store) pack_quat(w.q, qp);
       }
+      if constexpr (kHoistAct) act_consts(w, c, ac);  // (some lane of the wave holds new parameters: every lane re-forms — the same values for the others)
     }
     if (!early_store) pack_quat(w.q, qp);
     QR_STAMP(5, (float)w.q[0] + (float)w.x[0] + w.prm[0]);
