@@ -378,3 +378,40 @@ def test_fuzz_configurations_vs_oracle():
         assert np.abs(_np(obs_last).astype(np.float64) - ref_obs).max() <= 5e-6, tag
         if kind != "quad":
             assert np.abs(_np(env._integ[:, :n]).T - it).max() <= 1e-6, tag
+
+
+def test_plain_c_host_of_the_c_abi_matches_the_python_host(tmp_path):
+    """The drop-in boundary is a C-ABI, not a Python module: tests/cabi/host_demo.c — plain C99 built with gcc against
+    include/quadrotor_hip.h, the shared library and the HIP runtime's C API — resets 4 000 Quad-v0 envs, steps them 60 times with
+    in-launch resets and prints state rows and sums; QuadVecEnv driven with the same seed and the same actions gives the same bits."""
+    import subprocess
+    from conftest import ROOT
+    exe = tmp_path / "host_demo"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", f"-I{ROOT}/include",
+           f"{ROOT}/tests/cabi/host_demo.c", f"-L{ROOT}/gym_rotor_amd", "-lquadrotor_hip", "-L/opt/rocm/lib", "-lamdhip64",
+           f"-Wl,-rpath,{ROOT}/gym_rotor_amd", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    n, steps, seed = 4000, 60, 12345
+    r = subprocess.run([str(exe), str(n), str(steps), str(seed)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1000:]
+    lines = [l.split() for l in r.stdout.splitlines() if l and not l.startswith("/opt")]
+    c_done = int(next(l[1] for l in lines if l[0] == "done"))
+    c_sum = np.array([float(l[2]) for l in lines if l[0] == "sum"])
+    c_rows = {}
+    for l in lines:
+        if l[0] == "row":
+            c_rows.setdefault(int(l[1]), []).append(float(l[3]))
+    env = _env("quad", n, seed=seed, auto_reset=True)
+    env.reset("train")
+    i = torch.arange(n, device="cuda")[:, None]
+    j = torch.arange(4, device="cuda")[None, :]
+    total = 0
+    for t in range(steps):
+        act = (((i * 7 + j * 3 + t * 5) % 21) - 10).to(torch.float32) * 0.1
+        _, _, done, _, _ = env.step(act.contiguous())
+        total += int(done.sum())
+    st = _np(env.get_current_state())
+    assert total == c_done and total > 0
+    assert np.array_equal(st.sum(0), c_sum) or np.allclose(st.sum(0), c_sum, rtol=0, atol=1e-9)   # (summation order: C loop vs NumPy pairwise)
+    for k, row in c_rows.items():
+        assert np.array_equal(st[k], np.array(row)), k                                              # the rows themselves: bit for bit

@@ -97,6 +97,19 @@ def test_ctypes_structs_mirror_the_header(tmp_path):
             assert int(out[f"{sname}.{f}"]) == getattr(ct, f).offset, (sname, f)
 
 
+def test_plain_c_host_builds_against_the_header(tmp_path):
+    """tests/cabi/host_demo.c — a C99 host of the C-ABI (no Python, no HIP compiler: gcc + the HIP runtime's C API) — compiles with
+    -Wall -Werror against include/quadrotor_hip.h and links against the library.  (It RUNS, and matches the Python host bit for
+    bit, in the GPU suite: test_plain_c_host_of_the_c_abi_matches_the_python_host.)"""
+    _lib()
+    exe = tmp_path / "host_demo"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", f"-I{ROOT}/include",
+           f"{ROOT}/tests/cabi/host_demo.c", f"-L{ROOT}/gym_rotor_amd", "-lquadrotor_hip", "-L/opt/rocm/lib", "-lamdhip64",
+           f"-Wl,-rpath,{ROOT}/gym_rotor_amd", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0 and exe.exists(), r.stderr[-1500:]
+
+
 def test_abi_argument_errors_without_gpu():
     L = _lib()
     lib = L.load()
