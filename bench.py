@@ -68,6 +68,7 @@ PRESETS = {1: dict(kind="quad", envs=65536, substeps=1, total=65536, slabs=64, n
            3: dict(kind="decoupled", envs=32768, substeps=1, total=262144, slabs=64, name="configs[3]: DecoupledWrapper two-agent, 262 144 envs over 8 GPUs = 32 768 per GPU"),
            4: dict(kind="quad", envs=131072, substeps=10, total=1048576, slabs=32, name="configs[4]: Quad-v0 1 048 576 envs over 8 GPUs = 131 072 per GPU, 10 substeps")}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_COPY_GBS = 6290.0  # that measured copy ceiling: SURVEY.md 8(d) asks for the fraction of both
 
 
 def parse():
@@ -459,7 +460,8 @@ def main():
                        "wall_ms_per_step": wall_ms_per_step,
                        "wall_note": "host clock around lead-in + K steps incl. graph submission and synchronize, / (K + lead-in)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": (traffic or {}).get("bytes_per_launch"),
+                         "frac": achieved / HBM_PEAK_GBS, "frac_of_copy_ceiling": achieved / HBM_COPY_GBS,
+                         "copy_ceiling": HBM_COPY_GBS, "traffic": (traffic or {}).get("bytes_per_launch"),
                          "traffic_source": (traffic or {}).get("source"),
                          "kernel": kname, "grid": grid, "block": block, "avg_launch_us": launch_us,
                          # the committed rocprofv3 --kernel-trace figure of the same command, for comparison: the tool costs
