@@ -58,7 +58,7 @@ __device__ __forceinline__ void traj_start(Work<T, X>& w, Traj& tr, int goal_mod
   } else {  // mode 1: x_init + draws; mode 6: eight_shaped_center = x (:430), no draws
     tr.p2 = w_b1d;
     tr.p3 = 6.907755278982137f / t_traj;  // -ln(0.001) / t_traj
-tr.x0 = (float)w.x[0]; tr.x1 = (float)w.x[1]; tr.x2 = (float)w.x[2];
+    tr.x0 = (float)w.x[0]; tr.x1 = (float)w.x[1]; tr.x2 = (float)w.x[2];
   }
 }
 
@@ -178,7 +178,7 @@ __device__ __forceinline__ void traj_goal(Work<T, X>& w, Traj& tr, int goal_mode
     const float t = tr.calls * (2.0f * c.hdt);
     const float wb = tr.p2, sm = tr.p3;
     const float e = expf(-sm * t);
-const float xi[3] = {tr.x0, tr.x1, tr.x2};
+    const float xi[3] = {tr.x0, tr.x1, tr.x2};
 #pragma unroll
     for (int j = 0; j < 3; ++j) { w.goal[j] = xi[j] * e; w.goal[3 + j] = -xi[j] * sm * e; }
     float sn, cs;
