@@ -67,6 +67,19 @@ PRESETS = {1: dict(kind="quad", envs=65536, substeps=1, total=65536, slabs=64, n
            2: dict(kind="coupled", envs=65536, substeps=1, total=65536, slabs=64, name="configs[2]: CoupledWrapper 65 536 envs + reward/done"),
            3: dict(kind="decoupled", envs=32768, substeps=1, total=262144, slabs=64, name="configs[3]: DecoupledWrapper two-agent, 262 144 envs over 8 GPUs = 32 768 per GPU"),
            4: dict(kind="quad", envs=131072, substeps=10, total=1048576, slabs=32, name="configs[4]: Quad-v0 1 048 576 envs over 8 GPUs = 131 072 per GPU, 10 substeps")}
+# What the default 1-GPU run measures BESIDE the headline (config.baseline_configs), each through the same run() harness — hipGraph,
+# lead-in, >= 20 repetitions, HIP events — as the headline itself: the other BASELINE.json configs in their per-GPU and one-GPU
+# shapes, SURVEY.md 8(d)'s fused rollout, and configs[2]'s PPO collection loop.  `steps` = env-steps per timed repetition.
+BASELINE_CONFIGS = [
+    dict(name="configs[2] CoupledWrapper 65 536", kind="coupled", envs=65536, substeps=1, workload="step", horizon=1, steps=300, slabs=64),
+    dict(name="configs[3] DecoupledWrapper 32 768 (per-GPU share of 262 144)", kind="decoupled", envs=32768, substeps=1, workload="step", horizon=1, steps=300, slabs=64),
+    dict(name="configs[3] DecoupledWrapper 262 144 (one GPU)", kind="decoupled", envs=262144, substeps=1, workload="step", horizon=1, steps=300, slabs=32),
+    dict(name="configs[4] Quad-v0 131 072 x 10 substeps (per-GPU share of 1 048 576)", kind="quad", envs=131072, substeps=10, workload="step", horizon=1, steps=300, slabs=32),
+    dict(name="configs[4] Quad-v0 1 048 576 x 10 substeps (one GPU)", kind="quad", envs=1048576, substeps=10, workload="step", horizon=1, steps=150, slabs=16),
+    dict(name="Quad-v0 1 048 576 x 1 substep (one GPU, the HBM-roofline row)", kind="quad", envs=1048576, substeps=1, workload="step", horizon=1, steps=300, slabs=16),
+    dict(name="rollout T=100 Quad-v0 65 536 (SURVEY 8(d) config 2, fused)", kind="quad", envs=65536, substeps=1, workload="rollout", horizon=100, steps=1000, slabs=4),
+    dict(name="rollout_actor T=32 CoupledWrapper 65 536 (configs[2] PPO collection, actor in the kernel)", kind="coupled", envs=65536, substeps=1, workload="rollout_actor", horizon=32, steps=960, slabs=4),
+]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 HBM_COPY_GBS = 6290.0  # that measured copy ceiling: SURVEY.md 8(d) asks for the fraction of both
 
@@ -84,9 +97,13 @@ def parse():
     p.add_argument("--auto-reset", action=argparse.BooleanOptionalAction, default=True,
                    help="re-sample terminated envs inside the launch (what a loop that steps the reference's env does on done); "
                         "--no-auto-reset = T free-running random-action steps from one reset")
-    p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
+    p.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline leg (0 = skip)")
     p.add_argument("--action-batches", type=int, default=64, help="distinct pre-generated [N,A] action slabs cycled through (64 x 1 MiB > L2: every step streams its actions)")
-    p.add_argument("--extras", type=int, default=1, help="0: only the headline measurement (used under rocprofv3)")
+    p.add_argument("--extras", type=int, default=1, help="0: only the headline measurement (used under rocprofv3); 1: + config.other_reset_mode and "
+                                                         "config.baseline_configs within --extras-budget; 2: all of them whatever they take")
+    p.add_argument("--extras-budget", type=float, default=60.0, help="seconds after which the remaining baseline_configs rows are skipped (--extras 1)")
+    p.add_argument("--actor", default="ppo", choices=["ppo", "sac"], help="--workload rollout_actor: the actor form (ppo: parameter log_std, "
+                                                                            "tanh-of-mean rule; sac: state-dependent log_std head, tanh-of-sample rule = the POLICY=2 kernel)")
     p.add_argument("--workload", default="step", choices=["step", "rollout", "rollout_actor"],
                    help="step: one qr_step launch per env-step (the metric's configuration).  rollout: --horizon env-steps per qr_rollout "
                         "launch, state in registers (SURVEY.md 8(d) config 2).  rollout_actor: the PPO collection loop with the actor inside "
@@ -265,6 +282,21 @@ def _spawn_ranks(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def algo_bytes_per_env_step(kind: str, workload: str = "step", H: int = 1) -> float:
+    """SURVEY.md 8(d) algorithmic bytes per env-step.  One-step launches: the per-kind figure + 24 B of per-env parameters
+    (Quad-v0 165 + 24 = 189, Coupled 321 + 24, Decoupled 310 + 24).  Rollout launches: per step only what crosses memory EVERY
+    step — action row in (or, with the actor in the kernel, action + log-prob rows out), reward, done, [observation rows] —
+    plus the launch's once-per-horizon share of the working set (state r/w 144, params 24, integrators r/w 64)."""
+    from gym_rotor_amd.constants import ALGO_BYTES, ALGO_BYTES_PARAMS
+    if workload == "step":
+        return ALGO_BYTES[kind] + ALGO_BYTES_PARAMS
+    per_step_io = {"quad": 16 + 4 + 1, "coupled": 16 + 92 + 4 + 1, "decoupled": 20 + 72 + 8 + 2}[kind]
+    if workload == "rollout_actor":
+        per_step_io += {"coupled": 16, "decoupled": 20}[kind]          # action AND log-prob rows are written
+    once = 144 + 24 + (64 if kind != "quad" else 0)
+    return per_step_io + once / H
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -276,8 +308,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     _ensure_library(dist, local_rank)
-    from gym_rotor_amd import ALGO_BYTES, QuadVecEnv, shard_range
-    from gym_rotor_amd.constants import ALGO_BYTES_PARAMS
+    from gym_rotor_amd import QuadVecEnv, shard_range
     if a.scaling == "strong":      # a fixed global batch, this rank's 64-aligned shard of it (no collective on the step path either way)
         G = a.global_envs
         lo, hi = shard_range(G, rank, world)
@@ -293,46 +324,48 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def run(ar: bool, timed: bool):
-        """W warm-up steps, then repetitions of exactly K timed steps; returns the per-repetition
-        (HIP-event ms, wall ms) lists and a few facts about the final state."""
-        H = a.horizon
-        env = QuadVecEnv(a.kind, N, device=dev, seed=0, substeps=a.substeps, layout=a.layout, use_UDM=True,
-                         auto_reset=ar, env_offset=env_offset, helper=TRI[a.helper],
-                         **({"obs_rows": True} if a.workload == "rollout_actor" else {}))
+    def run(w, ar: bool, timed: bool):
+        """`w` = the workload (kind, envs, env_offset, substeps, workload, horizon, steps, slabs, helper, actor).  W warm-up
+        steps, then repetitions of exactly K = w.steps timed env-steps; returns the per-repetition (HIP-event ms, wall ms) lists
+        and a few facts about the final state.  timed=False: no cross-rank barrier (rank-0-only secondary measurements)."""
+        H, K, n = w.horizon, w.steps, w.envs
+        env = QuadVecEnv(w.kind, n, device=dev, seed=0, substeps=w.substeps, layout=a.layout, use_UDM=True,
+                         auto_reset=ar, env_offset=w.env_offset, helper=TRI[w.helper],
+                         **({"obs_rows": True} if w.workload == "rollout_actor" else {}))
 
         def fresh():  # the timed steps start from reset-distribution states (configs[1])
             env.reset("train")
-            if a.kind != "quad":
+            if w.kind != "quad":
                 env.get_norm_error_state()
 
         fresh()
         gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
-        if a.workload == "step":
-            acts = [torch.rand(N, env.action_dim, device=dev, generator=gen) * 2 - 1 for _ in range(a.action_batches)]
+        if w.workload == "step":
+            acts = [torch.rand(n, env.action_dim, device=dev, generator=gen) * 2 - 1 for _ in range(w.slabs)]
             launch = lambda i: env.step(acts[i % len(acts)])                      # noqa: E731
             last_done = lambda: env._done                                          # noqa: E731
-        elif a.workload == "rollout":   # [H, N, A] action slabs (4 x 105 MB at H = 100: streamed from HBM) and preallocated outputs
-            acts = [torch.rand(H, N, env.action_dim, device=dev, generator=gen) * 2 - 1 for _ in range(min(a.action_batches, 4))]
+        elif w.workload == "rollout":   # [H, N, A] action slabs (4 x 105 MB at H = 100: streamed from HBM) and preallocated outputs
+            acts = [torch.rand(H, n, env.action_dim, device=dev, generator=gen) * 2 - 1 for _ in range(min(w.slabs, 4))]
             ro = env.rollout(acts[0])
             launch = lambda i: env.rollout(acts[i % len(acts)], out=ro)            # noqa: E731
             last_done = lambda: ro["terminated"][H - 1]                            # noqa: E731
         else:                           # the actor(s) inside the step kernel, exploration noise drawn in the kernel
             from gym_rotor_amd import random_actors
-            actors = random_actors(a.kind, dev, generator=torch.Generator(device=dev).manual_seed(7), log_std=-0.5)
+            actors = random_actors(w.kind, dev, generator=torch.Generator(device=dev).manual_seed(7), log_std=-0.5,
+                                   **({"algo": w.actor} if w.actor != "ppo" else {}))
             po = env.rollout_actor(actors, H)
             pout = {k: v for k, v in po.items() if k != "obs"}
             launch = lambda i: env.rollout_actor(actors, H, out=pout)              # noqa: E731
             last_done = lambda: pout["terminated"][H - 1]                          # noqa: E731
-        n_launch = a.steps // H
+        n_launch = K // H
         for i in range(-(-a.warmup // H)):
             launch(i)
         # untimed lead-in of every repetition: long enough (~1.5 ms) to bring the chip back to its busy clocks after the
         # barrier's idle gap — the first ~50 launches after an idle period run 5-20 % slow — and to keep the queue ahead
-        n_lead = max(10, 300 - a.steps) if H == 1 else max(1, 300 // H)     # (in launches)
+        n_lead = max(10, 300 - K) if H == 1 else max(1, 300 // H)     # (in launches)
         # a graph launch costs a fixed ~9 us on the device whatever it holds (measured: the 20-step graph ran 8 % slower per step
         # than the 1000-step one): for small K the timed graph holds `copies` back-to-back copies of the K steps
-        copies = max(1, -(-300 // a.steps)) if a.mode == "graph" else 1
+        copies = max(1, -(-300 // K)) if a.mode == "graph" else 1
         graph = lead = None
         side = torch.cuda.Stream(dev)
         if a.mode == "graph":
@@ -386,7 +419,7 @@ def main():
             wall_ms.append((time.perf_counter() - t0) * 1e3)
             dev_ms.append(ev0.elapsed_time(ev1) / copies)
             done_reps = len(dev_ms)
-            stop = done_reps >= reps_max or (done_reps >= reps_min and sum(dev_ms) >= budget_ms)
+            stop = done_reps >= reps_max or (done_reps >= reps_min and sum(dev_ms) * copies >= budget_ms)
             if dist is not None and timed:  # all ranks stop together (the barrier count must match)
                 flag = torch.tensor([1 if stop else 0], dtype=torch.int32, device=dev if on_dev else "cpu")
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -397,7 +430,10 @@ def main():
         done_rate = float(last_done().float().mean())
         return dev_ms, wall_ms, finite, done_rate, env.kernel_info(H), n_lead * H, copies
 
-    dev_ms, wall_ms, finite, done_rate, kinfo, n_lead, copies = run(auto_reset, True)
+    from types import SimpleNamespace as NS
+    head = NS(kind=a.kind, envs=N, env_offset=env_offset, substeps=a.substeps, workload=a.workload, horizon=a.horizon, steps=a.steps,
+              slabs=a.action_batches, helper=a.helper, actor=a.actor)
+    dev_ms, wall_ms, finite, done_rate, kinfo, n_lead, copies = run(head, auto_reset, True)
     reps = len(dev_ms)
     med_dev, med_wall = float(np.median(dev_ms)), float(np.median(wall_ms))
     tmax = torch.tensor([med_dev, med_wall], dtype=torch.float64, device=dev if on_dev else "cpu")
@@ -415,16 +451,7 @@ def main():
         ms_per_step = med_dev / a.steps              # THE clock of this line: HIP events around the K steps
         launch_us = ms_per_step * 1e3 * H            # duration of one launch (= H env-steps)
         wall_ms_per_step = med_wall / (a.steps * copies + n_lead)
-        algo = ALGO_BYTES[a.kind] + ALGO_BYTES_PARAMS
-        # Algorithmic bytes per env-step of the rollout launches: per step only what crosses memory EVERY step — action row in
-        # (or, with the actor in the kernel, action + log-prob rows out), reward, done, [observation rows] — plus the launch's
-        # once-per-horizon share of the working set (state r/w, params, integrators r/w).
-        per_step_io = {"quad": 16 + 4 + 1, "coupled": 16 + 92 + 4 + 1, "decoupled": 20 + 72 + 8 + 2}[a.kind]
-        if a.workload == "rollout_actor":
-            per_step_io += {"coupled": 16, "decoupled": 20}[a.kind]          # action AND log-prob rows are written
-        once = 144 + 24 + (64 if a.kind != "quad" else 0)
-        if a.workload != "step":
-            algo = per_step_io + once / H
+        algo = algo_bytes_per_env_step(a.kind, a.workload, H)
         # bytes this layout really moves per env-step: 12-word state r/w (x, v, smallest-three quaternion, W), action, [integ r/w, obs rows],
         # reward, done, params
         state_b = {"mixed": 6 * 4 + 6 * 8, "f64": 12 * 8, "f32": 12 * 4}[a.layout] * 2
@@ -482,43 +509,40 @@ def main():
                                  "tile (reset pool, Quad-v0 reward, observation rows); DESIGN.md 3.5, 5"},
         }
         if n_gpus == 1 and a.extras and a.workload == "step":
-            # secondary figure: the other reset mode (no reset inside step = the reference's own semantics)
-            d2, _, _, _, _, _, _ = run(not auto_reset, False)
+            t_extra = time.perf_counter()
+            # the other reset mode of the headline workload (no reset inside step = the reference's own semantics: the population
+            # flies on beyond termination and the rate-adaptive kernel is the one launched)
+            d2 = run(head, not auto_reset, False)[0]
             us2 = float(np.median(d2)) * 1e3 / a.steps
-            out["config"]["other_reset_mode"] = {"auto_reset": not auto_reset, "env_steps_per_s": N / (us2 * 1e-6), "avg_launch_us": us2}
-            # secondary figure: fused rollout, T=100 env-steps per launch with the state in registers
-            # (SURVEY.md 8(d) config 2 asks for both per-launch step() and rollout(T=100))
-            env = QuadVecEnv(a.kind, N, device=dev, seed=0, substeps=a.substeps, layout=a.layout, use_UDM=True,
-                             auto_reset=auto_reset)
-            env.reset("train")
-            acts = torch.rand(100, N, env.action_dim, device=dev) * 2 - 1
-            ro = env.rollout(acts)
-            torch.cuda.synchronize(dev)
-            ts = []
-            for _ in range(5):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(); env.rollout(acts, out=ro); e1.record(); torch.cuda.synchronize(dev)
-                ts.append(e0.elapsed_time(e1))
-            t100 = float(np.median(ts))
-            out["config"]["rollout_T100"] = {"env_steps_per_s": N * 100 / (t100 * 1e-3), "us_per_env_step_batch": t100 * 10.0}
-            # secondary figure: the PPO collection loop of BASELINE configs[2] with the actor inside the
-            # step kernel (qr_rollout_actor): CoupledWrapper, T = 32 steps per launch, auto-reset, in-kernel noise
-            from gym_rotor_amd import random_actors
-            penv = QuadVecEnv("coupled", N, device=dev, seed=0, substeps=a.substeps, layout=a.layout, auto_reset=True, obs_rows=True)
-            penv.reset("train")
-            penv.get_norm_error_state()
-            actors = random_actors("coupled", dev, generator=torch.Generator(device=dev).manual_seed(7), log_std=-0.5)
-            po = penv.rollout_actor(actors, 32)
-            torch.cuda.synchronize(dev)
-            ts = []
-            for _ in range(5):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(); penv.rollout_actor(actors, 32, out={k: v for k, v in po.items() if k != "obs"}); e1.record()
-                torch.cuda.synchronize(dev)
-                ts.append(e0.elapsed_time(e1))
-            best = float(np.median(ts))
-            out["config"]["policy_rollout_coupled_T32"] = {"env_steps_per_s": N * 32 / (best * 1e-3), "us_per_env_step_batch": best * 1e3 / 32,
-                                                           "what": "CoupledWrapper env + 23->16->16->4 PPO actor (MFMA) + sampling in one launch per horizon"}
+            out["config"]["other_reset_mode"] = {
+                "mode": ("free run from one reset: auto_reset=False, reset_on_done=False (rate-adaptive kernel), the K steps that follow a reset"
+                         if auto_reset else "auto_reset=True: terminated envs re-sampled in the launch"),
+                "auto_reset": not auto_reset, "env_steps_per_s": N / (us2 * 1e-6), "avg_launch_us": us2}
+            # every other BASELINE.json config (per-GPU and one-GPU shapes), the fused rollout and the PPO collection loop, each
+            # through the SAME harness as the headline: hipGraph, lead-in, >= 20 repetitions, HIP events, median
+            rows = []
+            for spec in BASELINE_CONFIGS:
+                if a.extras < 2 and time.perf_counter() - t_extra > a.extras_budget:
+                    rows.append({"name": spec["name"], "skipped": f"--extras-budget {a.extras_budget:g} s spent"})
+                    continue
+                w = NS(kind=spec["kind"], envs=spec["envs"], env_offset=0, substeps=spec["substeps"], workload=spec["workload"],
+                       horizon=spec["horizon"], steps=spec["steps"], slabs=spec["slabs"], helper="auto", actor="ppo")
+                t_row = time.perf_counter()
+                dms, _, fin, drate, kinf, _, _ = run(w, True, False)
+                us_step = float(np.median(dms)) * 1e3 / w.steps          # per env-step of the whole batch
+                ab = algo_bytes_per_env_step(w.kind, w.workload, w.horizon)
+                gbs = ab * w.envs / (us_step * 1e-6) / 1e9
+                rows.append({"name": spec["name"], "kind": w.kind, "envs": w.envs, "substeps": w.substeps, "workload": w.workload,
+                             "env_steps_per_launch": w.horizon, "us_per_launch": us_step * w.horizon, "us_per_env_step": us_step,
+                             "env_steps_per_s": w.envs / (us_step * 1e-6), "algorithmic_bytes": ab * w.envs * w.horizon,
+                             "algorithmic_bytes_per_env_step": ab, "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS,
+                             "frac_of_copy_ceiling": gbs / HBM_COPY_GBS, "grid": kinf[1], "block": kinf[2], "repetitions": len(dms),
+                             "state_finite": fin, "done_rate_last_step": drate, "measure_s": time.perf_counter() - t_row})
+                torch.cuda.empty_cache()
+            out["config"]["baseline_configs"] = rows
+            out["config"]["baseline_configs_note"] = ("same harness as the headline (hipGraph of the K env-steps, untimed lead-in, >= 20 repetitions and >= 50 ms "
+                                                      "of timed work, HIP events, median); auto_reset=True, UDM parameters, 16-64 action slabs cycled")
+            out["config"]["extras_s"] = time.perf_counter() - t_extra
         if n_gpus == 1 and a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(a.kind, a.cpu_seconds)
         print(json.dumps(out))

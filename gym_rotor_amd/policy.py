@@ -116,5 +116,18 @@ def c_actor_array(actors: Sequence[ActorParams]):
     return arr
 
 
-def random_actors(kind: str, device, generator=None, log_std: float = 0.0) -> List[ActorParams]:
-    return [ActorParams.random(*d, device=device, generator=generator, log_std=log_std) for d in ACTOR_DIMS[kind]]
+def random_actors(kind: str, device, generator=None, log_std: float = 0.0, algo: str = "ppo") -> List[ActorParams]:
+    """Random-init actors of the reference's sizes for `kind`.  algo='ppo' (also TD3's form): parameter log_std, tanh-of-mean rule.
+    algo='sac': MLP_Actor_SAC's form — a state-dependent log_std head (bias = log_std, weights x0.1) and the tanh-of-sample rule
+    (sac_mlp.py:60-82), i.e. what rollout_actor runs in its general (POLICY = 2) kernel."""
+    if algo not in ("ppo", "sac"):
+        raise ValueError("algo must be 'ppo' or 'sac'")
+    actors = [ActorParams.random(*d, device=device, generator=generator, log_std=log_std) for d in ACTOR_DIMS[kind]]
+    if algo == "sac":
+        for a in actors:
+            _, hidden, adim = a.dims
+            k = hidden ** -0.5
+            a.log_std_w = (torch.rand(adim, hidden, device=device, generator=generator) * 2 - 1) * k * 0.1
+            a.log_std_b = torch.full((adim,), float(log_std), device=device)
+            a.log_std, a.squash = None, _lib.ACTOR_TANH_SAMPLE
+    return actors

@@ -442,6 +442,18 @@ def test_bench_presets_and_scaling_flags_without_gpu(monkeypatch):
     assert parse("--scaling", "strong").global_envs == 65536 and parse("--scaling", "strong", "--envs", "4096").global_envs == 4096
     assert parse("--scaling", "strong", "--global-envs", "777").global_envs == 777
     assert parse("--config", "2").kind == "coupled" and parse("--config", "1").envs == 65536
+    # what the default 1-GPU run measures beside the headline (config.baseline_configs): every other BASELINE.json config in its
+    # per-GPU and one-GPU shape, the fused rollout and the PPO collection loop — eight rows, each priced with SURVEY 8(d)'s bytes
+    shapes = [(c["kind"], c["envs"], c["substeps"], c["workload"], c["horizon"]) for c in bench.BASELINE_CONFIGS]
+    assert shapes == [("coupled", 65536, 1, "step", 1), ("decoupled", 32768, 1, "step", 1), ("decoupled", 262144, 1, "step", 1),
+                      ("quad", 131072, 10, "step", 1), ("quad", 1048576, 10, "step", 1), ("quad", 1048576, 1, "step", 1),
+                      ("quad", 65536, 1, "rollout", 100), ("coupled", 65536, 1, "rollout_actor", 32)]
+    assert all(c["steps"] % c["horizon"] == 0 and c["slabs"] * c["envs"] * 20 < 2 ** 31 for c in bench.BASELINE_CONFIGS)
+    assert [bench.algo_bytes_per_env_step(k) for k in ("quad", "coupled", "decoupled")] == [189, 345, 334]
+    assert abs(bench.algo_bytes_per_env_step("quad", "rollout", 100) - (21 + 168 / 100)) < 1e-12
+    assert abs(bench.algo_bytes_per_env_step("coupled", "rollout_actor", 32) - (129 + 232 / 32)) < 1e-12
+    a = parse()
+    assert a.extras == 1 and a.extras_budget > 0 and a.actor == "ppo" and parse("--actor", "sac").actor == "sac"
 
 
 def test_bench_gpus_n_spawns_its_own_ranks_without_gpu(monkeypatch):
