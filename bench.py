@@ -109,7 +109,7 @@ def parse():
                         "launch, state in registers (SURVEY.md 8(d) config 2).  rollout_actor: the PPO collection loop with the actor inside "
                         "the step kernel (qr_rollout_actor; BASELINE configs[2]; --kind coupled|decoupled).  --steps counts env-steps in all three")
     p.add_argument("--horizon", type=int, default=0, help="env-steps per launch of the rollout workloads (default 100 / 32)")
-    p.add_argument("--helper", default="auto", choices=["auto", "on", "off"], help="launch rule override: a helper wavefront per tile (QR_FLAG_FORCE_HELPER / QR_FLAG_NO_HELPER)")
+    p.add_argument("--helper", default="auto", choices=["auto", "on", "off"], help="launch rule override: a helper wavefront per tile (QR_FLAG_FORCE_HELPER / QR_FLAG_NO_HELPER; their _ROLLOUT twins for the rollout workloads)")
     p.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4],
                    help="preset = BASELINE.json configs[k] in its per-GPU shape: 1 Quad-v0 65 536 envs (the default run); 2 CoupledWrapper 65 536; "
                         "3 DecoupledWrapper 32 768 per GPU (262 144 over 8 GPUs); 4 Quad-v0 131 072 per GPU x 10 substeps (1 048 576 over 8 GPUs). "
@@ -330,7 +330,7 @@ def main():
         and a few facts about the final state.  timed=False: no cross-rank barrier (rank-0-only secondary measurements)."""
         H, K, n = w.horizon, w.steps, w.envs
         env = QuadVecEnv(w.kind, n, device=dev, seed=0, substeps=w.substeps, layout=a.layout, use_UDM=True,
-                         auto_reset=ar, env_offset=w.env_offset, helper=TRI[w.helper],
+                         auto_reset=ar, env_offset=w.env_offset, **{"helper" if w.workload == "step" else "helper_rollout": TRI[w.helper]},
                          **({"obs_rows": True} if w.workload == "rollout_actor" else {}))
 
         def fresh():  # the timed steps start from reset-distribution states (configs[1])

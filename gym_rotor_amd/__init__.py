@@ -7,7 +7,7 @@ DecoupledWrapper), executed by hand-written HIP kernels for gfx950 behind a C-AB
 from .constants import ACTION_DIM, ALGO_BYTES, FRAMEWORK, KINDS, N_AGENTS, OBS_DIMS, QuadConstants  # noqa: F401
 from .spaces import Box  # noqa: F401
 from .sharding import shard_range, make_sharded_env, all_gather_rows  # noqa: F401
-from .vec_env import QuadVecEnv, as_gymnasium_vector_env  # noqa: F401
+from .vec_env import CapturedStep, QuadVecEnv, as_gymnasium_vector_env  # noqa: F401
 from .compat import QuadEnv, CoupledWrapper, DecoupledWrapper  # noqa: F401
 from .rollout import RolloutStorage  # noqa: F401
 from .policy import ActorParams, random_actors  # noqa: F401

@@ -16,9 +16,10 @@ LIB_PATH = os.environ.get("QR_LIB", os.path.join(_HERE, "libquadrotor_hip.so"))
 KIND_QUAD, KIND_COUPLED, KIND_DECOUPLED = 0, 1, 2
 KIND_ID = {"quad": KIND_QUAD, "coupled": KIND_COUPLED, "decoupled": KIND_DECOUPLED}
 FLAG_AUTO_RESET, FLAG_EVAL_RESET, FLAG_NO_UDM = 1, 2, 4
-FLAG_FORCE_HELPER, FLAG_NO_HELPER = 8, 16   # launch-rule overrides (speed only)
-FLAG_CALLER_RESETS = 32                     # the caller resets every done env before stepping it again
-ABI_VERSION = 12
+FLAG_FORCE_HELPER, FLAG_NO_HELPER = 8, 16   # launch-rule overrides of the one-step launch (speed only)
+FLAG_CALLER_RESETS = 32                     # the caller resets every done env before stepping it again (one-step launches)
+FLAG_FORCE_HELPER_ROLLOUT, FLAG_NO_HELPER_ROLLOUT = 64, 128   # the same overrides for qr_rollout / qr_rollout_actor
+ABI_VERSION = 13
 GOAL_EXTERNAL, GOAL_MODE0, GOAL_MODE1, GOAL_MODE6, GOAL_MODE2, GOAL_MODE3, GOAL_MODE4, GOAL_MODE5 = 0, 1, 2, 3, 4, 5, 6, 7
 GOAL_ID = {None: 0, 0: 1, 1: 2, 6: 3, 2: 4, 3: 5, 4: 6, 5: 7}  # TrajectoryGenerator mode -> QR_GOAL_*
 LAYOUT_ID = {"mixed": 0, "f64": 1, "f32": 2}
@@ -27,9 +28,9 @@ ERRORS = {-1: "QR_E_NULL: a required pointer is NULL", -2: "QR_E_KIND: bad env k
           -3: "QR_E_SIZE: bad num_envs / substeps / n_steps / coefficients", -4: "QR_E_ALIGN: buffer not 16-byte aligned"}
 
 # every symbol include/quadrotor_hip.h declares
-SYMBOLS = ("qr_step", "qr_rollout", "qr_rollout_actor", "qr_error_obs", "qr_reset", "qr_get_state", "qr_set_state", "qr_check_state",
+SYMBOLS = ("qr_step", "qr_rollout", "qr_rollout_actor", "qr_error_obs", "qr_error_obs_format", "qr_reset", "qr_get_state", "qr_set_state", "qr_check_state",
            "qr_traj_start", "qr_get_desired", "qr_gae",
-           "qr_default_coeffs", "qr_abi_version", "qr_step_kernel_info")
+           "qr_default_coeffs", "qr_abi_version", "qr_step_kernel_info", "qr_launch_thresholds")
 
 
 class QrCoeffs(C.Structure):
@@ -105,6 +106,8 @@ def load():
     lib.qr_rollout_actor.argtypes = [P(QrEnv), P(QrPolicyRollout), C.c_int32, C.c_int32, P(QrStepOut), C.c_void_p]
     lib.qr_error_obs.restype = C.c_int
     lib.qr_error_obs.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.qr_error_obs_format.restype = C.c_int
+    lib.qr_error_obs_format.argtypes = [P(QrEnv), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.qr_reset.restype = C.c_int
     lib.qr_reset.argtypes = [P(QrEnv), C.c_void_p, C.c_void_p]
     lib.qr_get_state.restype = C.c_int
@@ -122,6 +125,8 @@ def load():
                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.qr_step_kernel_info.restype = C.c_char_p
     lib.qr_step_kernel_info.argtypes = [P(QrEnv), C.c_int32, P(C.c_int32), P(C.c_int32)]
+    lib.qr_launch_thresholds.restype = None
+    lib.qr_launch_thresholds.argtypes = [P(C.c_int32), P(C.c_int32), P(C.c_int32)]
     if lib.qr_abi_version() != ABI_VERSION:
         raise QuadrotorLibError(f"ABI mismatch: library {lib.qr_abi_version()} vs binding {ABI_VERSION}")
     _lib = lib
@@ -140,3 +145,10 @@ def check(rc: int, what: str):
     if rc < 0:
         raise ValueError(f"{what}: {ERRORS.get(rc, rc)}")
     raise QuadrotorLibError(f"{what}: hipError_t {rc}")
+
+
+def launch_thresholds() -> dict:
+    """The launch rule's helper-wavefront thresholds of this process, in 64-env tiles (qr_launch_thresholds)."""
+    q, w, r = C.c_int32(), C.c_int32(), C.c_int32()
+    load().qr_launch_thresholds(C.byref(q), C.byref(w), C.byref(r))
+    return {"step_quad": q.value, "step_wrappers": w.value, "rollout": r.value}

@@ -70,7 +70,7 @@ struct Args {
   const float* draws;     // qr_traj_start: injected [3][N] theta_b1d, t_traj, w_b1d
   float* goal_rows;       // qr_get_desired: [N][15]
   int32_t goal_mode;
-  int32_t store_goal;
+  int32_t store_goal;     // qr_get_desired: also write the goal buffer
   int64_t n;
   int64_t ld;             // elements between consecutive fields of every SoA buffer (>= n)
   int64_t env_offset;
@@ -90,6 +90,8 @@ struct Args {
   uint64_t step_base;
   float max_action;
   int32_t deterministic;
+  int32_t dry_run;        // qr_check_state: set_state_kernel validates and counts, writes nothing
+  int32_t pad0;
   Coeffs c;
 };
 

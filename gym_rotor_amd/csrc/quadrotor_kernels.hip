@@ -280,7 +280,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   if constexpr (HELP) {
     // (the wave's first lane decides: a wave-uniform branch in the compiler's eyes too — on threadIdx.x itself everything
     // after it counts as divergent control flow, and scalar offsets of the loads below were re-derived per lane)
-    if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= B) {  // ---- the helper wavefront: pass 0 of the tile's reset pool -> LDS ----
+    if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= B) {  // ---- the helper wavefront: pass 0 of the tile's reset pool -> LDS ----  //@sec helper-wave
       QR_HSTAMP(0, threadIdx.x);
       float hgoal[12];
 #pragma unroll
@@ -400,7 +400,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       return;
     }
   }
-  QR_STAMP(0, tid);
+  QR_STAMP(0, tid);  //@sec prologue-loads
 #if QR_TOUCH_COEFFS && defined(__HIP_DEVICE_COMPILE__)
   // The coefficient block spans five 64-byte lines of the kernarg segment (host-visible memory: ~0.5 us per miss).  The
   // compiler reads coefficients where they are used, i.e. it requests those lines only AFTER the first batch of scalar
@@ -466,7 +466,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 #pragma unroll
     for (int f = 0; f < 8; ++f) w.integ[f] = 0.0f;
   }
-  // ---- the rest of the arguments: one batch of scalar loads from the kernarg segment ----
+  // ---- the rest of the arguments: one batch of scalar loads from the kernarg segment ----  //@sec prologue-args
   const uint32_t flags = ka.flags;
   const uint64_t seed = ka.seed;
   const uint64_t gfirst = (uint64_t)(ka.env_offset + first);
@@ -520,6 +520,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   QuatPack<T> qp;             // attitude in its storage form, formed once per env-step
   qp.k[0] = qp.k[1] = qp.k[2] = T(0);
 
+  //@sec prologue-policy
   // POLICY: the observation the next action is computed from (rows -> lane registers once, then
   // carried from step to step)
   float po0[D0], po1[D1];
@@ -546,10 +547,13 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   // registers held across the loop.  Measured, profiles/r04/ab_hoist_act.txt: Quad-v0 65 536 envs 1.492 -> 1.469 us per env-step,
   // 262 144 envs 4.515 -> 4.354 = 60.2 G env-steps/s; Coupled 2.321 -> 2.289.)
   constexpr bool kHoistAct = QR_HOIST_ACT && !SINGLE && !POLICY && KIND != QR_KIND_DECOUPLED;
+  // (Measured and NOT adopted, profiles/r05/ab_rollout_diet.txt: the same constants parked in LDS by the kernels that cannot afford the
+  // registers — bit-identical, qr_rollout_actor 0.3-1.5 % and the Decoupled rollout 5 % SLOWER: eight ds_read_b64 on a lone wave's
+  // critical path cost more than the ~30 VALU instructions they replace.)
   ActConsts<T> ac;
   if constexpr (kHoistAct) act_consts(w, c, ac);
 
-  for (int t = 0; t < n_steps; ++t) {
+  for (int t = 0; t < n_steps; ++t) {  //@sec action-source
     float act[A];
     if constexpr (POLICY) {
       float pre[A], ls[A], eps[A], logp[A];
@@ -626,13 +630,13 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     uint8_t* const done_ptr = ka.done;
     uint8_t* const trunc_ptr = ka.truncated;
 #else
-    // ---- goal for this step from the pre-step state (main.py:145-147) ----
+    // ---- goal for this step from the pre-step state (main.py:145-147) ----  //@sec traj-goal
     if constexpr (TRAJ) {
       float b1d_dot[3];
       traj_goal<kStateful>(w, tr, goal_mode, c, b1d_dot);
     }
     QR_STAMP(2, (float)w.q[0] + (float)w.x[0] + act[0] + w.prm[0] + (float)w.W[2]);
-    // ---- action_wrapper ----
+    // ---- action_wrapper ----  //@sec action-map
     Dyn<T> dyn;
     if constexpr (!kHoistAct) act_consts(w, c, ac);
     action_map<KIND, T, X>(act, w, ac, c, dyn);
@@ -651,7 +655,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 #if QR_PREFETCH_OUT_PTRS
     if constexpr (!HELP) asm volatile("" ::"s"(done_ptr), "s"(trunc_ptr));
 #endif
-    // ---- observation_wrapper: integrate over dt with zero-order-hold (f, M) ----
+    // ---- observation_wrapper: integrate over dt with zero-order-hold (f, M) ----  //@sec integrate
     // The reference's DOP853 is adaptive (6 % of its steps subdivide); the fixed-step stand-in
     // is made rate-adaptive: RK4's local error grows like (|W| h)^5, so a wave that contains an
     // env spinning faster than w_adapt takes ceil(max|W_i| / w_adapt) times the substeps.  The
@@ -686,7 +690,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       const int nsub = ka.substeps;
       integrate(w.x, w.v, w.q, w.W, dyn, nsub, T(c.dt) * recip(T(nsub)));
     }
-    renorm_quat(w.q);
+    renorm_quat(w.q);  //@sec renorm-late-loads-pack
     if constexpr (kLateLoads) {
       const SoA<float> integ(a.integ, 8, L);
 #pragma unroll
@@ -703,7 +707,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     QR_STAMP(3, (float)w.q[0] + (float)w.x[0] + (float)w.v[2] + (float)w.W[0]);
 #endif
 
-    // ---- obs / reward / done ----
+    // ---- obs / reward / done ----  //@sec obs-reward-done
     T R[9];
     float o0[D0];
     float o1[D1];
@@ -754,7 +758,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       if (dn[g]) rwd[g] = -1.0f;
 
     QR_STAMP(4, rwd[0] + (dn[0] ? 1.0f : 0.0f));
-    // ---- time limit + auto-reset ----
+    // ---- time limit + auto-reset ----  //@sec reward-done-stores
     steps += 1;
     const bool trunc = ka.max_episode_steps > 0 && steps >= ka.max_episode_steps;
     bool any_done = trunc;
@@ -781,7 +785,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     // nothing of this wave's own (its reward / done stores in flight) has to be waited for.
     if constexpr (HELP && !kHelpReward) asm volatile("s_barrier" ::: "memory");
     const unsigned long long rmask = __ballot(need_reset);
-    if (rmask) {  // wave-uniform: skipped unless some lane of this wave starts a new episode
+    if (rmask) {  // wave-uniform: skipped unless some lane of this wave starts a new episode  //@sec reset-block
       if (early_store) {
         // This wave is about to spend ~0.5 us sampling episode starts.  The state of its lanes that do NOT
         // reset is final: hand it to the memory system first, so that those stores drain meanwhile.  Only for
@@ -875,13 +879,13 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       }
       if constexpr (kHoistAct) act_consts(w, c, ac);  // (some lane of the wave holds new parameters: every lane re-forms — the same values for the others)
     }
-    if (!early_store) pack_quat(w.q, qp);
+    if (!early_store) pack_quat(w.q, qp);  //@sec pack-quat
     QR_STAMP(5, (float)w.q[0] + (float)w.x[0] + w.prm[0]);
 #ifdef QR_STAMPS
     if (g_stamps != nullptr && lane == 0) g_stamps[(size_t)blockIdx.x * 8 + 7] = rmask;
 #endif
 
-    // ---- outputs of step t ----
+    // ---- outputs of step t ----  //@sec obs-rows-out
     if constexpr (kHelpRows) {  // rows -> LDS tile(s); the helper wave stores them
       if (KIND != QR_KIND_QUAD || ka.obs0 != nullptr) {
         if constexpr (KIND == QR_KIND_QUAD) {  // next state in the reference's order (x, v, vec_F(R), W)
@@ -926,11 +930,11 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 #pragma unroll
       for (int j = 0; j < D1; ++j) po1[j] = o1[j];
     }
-    if constexpr (!SINGLE) unpack_quat(qp, w.q);  // the next env-step starts from what a single-step launch would have re-loaded
+    if constexpr (!SINGLE) unpack_quat(qp, w.q);  //@sec unpack-quat  // the next env-step starts from what a single-step launch would have re-loaded
   }
 
   if constexpr (HELP && POLICY != 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the last step's tile: see the helper wave
-  // ---- write the working set back ----
+  // ---- write the working set back ----  //@sec epilogue-stores
   if (active) {
     if (!(SINGLE && stored_early)) {
       store_state<XV, QW, AUX>(a, first, lane, w, qp);
@@ -1071,7 +1075,7 @@ __global__ __launch_bounds__(64) void set_state_kernel(const Args a) {
     if (a.status) atomicAdd(a.status, 1);
     return;
   }
-  if (a.store_goal) return;  // (qr_check_state: the same decision, nothing written)
+  if (a.dry_run) return;  // (qr_check_state: the same decision, nothing written)
 #pragma unroll
   for (int j = 0; j < 4; ++j) w.q[j] = (QW)q[j];
   store_state<XV, QW>(a, (int64_t)blockIdx.x * 64, threadIdx.x, w);
@@ -1302,13 +1306,16 @@ static const Tuning& tuning() {
 }
 
 // Which instantiation a launch gets (shared by launch_kind and qr_step_kernel_info).
-// (in regime for sure: done envs are re-sampled — in the launch, or by the caller before the next step (QR_FLAG_CALLER_RESETS))
+// (in regime for sure: done envs are re-sampled — in the launch, or, between two ONE-STEP launches, by the caller
+// (QR_FLAG_CALLER_RESETS: a promise nobody can keep between the steps of a multi-step launch, which therefore ignores it))
 static inline bool wants_adapt(const Args& a) {
-  return a.c.inv_w_adapt > 0 && (!(a.flags & (QR_FLAG_AUTO_RESET | QR_FLAG_CALLER_RESETS)) || a.c.inv_w_adapt * a.c.W_lim * 2.5 > 1.0);
+  const bool resampled = (a.flags & QR_FLAG_AUTO_RESET) || ((a.flags & QR_FLAG_CALLER_RESETS) && a.n_steps == 1);
+  return a.c.inv_w_adapt > 0 && (!resampled || a.c.inv_w_adapt * a.c.W_lim * 2.5 > 1.0);
 }
-static inline bool helper_choice(const Args& a, unsigned tiles, unsigned limit) {  // (the instantiation exists: rule, or the env's override)
-  if (a.flags & QR_FLAG_NO_HELPER) return false;
-  if (a.flags & QR_FLAG_FORCE_HELPER) return true;
+static inline bool helper_choice(const Args& a, unsigned tiles, unsigned limit) {  // (the instantiation exists: rule, or the env's override for this launch family)
+  const bool multi = a.n_steps > 1 || a.act_out != nullptr;
+  if (a.flags & (multi ? QR_FLAG_NO_HELPER_ROLLOUT : QR_FLAG_NO_HELPER)) return false;
+  if (a.flags & (multi ? QR_FLAG_FORCE_HELPER_ROLLOUT : QR_FLAG_FORCE_HELPER)) return true;
   return tiles <= limit;
 }
 static inline bool wants_helper(const Args& a, int kind, int layout) {  // a helper wave per tile (HELP)
@@ -1345,12 +1352,18 @@ static void launch_kind(const Args& a, hipStream_t s) {
                            (KIND == QR_KIND_DECOUPLED && (a.actor[1].ls_w || a.actor[1].squash != QR_ACTOR_TANH_MEAN));
       const bool traj = a.goal_mode != QR_GOAL_EXTERNAL;
       if constexpr (std::is_same<XV, float>::value && std::is_same<QW, double>::value) {
-        // PPO / TD3 actors with in-launch resets and external goals, on grids where every wave is resident: a helper wave
+        // Actors with in-launch resets and external goals, on grids where every wave is resident: a helper wave
         // per tile (noise, reset pool, observation rows).  Measured, Coupled 65 536 envs, T = 32: 5.37 -> 4.51 us per step;
         // with the fused goal generator the same split measured SLOWER (5.65 -> 6.25 us per step, tools/ppo_rollout_bench.py;
         // both waves of a tile must be resident, which caps the kernel at 256 registers) and is not instantiated.
-        if (QR_HELP_POLICY && !general && !traj && (a.flags & QR_FLAG_AUTO_RESET) && helper_choice(a, grid.x, tuning().helper_grid_rollout)) {
-          hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 1, false, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
+        if (QR_HELP_POLICY && !traj && (a.flags & QR_FLAG_AUTO_RESET) && helper_choice(a, grid.x, tuning().helper_grid_rollout)) {
+          if (!general) {
+            hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 1, false, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
+            return;
+          }
+          // (the general form — SAC's log_std head and rule — with the same split: 256 VGPRs, both waves of a tile resident; measured,
+          //  profiles/r05/ab_sac_helper.txt, 65 536 envs, T = 32: Coupled 4.95 -> 4.38 us per env-step, Decoupled 5.54 -> 4.87, bit-identical)
+          hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 2, false, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
           return;
         }
       }
@@ -1549,17 +1562,23 @@ int qr_rollout_actor(const QrEnv* env, const QrPolicyRollout* policy, int32_t n_
   return qr::do_rollout(env, nullptr, policy, n_steps, substeps, out, stream);
 }
 
-int qr_error_obs(const QrEnv* env, float* obs0, float* obs1, void* stream) {
+int qr_error_obs_format(const QrEnv* env, int32_t format, float* obs0, float* obs1, void* stream) {
   qr::Args a{};
   if (int rc = qr::fill_env(a, env)) return rc;
   if (env->kind == QR_KIND_QUAD) return QR_E_KIND;
-  if (!env->integ || !obs0 || (env->kind == QR_KIND_DECOUPLED && !obs1)) return QR_E_NULL;
+  if (format != QR_KIND_COUPLED && format != QR_KIND_DECOUPLED) return QR_E_KIND;
+  if (!env->integ || !obs0 || (format == QR_KIND_DECOUPLED && !obs1)) return QR_E_NULL;
   a.obs0 = obs0; a.obs1 = obs1;
   const unsigned grid = (unsigned)((a.n + 63) / 64);
   if (grid == 0) return 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  QR_DISPATCH_LAYOUT(env->layout, (qr::launch_error_obs<XV, QW>(a, env->kind, grid, s)));
+  QR_DISPATCH_LAYOUT(env->layout, (qr::launch_error_obs<XV, QW>(a, format, grid, s)));
   return (int)hipGetLastError();
+}
+
+int qr_error_obs(const QrEnv* env, float* obs0, float* obs1, void* stream) {
+  if (!env) return QR_E_NULL;
+  return qr_error_obs_format(env, env->kind, obs0, obs1, stream);
 }
 
 int qr_reset(const QrEnv* env, const uint8_t* mask, void* stream) {
@@ -1603,7 +1622,7 @@ int qr_check_state(const QrEnv* env, const double* rows, const uint8_t* mask, in
   if (int rc = qr::fill_env(a, env)) return rc;
   if (!rows || !rejected) return QR_E_NULL;
   a.rows_in = rows; a.mask = mask; a.status = rejected;
-  a.store_goal = 1;  // dry run: count, write nothing
+  a.dry_run = 1;  // count, write nothing
   const unsigned grid = (unsigned)((a.n + 63) / 64);
   if (grid == 0) return 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1646,6 +1665,13 @@ int qr_gae(const float* reward, const uint8_t* done, const float* value, const f
   qr::GaeArgs g{reward, done, value, next_value, advantage, td_target, partials, n_cols, n_steps, gamma, lam};
   hipLaunchKernelGGL(qr::gae_kernel, dim3((unsigned)((n_cols + 63) / 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), g);
   return (int)hipGetLastError();
+}
+
+void qr_launch_thresholds(int32_t* step_quad, int32_t* step_wrappers, int32_t* rollout) {
+  const qr::Tuning& tn = qr::tuning();
+  if (step_quad) *step_quad = (int32_t)tn.helper_grid;
+  if (step_wrappers) *step_wrappers = (int32_t)tn.helper_grid_wrap;
+  if (rollout) *rollout = (int32_t)tn.helper_grid_rollout;
 }
 
 const char* qr_step_kernel_info(const QrEnv* env, int32_t n_steps, int32_t* grid, int32_t* block) {

@@ -17,12 +17,13 @@ fallback, and constructing the env without the library or without a GPU raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, launch_cache
 from .constants import ACTION_DIM, FRAMEWORK, KINDS, N_AGENTS, OBS_DIMS, QuadConstants
 from .spaces import Box
 
@@ -115,11 +116,17 @@ class QuadVecEnv:
     final_obs       with auto_reset: also keep the TERMINAL observation rows of the envs that were
                     re-sampled in the last step (`final_observation()`; the reference's obs_next of
                     that transition, main.py:163-178) — what a learner bootstraps V(s') from
-    helper          launch-rule override (speed only, no result bit changes): None = the library's rule (a helper wavefront per
-                    64-env tile on small grids, thresholds measured on MI355X; the environment variables QR_HELPER_GRID /
-                    QR_HELPER_GRID_WRAP / QR_HELPER_GRID_ROLLOUT override them per process); True / False force / forbid it
-    autotune        time step() with and without the helper wavefront for THIS env (kind, size, box) at construction — see
-                    autotune_launch() — and keep the faster (sets `helper`)
+    helper          launch-rule override of step() (speed only, no result bit changes): None = the library's rule (a helper
+                    wavefront per 64-env tile on small grids, thresholds measured on MI355X; the environment variables
+                    QR_HELPER_GRID / QR_HELPER_GRID_WRAP / QR_HELPER_GRID_ROLLOUT override them per process); True / False force /
+                    forbid it.  helper_rollout: the same for rollout() / rollout_actor(), a separate choice (their crossover
+                    is a different one; a choice timed on step() says nothing about them)
+    autotune        the launch rule's compiled-in thresholds are crossovers measured on other boxes; boxes differ.  None (default):
+                    if `helper` is None and this env's grid lies within +-25 % of the rule's threshold, use the choice recorded for
+                    (device, library, kind, size, ...) in ~/.cache/gym_rotor_amd/launch.json (launch_cache.py; QR_LAUNCH_CACHE
+                    moves / disables it) — and if there is none yet, time both instantiations once (autotune_launch(), ~0.2 s)
+                    and record it; away from the threshold the rule is unambiguous and nothing is timed or read.  True: always
+                    time (and record).  False (or QR_AUTOTUNE=0 in the environment): the rule as compiled, never the cache
     obs_rows        write float32 observation rows [N,D].  Always on for the wrappers.  For
                     kind='quad' the observation is the next state (quad.py:269-271): True writes
                     it as float32 [N,18] rows each step; False (default) writes nothing and
@@ -134,7 +141,8 @@ class QuadVecEnv:
                  env_offset: int = 0, want_raw_reward: bool = False, obs_rows: Optional[bool] = None,
                  field_stride: Optional[int] = None, goal_mode: Optional[int] = None, w_adapt: float = 16.0,
                  constants: Optional[QuadConstants] = None, final_obs: bool = False,
-                 helper: Optional[bool] = None, autotune: bool = False, reset_on_done: bool = False):
+                 helper: Optional[bool] = None, autotune: Optional[bool] = None, reset_on_done: bool = False,
+                 helper_rollout: Optional[bool] = None):
         if kind not in KINDS:
             raise ValueError(f"kind must be one of {KINDS}, got {kind!r}")
         if num_envs < 1:
@@ -159,8 +167,15 @@ class QuadVecEnv:
         self.use_UDM, self.UDM_percentage = bool(use_UDM), float(UDM_percentage)
         self.auto_reset, self.max_episode_steps = bool(auto_reset), int(max_episode_steps)
         self.env_offset, self.seed = int(env_offset), self._check_seed(seed)
-        self._helper = helper
+        self._helper, self._helper_rollout = helper, helper_rollout
+        self._act_align = 16 if self.action_dim == 4 else 4   # (quadrotor_hip.h: A = 4 one 16-byte load per lane, A = 5 dword loads)
         self.reset_on_done = bool(reset_on_done)
+        if auto_reset and self.env_offset % 64:
+            import warnings
+            warnings.warn(f"QuadVecEnv(auto_reset=True, env_offset={self.env_offset}): the in-launch reset stream is keyed by the global id of each "
+                          "64-env tile's first env, so results are independent of the sharding only when every shard starts at a multiple of 64 "
+                          "envs (shard_range() cuts there); this shard is still deterministic, but not bit-equal to the same envs inside another "
+                          "partition", stacklevel=2)
         if self.reset_on_done and auto_reset:
             raise ValueError("reset_on_done is the caller's promise for auto_reset=False; with auto_reset=True the launch resets itself")
         c = self.constants = constants or QuadConstants(UDM_percentage=UDM_percentage)
@@ -248,8 +263,12 @@ class QuadVecEnv:
         self._sync_structs()
         self._closed = False
         self.autotune_report = None
+        if autotune is None and os.environ.get("QR_AUTOTUNE", "1").lower() in ("0", "off", "false"):
+            autotune = False
         if autotune:
             self.autotune_launch()
+        elif autotune is None and helper is None:
+            self._autotune_from_cache()
 
     # ------------------------------------------------------------------------------
     @staticmethod
@@ -265,6 +284,7 @@ class QuadVecEnv:
         return torch.zeros(fields, self._ld, dtype=dtype, device=self.device)[:, :self.num_envs]
 
     def _sync_structs(self):
+        self._epoch = getattr(self, "_epoch", 0) + 1   # launches captured before this point hold stale pointers / flags (CapturedStep)
         e, o = self._cenv, self._cout
         e.kind, e.layout = _lib.KIND_ID[self.kind], _lib.LAYOUT_ID[self.layout]
         e.num_envs, e.field_stride = self.num_envs, self._ld
@@ -277,6 +297,7 @@ class QuadVecEnv:
         e.max_episode_steps = self.max_episode_steps
         e.flags = (_lib.FLAG_AUTO_RESET if self.auto_reset else 0) | (0 if self.use_UDM else _lib.FLAG_NO_UDM)
         e.flags |= {None: 0, True: _lib.FLAG_FORCE_HELPER, False: _lib.FLAG_NO_HELPER}[self._helper]
+        e.flags |= {None: 0, True: _lib.FLAG_FORCE_HELPER_ROLLOUT, False: _lib.FLAG_NO_HELPER_ROLLOUT}[self._helper_rollout]
         e.flags |= _lib.FLAG_CALLER_RESETS if self.reset_on_done else 0
         o.obs0, o.obs1, o.reward, o.reward_raw = _ptr(self._obs0), _ptr(self._obs1), _ptr(self._reward), _ptr(self._reward_raw)
         o.done, o.truncated = _ptr(self._done), (_ptr(self._trunc) if self._steps is not None else None)
@@ -308,7 +329,7 @@ class QuadVecEnv:
             raise ValueError(f"actions shape {tuple(actions.shape)} != {want}")
         if not actions.is_contiguous():
             actions = actions.contiguous()
-        if actions.data_ptr() % 16:  # e.g. a row slice of a bigger tensor: the kernel wants 16-byte aligned rows
+        if actions.data_ptr() % self._act_align:  # e.g. a row slice of a bigger tensor: A = 4 rows are read with 16-byte loads
             actions = actions.clone()
         return actions
 
@@ -477,6 +498,85 @@ class QuadVecEnv:
         out["obs"] = out["obs0"] if len(self.obs_dims) == 1 else (out["obs0"], out["obs1"])
         return out
 
+    def capture(self, actions: Optional[torch.Tensor] = None, n_steps: int = 1, body=None, warmup: int = 1) -> "CapturedStep":
+        """step() inside ONE replayable hipGraph, captured once on a side stream and replayed with a single host call.
+
+        Why: an eager step() costs ~5.6-6.0 us of host time per call (4.65 of it the HIP launch path), more than the kernel takes
+        at 65 536 envs (4.2 us); a graph replay costs ~10 us of host time whatever it holds (measured on MI355X,
+        profiles/r05/eager_cost.json).  So a replay pays as soon as it carries more than one launch:
+
+            # (a) the caller's per-step work and the env step in one replay — e.g. a torch policy (~10 launches) + step():
+            step = env.capture(body=lambda: env.step(policy(env_obs)))      # body runs once, under capture; its return value is kept
+            ... = step()                                                     # ONE host call per env-step
+            # (b) n_steps env-steps per replay, one action slab each (4.2 us per step at 65 536 envs from n_steps ~ 8 on):
+            steps = env.capture(n_steps=64); steps.actions.copy_(slabs); obs, reward, terminated, truncated, info = steps()
+            # (c) a single step per replay (n_steps=1, no body): correct, but SLOWER than eager step() — use it only to splice the
+            #     step into a caller-side graph-driven loop
+
+        `warmup` (with `body`): libraries the body calls (hipBLASLt behind torch.nn.Linear, ...) initialise on first use and must not
+        do that under capture, so body() is first run `warmup` times eagerly on the side stream — with the ENV's state, counters and
+        RNG position saved before and restored after (like autotune_launch; what the body does to the caller's own tensors is the
+        caller's business).  warmup=0 skips it (the caller has already run the same shapes).
+        `actions`: the static buffer every replay reads — a contiguous float32 [N, A] tensor on the env's device (A = 4: 16-byte
+        aligned), or [n_steps, N, A] (each launch its own slab); default: allocated here (`.actions` of the result).  With `body`
+        no action buffer is involved: body() must call env.step(...) itself, on tensors that stay alive and in place.
+        The returned tensors are the env's own output buffers (as with step()): with n_steps > 1 they hold the LAST step's rows.
+        Replays are bit-identical to eager calls: in-launch resets draw from per-tile counters in device memory, which advance
+        under replay exactly as under eager launches (quadrotor_hip.h: reset_count).  capture() itself executes nothing: the
+        env's state is untouched until the first replay.  A later call that changes what the launches baked in — the first
+        set_goal_state() / set_state(params=) (they allocate a buffer), reset(seed=), set_launch(), load_state_dict() — makes the
+        capture stale: replaying it raises, capture again."""
+        N, A, dev = self.num_envs, self.action_dim, self.device
+        n_steps = int(n_steps)
+        if n_steps < 1:
+            raise ValueError("n_steps must be >= 1")
+        if body is not None:
+            if actions is not None or n_steps != 1:
+                raise ValueError("capture(body=...) takes neither actions nor n_steps: the body calls env.step() itself")
+        else:
+            if actions is None:
+                actions = torch.zeros((N, A) if n_steps == 1 else (n_steps, N, A), dtype=torch.float32, device=dev)
+            if actions.dim() == 2:
+                checked = self._check_actions(actions)
+            elif actions.dim() == 3 and actions.shape[0] == n_steps:
+                checked = self._check_actions(actions, lead=(n_steps,))
+                if (N * A * 4) % self._act_align:
+                    raise ValueError(f"per-step action slabs need N * A * 4 bytes to be a multiple of {self._act_align}")
+            else:
+                raise ValueError(f"actions must be [{N}, {A}] or [{n_steps}, {N}, {A}]")
+            if checked.data_ptr() != actions.data_ptr():
+                raise ValueError(f"the static action buffer must be contiguous and {self._act_align}-byte aligned (it is read in place by every replay)")
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        if body is not None and warmup > 0:
+            saved, last = self.state_dict(), self._last_obs
+            outs = [t for t in (self._obs0, self._obs1, self._reward, self._reward_raw, self._done, self._trunc, self._final0, self._final1)
+                    if t is not None]                       # the env's output buffers: a body typically reads its action from them
+            with torch.cuda.stream(side):
+                kept = [t.clone() for t in outs]
+                for _ in range(int(warmup)):
+                    body()
+                for t, k in zip(outs, kept):
+                    t.copy_(k)
+            side.synchronize()
+            self.load_state_dict(saved)
+            self._last_obs = last
+        graph = torch.cuda.CUDAGraph()
+        epoch = self._epoch
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                if body is not None:
+                    ret = body()
+                else:
+                    for k in range(n_steps):
+                        ret = self.step(actions if actions.dim() == 2 else actions[k])
+        cur.wait_stream(side)
+        if self._epoch != epoch:
+            raise RuntimeError("capture(body=...): the body changed the env's buffers / launch configuration (set_goal_state, reset(seed=), ...): "
+                               "do that before capturing")
+        return CapturedStep(self, graph, actions, ret, n_steps)
+
     def reset(self, env_type: str = "train", seed: Optional[int] = None, options: Optional[dict] = None,
               mask: Optional[torch.Tensor] = None):
         """QuadEnv.reset (quad.py:171-222): new parameters (train + use_UDM), initial error
@@ -489,6 +589,7 @@ class QuadVecEnv:
             self.seed = self._check_seed(seed)
             self._cenv.seed = self.seed
             self._op_cfg[3] = self.seed
+            self._epoch += 1
         m = None
         if mask is not None:
             if mask.shape != (self.num_envs,) or mask.device != self.device:
@@ -510,16 +611,31 @@ class QuadVecEnv:
         return self.get_current_state().to(torch.float32)
 
     def get_norm_error_state(self, framework: Optional[str] = None):
-        """quad.py:421-466.  Advances the integral terms (same side effect as the reference)."""
+        """quad.py:421-466.  Advances the integral terms (same side effect as the reference).  `framework` selects the FORMAT as
+        in the reference — "MONO": [obs[N,23]], "MODUL": [obs1[N,15], obs2[N,3]] — on either wrapper kind (the method is
+        QuadEnv's, both wrappers inherit it unchanged); default: the env's own.  The env's own format is written to its output
+        buffers (what step() returns next is unaffected either way); the other one to fresh tensors.  kind='quad' raises
+        AttributeError like a bare QuadEnv does (it has no alpha / beta / eIx_lim: quad.py:448)."""
         if self.kind == "quad":
-            raise RuntimeError("get_norm_error_state is defined for kind 'coupled'/'decoupled'")
-        if framework is not None and framework != self.framework:
-            raise ValueError(f"env kind {self.kind!r} produces {self.framework} observations, not {framework}")
+            raise AttributeError("'QuadEnv' object has no attribute 'alpha' — get_norm_error_state needs the integral terms of a "
+                                 "wrapper env (kind 'coupled' / 'decoupled'), exactly as in the reference (quad.py:448)")
+        fw = self.framework if framework is None else framework
+        if fw not in ("MONO", "MODUL"):
+            raise ValueError(f"framework must be 'MONO' or 'MODUL', got {framework!r}")
+        if fw == self.framework:
+            with self._on_device():
+                rc = self._lib.qr_error_obs(C.byref(self._cenv), _ptr(self._obs0), _ptr(self._obs1), self._stream())
+            _lib.check(rc, "qr_error_obs")
+            self._last_obs = self._obs()
+            return [self._obs0] if self._obs1 is None else [self._obs0, self._obs1]
+        dims = OBS_DIMS["coupled" if fw == "MONO" else "decoupled"]
+        rows = [torch.empty(self.num_envs, d, dtype=torch.float32, device=self.device) for d in dims]
         with self._on_device():
-            rc = self._lib.qr_error_obs(C.byref(self._cenv), _ptr(self._obs0), _ptr(self._obs1), self._stream())
-        _lib.check(rc, "qr_error_obs")
-        self._last_obs = self._obs()
-        return [self._obs0] if self._obs1 is None else [self._obs0, self._obs1]
+            rc = self._lib.qr_error_obs_format(C.byref(self._cenv), _lib.KIND_ID["coupled" if fw == "MONO" else "decoupled"],
+                                               rows[0].data_ptr(), rows[1].data_ptr() if len(rows) > 1 else None, self._stream())
+        _lib.check(rc, "qr_error_obs_format")
+        self._last_obs = None   # (rows of the other format are not what this env's actor consumes)
+        return rows
 
     # ------------------------------------------------------------------------------
     def _rows3(self, v, name):
@@ -537,6 +653,7 @@ class QuadVecEnv:
         if self._goal is None:
             self._goal = self._soa(12, torch.float32)
             self._cenv.goal = self._goal.data_ptr()
+            self._epoch += 1
         self._goal[0:3] = self._rows3(xd, "xd")
         self._goal[3:6] = self._rows3(vd, "vd")
         self._goal[6:9] = self._rows3(b1d, "b1d")
@@ -573,6 +690,7 @@ class QuadVecEnv:
         if store_goal and self._goal is None:
             self._goal = self._soa(12, torch.float32)
             self._cenv.goal = self._goal.data_ptr()
+            self._epoch += 1
         with self._on_device():
             _lib.check(self._lib.qr_get_desired(C.byref(self._cenv), _ptr(m), rows.data_ptr(), int(store_goal), self._stream()), "qr_get_desired")
         return rows[:, 0:3], rows[:, 3:6], rows[:, 6:9], rows[:, 9:12], rows[:, 12:15]
@@ -629,6 +747,7 @@ class QuadVecEnv:
                 self._params = self._soa(6, torch.float32)
                 self._params.copy_(torch.tensor(self.constants.nominal_params, dtype=torch.float32, device=self.device)[:, None].expand(6, self.num_envs))
                 self._cenv.params = self._params.data_ptr()
+                self._epoch += 1
             put(self._params, params_src)
 
     def final_observation(self):
@@ -688,10 +807,44 @@ class QuadVecEnv:
     def episode_steps(self):
         return self._steps
 
-    def set_launch(self, helper: Optional[bool] = None):
-        """Pin (True / False) or release (None) the launch rule's choice — a helper wavefront per tile — for this env."""
-        self._helper = helper
+    def set_launch(self, helper: Optional[bool] = None, helper_rollout: Optional[bool] = None):
+        """Pin (True / False) or release (None) the launch rule's choice — a helper wavefront per tile — for this env's step()
+        (`helper`) and, separately, for its rollout() / rollout_actor() (`helper_rollout`)."""
+        self._helper, self._helper_rollout = helper, helper_rollout
         self._sync_structs()
+
+    # ---- launch rule: cached / timed choice -------------------------------------------------------------------------
+    def _launch_cache_key(self, action_source: str = "default") -> str:
+        lib_id = f"abi{_lib.ABI_VERSION}:{os.path.getsize(_lib.LIB_PATH) if os.path.exists(_lib.LIB_PATH) else 0}"
+        goal = "external" if self.goal_mode is None else f"mode{self.goal_mode}"
+        return launch_cache.key(torch.cuda.get_device_name(self.device), lib_id, self.kind, (self.num_envs + 63) // 64, self.layout,
+                                goal, action_source)
+
+    def _has_both_step_launches(self) -> bool:
+        """Does qr_step have a helper-wave AND a plain instantiation for this env?  (quadrotor_kernels.hip: wants_helper /
+        wants_helper_traj — in-launch resets, the default layout, external goals or the stateless generator modes.)"""
+        return self.auto_reset and self.layout == "mixed" and self.goal_mode in (None, 0, 1, 6)
+
+    def _autotune_from_cache(self):
+        """The default path of the constructor: nothing unless the grid is near the rule's threshold; then the recorded choice, or
+        one timing run whose result is recorded.  Never raises: a failure leaves the compiled rule in force."""
+        if not self._has_both_step_launches():
+            return
+        thr = _lib.launch_thresholds()["step_quad" if self.kind == "quad" else "step_wrappers"]
+        if not launch_cache.near_threshold((self.num_envs + 63) // 64, thr):
+            return
+        try:
+            key = self._launch_cache_key()
+            hit = launch_cache.lookup(key)
+            if hit is not None:
+                self.set_launch({"default": None, "helper": True, "no_helper": False}[hit["picked"]], self._helper_rollout)
+                self.autotune_report = dict(hit.get("us", {}), picked=hit["picked"], source="cache")
+                return
+            report = self.autotune_launch()
+            report["source"] = "timed"
+        except Exception as ex:   # pragma: no cover - a tuning failure must not take the env down
+            import warnings
+            warnings.warn(f"gym_rotor_amd: launch autotuning skipped ({type(ex).__name__}: {ex}); the compiled launch rule stays in force")
 
     def autotune_launch(self, actions: Optional[torch.Tensor] = None, launches: int = 200, repeats: int = 3):
         """Time step() under the launch-rule choices that exist for this env — the library's default, helper wavefront forced,
@@ -710,7 +863,7 @@ class QuadVecEnv:
             acts = [self._check_actions(a_) for a_ in (actions if isinstance(actions, (list, tuple)) else [actions])]
         cands, seen, report = {"default": None, "helper": True, "no_helper": False}, {}, {}
         for name, h in cands.items():
-            self.set_launch(h)
+            self.set_launch(h, self._helper_rollout)
             geom = self.kernel_info()[1:]
             if geom in seen:        # the same instantiation as an earlier candidate
                 report[name] = report[seen[geom]]
@@ -737,12 +890,13 @@ class QuadVecEnv:
         self.load_state_dict(saved)
         pick = min(("helper", "no_helper"), key=lambda k: report[k])
         if report["default"] <= report[pick] * 1.01:   # within noise of the rule's own choice: keep the rule
-            self.set_launch(saved_choice)
+            self.set_launch(saved_choice, self._helper_rollout)
             report["picked"] = "default"
         else:
-            self.set_launch(cands[pick])
+            self.set_launch(cands[pick], self._helper_rollout)
             report["picked"] = pick
         self.autotune_report = report
+        launch_cache.store(self._launch_cache_key("default" if actions is None else "caller"), report)
         return report
 
     def kernel_info(self, n_steps=1):
@@ -756,6 +910,30 @@ class QuadVecEnv:
 
     def close(self):
         self._closed = True
+
+
+class CapturedStep:
+    """A captured env.step(): see QuadVecEnv.capture().  `actions` is the static buffer every replay reads; calling the object
+    replays the graph on torch's current stream and returns step()'s tuple (the env's own output buffers)."""
+
+    def __init__(self, env: QuadVecEnv, graph, actions: torch.Tensor, ret, n_steps: int):
+        self.env, self.graph, self.actions, self.n_steps = env, graph, actions, n_steps
+        self._ret, self._epoch = ret, env._epoch
+
+    def __call__(self, actions: Optional[torch.Tensor] = None):
+        env = self.env
+        if env._epoch != self._epoch:
+            raise RuntimeError("the env changed after capture() (a buffer was allocated, the seed or the launch rule changed, or a state_dict "
+                               "was loaded): the captured launch holds stale arguments — call env.capture() again")
+        if actions is not None and actions is not self.actions:
+            if self.actions is None:
+                raise ValueError("this capture runs a caller-supplied body: it has no action buffer")
+            self.actions.copy_(actions)      # (a copy kernel per step: write into .actions in place to avoid it)
+        self.graph.replay()
+        env._last_obs = env._obs()
+        return self._ret
+
+    replay = __call__
 
 
 def as_gymnasium_vector_env(env: "QuadVecEnv"):

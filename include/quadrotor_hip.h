@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define QR_ABI_VERSION 12
+#define QR_ABI_VERSION 13
 
 /* env kinds */
 #define QR_KIND_QUAD      0 /* QuadEnv            gym_rotor/envs/quad.py:19            */
@@ -89,14 +89,18 @@ extern "C" {
                                     again.  Then no env ever starts a step outside the termination bounds, rate adaptivity
                                     (QrCoeffs.w_adapt) cannot trigger, and the launcher takes the kernel compiled without it — the
                                     same arithmetic, bit for bit, as with QR_FLAG_AUTO_RESET (4.03 instead of 4.39 us per 65 536-env
-                                    launch).  A caller that steps done envs on anyway only loses the adaptivity: fixed substeps. */
+                                    launch).  A caller that steps done envs on anyway only loses the adaptivity: fixed substeps.
+                                    Honoured by ONE-STEP launches only (qr_step): inside a qr_rollout / qr_rollout_actor launch of
+                                    several steps nobody can reset an env between two of them, so those keep the rate-adaptive kernel. */
 /* Launch-rule overrides (speed only: no choice changes a result bit).  By default qr_step / qr_rollout(_actor) decide from the
  * grid size whether every 64-env tile gets a second, helper wavefront, with thresholds measured on MI355X (environment variables
  * QR_HELPER_GRID, QR_HELPER_GRID_WRAP, QR_HELPER_GRID_ROLLOUT override them per process, read once); these bits pin the choice
  * per env — what an autotuner that timed both on ITS box, kind, size and action source sets.  Ignored where the instantiation
  * does not exist (a helper wavefront needs QR_FLAG_AUTO_RESET, the default layout and no rate adaptivity in reach). */
-#define QR_FLAG_FORCE_HELPER   8u /* a helper wavefront per 64-env tile whatever the grid size      */
-#define QR_FLAG_NO_HELPER     16u /* never                                                          */
+#define QR_FLAG_FORCE_HELPER   8u /* qr_step: a helper wavefront per 64-env tile whatever the grid size */
+#define QR_FLAG_NO_HELPER     16u /* qr_step: never                                                     */
+#define QR_FLAG_FORCE_HELPER_ROLLOUT  64u /* the same two for the multi-step launches (qr_rollout, qr_rollout_actor), whose crossover  */
+#define QR_FLAG_NO_HELPER_ROLLOUT    128u /* is a different one (two waves per SIMD): a choice timed on one family says nothing about the other */
 
 /* Coefficients a caller may override (args_parse.py:23-35); qr_default_coeffs() fills the
  * reference defaults.  reward_min* are derived inside (quad.py:81-88). */
@@ -264,6 +268,13 @@ int qr_rollout_actor(const QrEnv* env, const QrPolicyRollout* policy, int32_t n_
  * effect as the reference).  kind must be COUPLED or DECOUPLED. */
 int qr_error_obs(const QrEnv* env, float* obs0, float* obs1, void* stream);
 
+/* The same with the FORMAT chosen by the caller, as the reference's `framework` argument does (quad.py:452-466: "MONO" ->
+ * one [N][23] row, "MODUL" -> [N][15] + [N][3], on whichever wrapper class the method is called): format = QR_KIND_COUPLED
+ * (MONO; obs1 unused) or QR_KIND_DECOUPLED (MODUL; obs1 required), independent of env->kind.  env->kind must still be COUPLED
+ * or DECOUPLED (the integrator terms live there; a bare QuadEnv raises AttributeError in the reference): QR_E_KIND otherwise.
+ * Same side effect on the integrators. */
+int qr_error_obs_format(const QrEnv* env, int32_t format, float* obs0, float* obs1, void* stream);
+
 /* Replaces QuadEnv.reset(env_type) (quad.py:171-222, 338-404) for every env with
  * mask[i] != 0 (mask NULL = all): draws UDM parameters (unless QR_FLAG_NO_UDM / no params
  * buffer), the initial error state, R = Rz(yaw)Ry(pitch)Rx(roll), zeroes the integrators
@@ -328,6 +339,12 @@ int  qr_abi_version(void);
  * helper wavefront per tile (QR_FLAG_AUTO_RESET, default layout, grids in the launch-latency regime).  "" if the env
  * descriptor is invalid. */
 const char* qr_step_kernel_info(const QrEnv* env, int32_t n_steps, int32_t* grid, int32_t* block);
+
+/* The launch rule's thresholds in force in this process (compiled-in defaults or the QR_HELPER_GRID* environment variables), in
+ * 64-env tiles: grids up to *step_quad (Quad-v0) / *step_wrappers (Coupled, Decoupled) tiles run qr_step with a helper wavefront
+ * per tile, grids up to *rollout tiles run qr_rollout / qr_rollout_actor with one.  What a host-side autotuner needs to know
+ * whether a grid is close enough to a crossover to be worth timing (QuadVecEnv: within +-25 %).  NULL pointers are skipped. */
+void qr_launch_thresholds(int32_t* step_quad, int32_t* step_wrappers, int32_t* rollout);
 
 #ifdef __cplusplus
 }

@@ -443,3 +443,79 @@ def test_plain_c_host_of_the_c_abi_matches_the_python_host(tmp_path):
     assert np.array_equal(st.sum(0), c_sum) or np.allclose(st.sum(0), c_sum, rtol=0, atol=1e-9)   # (summation order: C loop vs NumPy pairwise)
     for k, row in c_rows.items():
         assert np.array_equal(st[k], np.array(row)), k                                              # the rows themselves: bit for bit
+
+
+@pytest.mark.parametrize("kind,kw", [("quad", dict(obs_rows=True)), ("quad", dict()), ("coupled", dict(max_episode_steps=40)),
+                                     ("decoupled", dict(final_obs=True))])
+def test_captured_step_equals_eager_step_bit_for_bit(kind, kw):
+    """QuadVecEnv.capture(): one replayable hipGraph of step().  200 replays with in-launch resets against 200 eager step()
+    calls from the same start: observation rows, rewards, flags, terminal observations, state, parameters, episode counters and
+    the per-tile reset counters (which must advance under replay: quadrotor_hip.h, reset_count) agree to the bit; a capture made
+    stale by a later allocation refuses to replay."""
+    n, T = 4096 + 37, 200
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    acts = torch.rand(T, n, orc.ACTION_DIM[kind], device="cuda", generator=g) * 2 - 1
+
+    def start():
+        env = _env(kind, n, seed=5, auto_reset=True, **kw)
+        env.reset("train")
+        if kind != "quad":
+            env.get_norm_error_state()
+        return env
+
+    def snap(env, ret):
+        obs, rwd, done, trunc, _ = ret
+        obs = [] if obs is None else ([obs] if isinstance(obs, torch.Tensor) else list(obs))
+        fin = []
+        if kw.get("final_obs"):
+            rows = done.reshape(n, -1).any(dim=1)
+            fin = [f[rows].clone() for f in env.final_observation()]
+        return [o.clone() for o in obs] + [rwd.clone(), done.clone(), trunc.clone()] + fin
+
+    eager, e_hist = start(), []
+    for t in range(T):
+        e_hist.append(snap(eager, eager.step(acts[t])))
+    cap_env = start()
+    step = cap_env.capture()
+    assert step.actions.shape == (n, orc.ACTION_DIM[kind]) and int(cap_env._reset_count.abs().sum()) == 0   # capture() executes nothing
+    for t in range(T):
+        step.actions.copy_(acts[t])
+        got = snap(cap_env, step())
+        assert len(got) == len(e_hist[t]) and all(torch.equal(a, b) for a, b in zip(got, e_hist[t])), t
+    for name in ("_pos_vel", "_att_rate", "_params", "_episode", "_reset_count", "_integ", "_steps"):
+        a, b = getattr(eager, name), getattr(cap_env, name)
+        assert (a is None and b is None) or torch.equal(a, b), name
+    assert int(cap_env._episode.sum()) > 0 and int(cap_env._reset_count.min()) == T
+    # the other calling form (rows passed to the call) and a caller-owned static buffer
+    buf = torch.zeros(n, orc.ACTION_DIM[kind], device="cuda")
+    step2 = cap_env.capture(buf)
+    r1 = [x.clone() for x in snap(cap_env, step2(acts[0]))]
+    eager_next = snap(eager, eager.step(acts[0]))
+    assert torch.equal(buf, acts[0]) and all(torch.equal(a, b) for a, b in zip(r1, eager_next))
+    # a multi-step capture: n_steps launches, one slab each; outputs hold the last step's rows
+    step3 = cap_env.capture(n_steps=3)
+    step3.actions.copy_(acts[1:4])
+    last = snap(cap_env, step3())
+    for t in (1, 2, 3):
+        want = snap(eager, eager.step(acts[t]))
+    assert all(torch.equal(a, b) for a, b in zip(last, want)) and torch.equal(eager._att_rate, cap_env._att_rate)
+    # a caller-side body in the same graph: a small torch policy writing the actions, then the step — ONE host call per env-step
+    if kind == "coupled":
+        torch.manual_seed(0)
+        pol = torch.nn.Sequential(torch.nn.Linear(23, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Tanh()).cuda()
+        e2, c2 = start(), start()
+        with torch.no_grad():
+            looped = c2.capture(body=lambda: c2.step(pol(c2._obs0)))
+            for t in range(30):
+                want = snap(e2, e2.step(pol(e2._obs0)))
+                got = snap(c2, looped())
+                assert all(torch.equal(a, b) for a, b in zip(got, want)), t
+        with pytest.raises(ValueError):
+            c2.capture(body=lambda: None, n_steps=2)
+    # stale captures refuse to replay
+    if kind != "quad":
+        cap_env.set_goal_state(np.zeros(3), np.zeros(3), np.array([1.0, 0, 0]))   # allocates the goal buffer: new pointer
+        with pytest.raises(RuntimeError, match="capture"):
+            step()
+    with pytest.raises(ValueError):
+        cap_env.capture(torch.zeros(n, orc.ACTION_DIM[kind] + 1, device="cuda"))

@@ -390,9 +390,9 @@ def test_api_errors():
     with pytest.raises(ValueError):
         env.step(torch.zeros(8, 4))
     with pytest.raises(ValueError):
-        env.get_norm_error_state("MODUL")
-    with pytest.raises(RuntimeError):
-        _env("quad", 8).get_norm_error_state()
+        env.get_norm_error_state("BOTH")
+    with pytest.raises(AttributeError):                      # a bare QuadEnv raises AttributeError in the reference (no alpha / eIx_lim)
+        _env("quad", 8).get_norm_error_state("MONO")
     with pytest.raises(ValueError):
         env.set_state(np.zeros((7, 18)))
 
@@ -974,3 +974,66 @@ def test_set_state_rejects_rows_without_a_nearest_rotation():
     assert int(rej.item()) == 3 and np.array_equal(after[bad], before[bad])                # rejected rows: previous state kept
     assert np.allclose(after[~bad, 0], s[~bad, 0]) and np.isfinite(after).all()
     env.set_state(s, mask=torch.from_numpy(~bad).cuda())          # masked out: not looked at
+
+
+@pytest.mark.parametrize("kind", ["coupled", "decoupled"])
+@pytest.mark.parametrize("layout", ["mixed", "f64"])
+def test_error_obs_in_either_format_on_either_wrapper(kind, layout, golden):
+    """get_norm_error_state(framework) (quad.py:421-466): the ARGUMENT selects the format — MONO [N,23] or MODUL [N,15] + [N,3] —
+    on whichever wrapper class it is called; the integral terms advance the same way.  Golden: the reference's own method called
+    with both frameworks on both wrapper classes (tests/golden/errobs_formats.npz, tools/gen_golden.py errobs); oracle beside it."""
+    gd = golden("errobs_formats")
+    n = gd["state"].shape[0]
+    assert bytes(gd["quad_raises"].astype(np.uint8)).decode() == "AttributeError"
+    for fw, okind in (("MONO", "coupled"), ("MODUL", "decoupled")):
+        env = _env(kind, n, use_UDM=False, layout=layout)
+        env.set_state(gd["state"], integ=gd["integ"])
+        _set_goal(env, torch.from_numpy(gd["goal"]).float().cuda())
+        rows = env.get_norm_error_state(fw)
+        want = [gd[f"{kind}_{fw}_obs{k}"] for k in range(len(rows))]
+        orc_out = orc.error_obs_batch(okind, gd["state"], gd["goal"], gd["integ"])
+        assert [tuple(r.shape) for r in rows] == [w.shape for w in want]
+        for r, w, o in zip(rows, want, orc_out["obs"]):
+            assert np.abs(_np(r) - w).max() <= 2e-6 and np.abs(o - w).max() <= 1e-6
+        assert np.abs(_np(env.integ) - gd[f"{kind}_{fw}_next_integ"]).max() <= 4e-6
+        # the env's own format lands in its output buffers (and is what the next rollout_actor starts from); the other one does not
+        own = env.framework == fw
+        assert (env._last_obs is not None) == own
+        if own:
+            assert rows[0].data_ptr() == env._obs0.data_ptr()
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_rollout_ignores_the_callers_reset_promise(kind):
+    """QR_FLAG_CALLER_RESETS (QuadVecEnv(reset_on_done=True)) is a promise about what happens BETWEEN one-step launches: nobody can
+    reset an env between two steps of a fused rollout, so a multi-step launch must keep the rate-adaptive kernel — envs that
+    terminate mid-launch fly on with the accuracy guard in place.  A 300-step random-action rollout (the population tumbles far
+    beyond |W| = w_adapt) with the flag set equals the free-running env's rollout bit for bit, and differs from what fixed
+    substeps would give; the one-step launch still honours the flag."""
+    n, T = 2048, 300
+    adim = 5 if kind == "decoupled" else 4
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    acts = torch.rand(T, n, adim, device="cuda", generator=g) * 2 - 1
+    if kind != "quad":   # the wrappers' torque commands are unscaled Nm: hold a per-env sign pattern so that the envs do spin up
+        acts[:, :, 1:] = torch.sign(acts[0, :, 1:])[None]
+    outs = []
+    for kw in (dict(reset_on_done=True), dict(), dict(w_adapt=0.0)):
+        e = _env(kind, n, seed=4, **kw)
+        e.reset("train")
+        if kind != "quad":
+            e.get_norm_error_state()
+        ro = e.rollout(acts)
+        outs.append((_np(e.get_current_state()), _np(ro["reward"]), _np(ro["terminated"])))
+    promised, free, fixed = outs
+    assert np.abs(free[0][:, 15:18]).max() > 16.0                       # the population did leave the regime
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(promised, free))
+    assert not np.array_equal(free[0], fixed[0], equal_nan=True)        # (adaptivity mattered on this rollout)
+    # one-step launches: the promise selects the plain kernel = the arithmetic of the in-launch-reset mode
+    a, b = _env(kind, n, seed=4, reset_on_done=True), _env(kind, n, seed=4, w_adapt=0.0)
+    for e in (a, b):
+        e.reset("train")
+        if kind != "quad":
+            e.get_norm_error_state()
+        for t in range(40):
+            e.step(acts[t])
+    assert torch.equal(a.get_current_state(), b.get_current_state())

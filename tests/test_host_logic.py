@@ -141,6 +141,11 @@ def test_abi_argument_errors_without_gpu():
     assert lib.qr_error_obs(C.byref(e), None, None, None) == -1
     e.kind = 0
     assert lib.qr_error_obs(C.byref(e), 0x6000, None, None) == -2            # undefined for Quad-v0
+    assert lib.qr_error_obs_format(C.byref(e), 1, 0x6000, None, None) == -2  # ... in either format (a bare QuadEnv raises in the reference too)
+    e.kind = 1
+    assert lib.qr_error_obs_format(C.byref(e), 0, 0x6000, None, None) == -2 and lib.qr_error_obs_format(C.byref(e), 3, 0x6000, None, None) == -2
+    assert lib.qr_error_obs_format(C.byref(e), 2, 0x6000, None, None) == -1  # no integrator buffer; and MODUL needs obs1
+    e.kind = 0
     assert lib.qr_get_state(C.byref(e), None, None) == -1 and lib.qr_set_state(C.byref(e), None, None, None, None) == -1
     # empty batch: a no-op that succeeds; oversize batch (32-bit buffer offsets): refused
     e2, o2 = L.QrEnv(), L.QrStepOut()
@@ -261,10 +266,19 @@ def test_launch_geometry_rule_without_gpu():
     assert GOAL_EXTERNAL == 0 and info(1, 65536, AR, goal_mode=gm)[2] == 128 and info(1, 65536, AR, goal_mode=gm, n_steps=8)[2] == 64
     assert info(0, -5, AR)[0] == ""                                        # invalid descriptor
     # the override bits pin the choice per env, beyond the rule's limits in both directions; ignored where no helper instantiation exists
-    flag = {n: int(re.search(r"#define QR_FLAG_%s\s+(\d+)u" % n, hdr).group(1)) for n in ("FORCE_HELPER", "NO_HELPER")}
+    flag = {n: int(re.search(r"#define QR_FLAG_%s\s+(\d+)u" % n, hdr).group(1))
+            for n in ("FORCE_HELPER", "NO_HELPER", "FORCE_HELPER_ROLLOUT", "NO_HELPER_ROLLOUT", "CALLER_RESETS")}
+    assert len(set(flag.values()) | {AR, 2, 4}) == 8                       # eight distinct bits
     assert info(0, 1 << 20, AR)[1:] == (16384, 64)
     assert info(0, 1 << 20, AR | flag["FORCE_HELPER"])[1:] == (16384, 128) and info(0, 65536, AR | flag["NO_HELPER"])[1:] == (1024, 64)
-    assert info(2, 32768, AR | flag["NO_HELPER"])[2] == 64 and info(1, 1 << 19, AR | flag["FORCE_HELPER"], n_steps=8)[2] == 128
+    assert info(2, 32768, AR | flag["NO_HELPER"])[2] == 64 and info(1, 1 << 19, AR | flag["FORCE_HELPER_ROLLOUT"], n_steps=8)[2] == 128
+    # one bit pair per launch FAMILY: a choice timed on step() does not reach the rollouts, and the other way round
+    assert info(1, 1 << 19, AR | flag["FORCE_HELPER"], n_steps=8)[2] == 64 and info(0, 65536, AR | flag["NO_HELPER"], n_steps=100)[2] == 128
+    assert info(0, 65536, AR | flag["NO_HELPER_ROLLOUT"], n_steps=100)[2] == 64 and info(0, 65536, AR | flag["NO_HELPER_ROLLOUT"])[2] == 128
+    assert info(0, 1 << 20, AR | flag["FORCE_HELPER_ROLLOUT"])[2] == 64
+    # the thresholds the host-side autotuner reads
+    thr = L.launch_thresholds()
+    assert thr == {"step_quad": 2560, "step_wrappers": 2048, "rollout": 1024} or any(k in os.environ for k in ("QR_HELPER_GRID", "QR_HELPER_GRID_WRAP", "QR_HELPER_GRID_ROLLOUT"))
     assert info(0, 65536, AR | flag["FORCE_HELPER"], layout=1)[2] == 64 and info(0, 65536, AR | flag["FORCE_HELPER"], w_adapt=3.0)[2] == 64
     assert info(0, 65536, flag["FORCE_HELPER"])[2] == 64                   # no such instantiation without in-launch resets: ignored
 
@@ -630,3 +644,28 @@ def test_checkpoint_attitude_conversion():
             dec = torch.stack(kk)
             assert min((dec - q[:, n]).abs().max(), (dec + q[:, n]).abs().max()) <= tol   # q and -q are the same rotation
         assert int(idx[0]) == 0 and int(idx[1]) == 2 and float(p[:3, 0].abs().max()) == 0.0
+
+
+def test_launch_cache_roundtrip_and_near_threshold(tmp_path, monkeypatch):
+    """gym_rotor_amd.launch_cache (host logic of the default autotuner): which grids are worth timing, and the JSON file the choices
+    persist in — merge on store, tolerant of a missing / corrupt file, QR_LAUNCH_CACHE moves or disables it."""
+    sys.path.insert(0, ROOT)
+    from gym_rotor_amd import launch_cache as lc
+    assert lc.near_threshold(2560, 2560) and lc.near_threshold(1920, 2560) and lc.near_threshold(3200, 2560)
+    assert not lc.near_threshold(1919, 2560) and not lc.near_threshold(3201, 2560) and not lc.near_threshold(1024, 2560)
+    assert lc.near_threshold(3072, 2560) and not lc.near_threshold(2048, 0)       # Quad-v0 196 608 envs: timed; no threshold: never
+    f = tmp_path / "sub" / "launch.json"
+    monkeypatch.setenv("QR_LAUNCH_CACHE", str(f))
+    k1 = lc.key("AMD Instinct MI355X", "abi13:2600000", "quad", 3072, "mixed", "external", "default")
+    k2 = lc.key("AMD Instinct MI355X", "abi13:2600000", "coupled", 2048, "mixed", "external", "default")
+    assert lc.lookup(k1) is None
+    assert lc.store(k1, {"default": 9.0, "helper": 8.4, "no_helper": 9.0, "picked": "helper"})
+    assert lc.store(k2, {"default": 9.5, "helper": 9.5, "no_helper": 9.2, "picked": "no_helper"})
+    assert lc.lookup(k1) == {"picked": "helper", "us": {"default": 9.0, "helper": 8.4, "no_helper": 9.0}} and lc.lookup(k2)["picked"] == "no_helper"
+    assert lc.lookup(k1.replace("abi13", "abi14")) is None                        # another library build: its own entries
+    f.write_text("{ not json")
+    assert lc.lookup(k1) is None and lc.store(k1, {"default": 1.0, "helper": 1.0, "no_helper": 1.0, "picked": "default"}) and lc.lookup(k1)["picked"] == "default"
+    monkeypatch.setenv("QR_LAUNCH_CACHE", "off")
+    assert lc.path() is None and lc.lookup(k1) is None and not lc.store(k1, {"picked": "helper"})
+    monkeypatch.delenv("QR_LAUNCH_CACHE")
+    assert lc.path().endswith(os.path.join(".cache", "gym_rotor_amd", "launch.json"))

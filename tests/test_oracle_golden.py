@@ -244,3 +244,22 @@ def test_sac_actor_oracle_vs_reference_module(golden, tag):
     assert np.abs(logprob - d[f"{tag}_logprob"])[inner].max() <= 5e-4
     det, none, _, _ = ao.sac_sample(p, d[f"{tag}_obs"], None)
     assert none is None and np.abs(det - np.tanh(d[f"{tag}_mean"].astype(np.float64))).max() <= 2e-6
+
+
+def test_error_obs_formats_oracle_vs_reference(golden):
+    """get_norm_error_state(framework): the argument, not the wrapper class, selects MONO / MODUL (quad.py:452-466).  The oracle's
+    batch form and its single-env RefEnv against the reference's own outputs in both formats (tests/golden/errobs_formats.npz)."""
+    gd = golden("errobs_formats")
+    for fw, okind in (("MONO", "coupled"), ("MODUL", "decoupled")):
+        out = orc.error_obs_batch(okind, gd["state"], gd["goal"], gd["integ"])
+        for cls in ("coupled", "decoupled"):
+            for k, o in enumerate(out["obs"]):
+                assert o.dtype == np.float32 and np.array_equal(o, gd[f"{cls}_{fw}_obs{k}"]) or np.abs(o - gd[f"{cls}_{fw}_obs{k}"]).max() <= 1.2e-7
+            assert np.abs(out["integ"] - gd[f"{cls}_{fw}_next_integ"]).max() <= 1e-12
+    env = orc.RefEnv("coupled")
+    for i in (0, 7, 100):
+        for fw in ("MONO", "MODUL"):
+            env.state = gd["state"][i].copy(); env.set_goal(gd["goal"][i]); env.set_integ(gd["integ"][i])
+            rows = env.get_norm_error_state(fw)
+            for k, r in enumerate(rows):
+                assert np.abs(r - gd[f"coupled_{fw}_obs{k}"][i]).max() <= 1.2e-7

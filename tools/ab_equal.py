@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Do two builds of the library compute the same bits?  Each build (QR_LIB) steps the same batch (QR_AB_KIND, default quad; 65 536
 envs) with in-launch resets in its own subprocess and prints a digest of state, integrators, parameters, observation rows, rewards,
-dones, terminal observations, episode and tile counters.
+dones, terminal observations, episode and tile counters — then the same for qr_rollout and (wrappers) qr_rollout_actor with a PPO and an SAC actor.
 
     [QR_AB_KIND=coupled] python tools/ab_equal.py build/ab/A.so build/ab/B.so        (GPU box)
 """
@@ -31,7 +31,27 @@ for t in range(300):
         rows = d.reshape(65536, -1).any(dim=1)
         for x in [env.get_current_state(), env._params, r, env._reward_raw, d, env._episode, env._reset_count] + obs + [f[rows] for f in fin] + ([env._integ] if env._integ is not None else []):
             h.update(x.cpu().numpy().tobytes())
-print(h.hexdigest(), int(env._episode.sum()))
+step_digest = h.hexdigest()
+# the multi-step instantiations: qr_rollout (T = 24, twice) and, for the wrappers, qr_rollout_actor (PPO and SAC forms, T = 8)
+h = hashlib.sha256()
+def upd(d):
+    for k in sorted(d):
+        v = d[k]
+        if k == "obs" or v is None:
+            continue
+        for x in (v if isinstance(v, (tuple, list)) else [v]):
+            h.update(x.cpu().numpy().tobytes())
+for rep in range(2):
+    upd(env.rollout(torch.rand(24, 65536, env.action_dim, device="cuda", generator=g) * 2 - 1))
+h.update(env.get_current_state().cpu().numpy().tobytes()); h.update(env._reset_count.cpu().numpy().tobytes())
+if kind != "quad":
+    from gym_rotor_amd import random_actors
+    for algo in ("ppo", "sac"):
+        actors = random_actors(kind, "cuda", generator=torch.Generator(device="cuda").manual_seed(5), log_std=-0.5, algo=algo)
+        env.get_norm_error_state()
+        upd(env.rollout_actor(actors, 8))
+    h.update(env.get_current_state().cpu().numpy().tobytes()); h.update(env._integ.cpu().numpy().tobytes())
+print(step_digest, h.hexdigest(), int(env._episode.sum()))
 ''' % ROOT
 out = []
 for lib in sys.argv[1:3]:

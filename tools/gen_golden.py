@@ -16,6 +16,7 @@ Files written (see tests/golden/README.md for the field lists):
   onestep_{kind}.npz       512 single-step transitions per env kind
   traj_free_{kind}.npz     1000-step free-run (no reset) trajectories, 4 envs per kind
   traj_reset_{kind}.npz    1000-step trajectories with reset-on-done to injected states
+  errobs_formats.npz       (`python tools/gen_golden.py errobs`) get_norm_error_state("MONO" | "MODUL") on BOTH wrapper classes: the argument selects the format
   flightlog_modul.npz      all 3600 rows of results/MODUL_log_20250303_120200.dat
   gae.npz                  the reference's own GAE + normalisation lines (ppo.py:134-147) on synthetic data
   trajgoal_m{0,1,6}_{kind}.npz  closed loop env + TrajectoryGenerator (modes 0/1/6) as main.py drives them
@@ -805,6 +806,52 @@ def gen_closedloop_td3(framework, actors, report, modes=((0, 600), (1, 1000), (6
     np.savez_compressed(os.path.join(OUT, f"closedloop_td3_{framework.lower()}{suffix}.npz"), **out)
 
 
+def gen_errobs_formats(n=192, seed=0):
+    """get_norm_error_state(framework) with EITHER framework on each wrapper class (quad.py:421-466: the argument, not the class,
+    selects the format) — the same injected state / goal / integrator terms through CoupledWrapper and DecoupledWrapper, asked for
+    MONO and for MODUL: observation rows and the advanced integrator terms.  A bare QuadEnv raises AttributeError here (it has no
+    alpha / beta / eIx_lim): recorded as `quad_raises`."""
+    rng = np.random.default_rng(4100 + seed)
+    state = state_in(np.concatenate([orc.sample_reset_state(rng, n - n // 4, "train"), boundary_states(rng, n // 4)]))
+    goal = np.tile(orc.DEFAULT_GOAL, (n, 1)); goal[n // 3:] = random_goal(rng, n)[n // 3:]
+    integ = np.zeros((n, 8))
+    integ[:, 0:3] = rng.uniform(-1.0, 1.0, (n, 3)); integ[::5, 0:3] = rng.uniform(-4.0, 4.0, (len(integ[::5]), 3))
+    integ[:, 3:6] = rng.uniform(-1.0, 1.0, (n, 3))
+    integ[:, 6] = rng.uniform(-2.0, 2.0, n); integ[::9, 6] = rng.uniform(-4.0, 4.0, len(integ[::9]))
+    integ[:, 7] = rng.uniform(-3.0, 3.0, n)
+    integ = f32r(integ)
+    out = dict(state=state, goal=goal, integ=integ)
+    for kind in ("coupled", "decoupled"):
+        env = make_env(kind)
+        for fw, dims in (("MONO", [23]), ("MODUL", [15, 3])):
+            obs = [np.zeros((n, d), np.float32) for d in dims]
+            nxt = np.zeros((n, 8))
+            for i in range(n):
+                inject(env, state[i], goal[i], integ[i])
+                o = env.get_norm_error_state(fw)
+                assert [x.dtype for x in o] == [np.float32] * len(dims)
+                for k in range(len(dims)):
+                    obs[k][i] = o[k]
+                nxt[i] = read_integ(env)
+            for k in range(len(dims)):
+                out[f"{kind}_{fw}_obs{k}"] = obs[k]
+            out[f"{kind}_{fw}_next_integ"] = nxt
+    # the class does not matter: both wrappers inherit the method unchanged
+    for fw, nk in (("MONO", 1), ("MODUL", 2)):
+        for k in range(nk):
+            assert np.array_equal(out[f"coupled_{fw}_obs{k}"], out[f"decoupled_{fw}_obs{k}"])
+    sys.argv = ["x", "--framework", "MONO"]
+    bare = QuadEnv(); bare.reset(env_type="eval")
+    try:
+        bare.get_norm_error_state("MONO")
+        raises = ""
+    except AttributeError as ex:
+        raises = type(ex).__name__
+    out["quad_raises"] = np.array([ord(ch) for ch in raises], dtype=np.int32)
+    np.savez_compressed(os.path.join(OUT, "errobs_formats.npz"), **out)
+    print(f"errobs_formats: n={n} bare QuadEnv raises {raises!r}")
+
+
 def gen_flightlog(rows=3600):
     log = np.loadtxt(os.path.join(REF, "results", "MODUL_log_20250303_120200.dat"))
     np.savez_compressed(os.path.join(OUT, "flightlog_modul.npz"), log=log[:rows])
@@ -828,6 +875,9 @@ if __name__ == "__main__":
         for fw in ("MODUL", "MONO"):
             gen_closedloop_td3(fw, shipped[fw], rep, modes=((2, 1300), (3, 500), (4, 300), (5, 6900)), suffix="_modes2345", init_x=init_x)
         sys.exit(0)
+    if ARGV[:1] == ["errobs"]:  # only get_norm_error_state(framework) in both formats on both wrapper classes
+        gen_errobs_formats()
+        sys.exit(0)
     if ARGV[:1] == ["actor"]:  # only the actor files
         gen_actor()
         gen_actor_td3()
@@ -848,6 +898,7 @@ if __name__ == "__main__":
     for kind in ("coupled", "decoupled"):
         for mode in (0, 1, 6):
             gen_trajgoal(kind, mode)
+    gen_errobs_formats()
     gen_actor()
     gen_actor_td3()
     gen_actor_sac()
