@@ -98,30 +98,15 @@ __device__ unsigned long long* g_stamps = nullptr;
 #ifndef QR_HELP_POLICY
 #define QR_HELP_POLICY 1  // 0: no helper wave in qr_rollout_actor (Coupled 65 536 envs, T = 32: 5.37 -> 4.51 us per env-step)
 #endif
-#ifndef QR_TOUCH_COEFFS
-#define QR_TOUCH_COEFFS 1       // the stepping wave requests its kernarg lines with its first instructions (Decoupled 5.16 -> 5.02 us)
-#endif
-#ifndef QR_PREFETCH_OUT_PTRS
-#define QR_PREFETCH_OUT_PTRS 1  // plain launches read their output pointers with the first scalar batch (§3.4: Quad-v0 1 M envs 34.7 -> 33.9 us)
-#endif
-#ifndef QR_EARLY_TILE
-#define QR_EARLY_TILE 1         // plain wrapper launches write their rows to the LDS tile before the reset block (§3.3: 262 144 envs 19.1 -> 16.5 us)
-#endif
-#ifndef QR_LATE_LOADS
-#define QR_LATE_LOADS 1         // ... and request goal / integrators only after the integration (same measurement)
-#endif
-#ifndef QR_LAZY_ROLE
-#define QR_LAZY_ROLE 1          // one-step launches form the pool's role constants in the reset block (§3.3: Quad-v0 142 -> 128 VGPRs)
-#endif
-#ifndef QR_HELP_ROWS
-#define QR_HELP_ROWS 1          // the helper wave carries the observation rows out (§3.3 item 3)
-#endif
 #ifndef QR_HELP_REWARD
-#define QR_HELP_REWARD 1        // ... and forms Quad-v0's reward (§3.3 item 2; profiles/r03/ab_quad_builds.txt column q_norew)
+#define QR_HELP_REWARD 1        // the helper wave forms Quad-v0's reward (§3.3 item 2; evidence build q_norew: profiles/r03/ab_quad_builds.txt)
 #endif
-#ifndef QR_HOIST_ACT
-#define QR_HOIST_ACT 1          // rollouts form the parameter part of the action map once per episode, not per env-step (profiles/r04/ab_hoist_act.txt)
-#endif
+// (Settled A/Bs whose losing arms are gone from the tree — the winning arm is the code, the measurement is cited where it applies:
+//  kernarg lines requested with the wave's first instructions (Decoupled 5.16 -> 5.02 us), output pointers read with the first scalar
+//  batch in the plain launches (1 M envs 34.7 -> 33.9 us), rows to the LDS tile before the reset block + late goal / integrator loads
+//  in the plain wrapper launches (262 144 envs 19.1 -> 16.5 us), role constants formed in the reset block of one-step launches
+//  (142 -> 128 VGPRs), observation rows carried out by the helper wave, per-episode action-map constants in the rollouts
+//  (profiles/r04/ab_hoist_act.txt).  DESIGN.md / docs/EXPERIMENTS.md name the files.)
 #ifndef QR_HELPER_GRID
 // Grids up to this many tiles run the one-step kernel with a helper wave per tile (HELP).  The limit is an EMPIRICAL crossover,
 // not a residency rule: 2560 tiles are 5120 waves, more than the 4096 wave slots the 120-VGPR kernel has at four waves per SIMD —
@@ -269,13 +254,13 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   constexpr bool kHelpReward = HELP && !POLICY && !TRAJ && KIND == QR_KIND_QUAD && QR_HELP_REWARD;  // (TRAJ: the goal lives in the stepping wave's registers)
   __shared__ typename std::conditional<kHelpReward, PostLds<T, X>, char>::type post_lds[SINGLE ? 1 : 2];  // (a rollout alternates)
   __shared__ PoolLds<T> own_pool;  // pools this wave samples itself (no helper; or a tile's 13th.. resetting lane)
-  constexpr bool kHelpRows = HELP && SINGLE && QR_HELP_ROWS;
+  constexpr bool kHelpRows = HELP && SINGLE;
   // (plain one-step wrapper kernels: large grids) the observation rows go to their LDS tile as soon as they are formed,
   // BEFORE the reset block, and a re-sampled env overwrites its row there: the 18-23 row registers need not survive the
   // reset block.  With the late loads below: Coupled 150 -> 114 VGPRs, Decoupled 148 -> 115, i.e. four waves per SIMD
   // (262 144 envs 19.1 -> 16.5 us).  Not in the helper-wave launches, where the second write of a re-sampled env's row
   // is on the stepping wave's path (65 536 envs: 6.03 -> 6.15 us with it).
-  constexpr bool kEarlyTile = QR_EARLY_TILE && SINGLE && !HELP && !POLICY && KIND != QR_KIND_QUAD;
+  constexpr bool kEarlyTile = SINGLE && !HELP && !POLICY && KIND != QR_KIND_QUAD;
   __shared__ __attribute__((aligned(16))) float smem1[(kHelpRows || kEarlyTile || (HELP && POLICY)) && KT::D1 > 0 ? B * D1 : 4];  // (Decoupled: both tiles at once)
   if constexpr (HELP) {
     // (the wave's first lane decides: a wave-uniform branch in the compiler's eyes too — on threadIdx.x itself everything
@@ -401,7 +386,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     }
   }
   QR_STAMP(0, tid);  //@sec prologue-loads
-#if QR_TOUCH_COEFFS && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
   // The coefficient block spans five 64-byte lines of the kernarg segment (host-visible memory: ~0.5 us per miss).  The
   // compiler reads coefficients where they are used, i.e. it requests those lines only AFTER the first batch of scalar
   // loads is back, and the first arithmetic then waits for them.  One dummy word per line, requested with the wave's
@@ -457,7 +442,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   // (kLateLoads) The plain one-step wrapper kernel serves grids of several waves per SIMD, where a load's latency is
   // other waves' time: it requests the 20 words only the error observation wants (goal, integrators) AFTER the
   // integration instead of holding them across it — registers for occupancy.
-  constexpr bool kLateLoads = QR_LATE_LOADS && SINGLE && !HELP && !ADAPT && !TRAJ && !POLICY && KIND != QR_KIND_QUAD;
+  constexpr bool kLateLoads = SINGLE && !HELP && !ADAPT && !TRAJ && !POLICY && KIND != QR_KIND_QUAD;
   if constexpr (KIND != QR_KIND_QUAD && !kLateLoads) {
     const SoA<float> integ(a.integ, 8, L);
 #pragma unroll
@@ -476,7 +461,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   const bool eval_reset = (flags & QR_FLAG_EVAL_RESET) != 0;
   const bool randomise = !eval_reset && !(flags & QR_FLAG_NO_UDM) && a.params != nullptr;
   // One-step launches form the role constants in the reset block (below); a rollout forms them once, here.
-  constexpr bool kLazyRole = QR_LAZY_ROLE && SINGLE;
+  constexpr bool kLazyRole = SINGLE;
   if (!kLazyRole && !HELP && auto_reset) pool_role(role, randomise, eval_reset, c);  // (scalars only: runs while the loads are in flight)
 #pragma unroll
   for (int f = 0; f < 12; ++f) w.goal[f] = f == 6 ? 1.0f : 0.0f;  // hover default (quad.py:98-101)
@@ -506,7 +491,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       for (int f = 0; f < 12; ++f) w.goal[f] = goal.load(f, ufirst, ll);
     }
   }
-#if QR_TOUCH_COEFFS && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
   // (steps_ptr is back => s_waitcnt lgkmcnt(0) has been passed => the dummy words have landed: their registers are free)
   asm volatile("" ::"s"(ctouch[0]), "s"(ctouch[1]), "s"(ctouch[2]), "s"(ctouch[3]), "s"(ctouch[4]), "s"(ctouch[5]), "s"(steps_ptr));
 #endif
@@ -546,7 +531,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   // the loop: those kernels are at their register limit; not for Decoupled, whose rollout kernel is 1 % SLOWER with the 22 more
   // registers held across the loop.  Measured, profiles/r04/ab_hoist_act.txt: Quad-v0 65 536 envs 1.492 -> 1.469 us per env-step,
   // 262 144 envs 4.515 -> 4.354 = 60.2 G env-steps/s; Coupled 2.321 -> 2.289.)
-  constexpr bool kHoistAct = QR_HOIST_ACT && !SINGLE && !POLICY && KIND != QR_KIND_DECOUPLED;
+  constexpr bool kHoistAct = !SINGLE && !POLICY && KIND != QR_KIND_DECOUPLED;
   // (Measured and NOT adopted, profiles/r05/ab_rollout_diet.txt: the same constants parked in LDS by the kernels that cannot afford the
   // registers — bit-identical, qr_rollout_actor 0.3-1.5 % and the Decoupled rollout 5 % SLOWER: eight ds_read_b64 on a lone wave's
   // critical path cost more than the ~30 VALU instructions they replace.)
@@ -652,9 +637,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     // (65 536 envs: 4.41 us against 4.49 with the early read, 4.67 with a read pinned behind the action map).
     uint8_t* const done_ptr = ka.done;
     uint8_t* const trunc_ptr = ka.truncated;
-#if QR_PREFETCH_OUT_PTRS
     if constexpr (!HELP) asm volatile("" ::"s"(done_ptr), "s"(trunc_ptr));
-#endif
     // ---- observation_wrapper: integrate over dt with zero-order-hold (f, M) ----  //@sec integrate
     // The reference's DOP853 is adaptive (6 % of its steps subdivide); the fixed-step stand-in
     // is made rate-adaptive: RK4's local error grows like (|W| h)^5, so a wave that contains an

@@ -79,6 +79,18 @@ extern "C" {
 #define QR_GOAL_MODE3    5 /* mode 3 landing: descend at 1 m/s to the motor cut-off height -0.25 m                            */
 #define QR_GOAL_MODE4    6 /* mode 4 stay: hold the current position and heading (manual mode from the second call on)        */
 #define QR_GOAL_MODE5    7 /* mode 5 circle: 1.75 s run-up along +x, two circles of radius 0.7 m at 0.4 rad/s, then manual    */
+/* Two deviations of the stateful modes (2-5) from the reference's long-lived TrajectoryGenerator object, both bounded:
+ *  (1) Episode start.  mark_traj_start (trajectory_generator.py:176-191) keeps xd, vd, b1d, b1d_dot, Wd of the PREVIOUS episode on
+ *      the object; here every episode starts from a fresh generator (xd = vd = Wd = 0, b1d = e1, b1d_dot = 0).  Modes 2-4
+ *      overwrite all of them in their first call, so only mode 5 can tell: an episode that ended mid-circle would carry
+ *      b1d_dot != 0 into the next run-up, i.e. a non-zero Wd for the first call (|Wd_3| <= 0.4 rad/s), until the run-up branch
+ *      rewrites b1d_dot at that same call's end.  (A per-env generator has no "previous object"; the oracle models the same.)
+ *  (2) Phase boundaries.  The generator's clock is t = calls * dt formed in float32; the reference accumulates t += dt in
+ *      float64 (:224-229).  A phase test `t < t_switch` therefore flips at the same call unless t_switch lies within ~1e-6 s
+ *      of a multiple of dt — then one call early or late: a one-step goal error of at most |v| dt (take-off 0.25 mm, landing
+ *      5 mm, circle run-up 2 mm).  The one boundary that IS an exact multiple of the default dt (the circle's run-up, 350 dt)
+ *      is matched to the reference's accumulated value (1.7499999999999847 s: still run-up).  Pinned by the closed-loop
+ *      goldens for the default dt (tests/test_closedloop_td3.py); other dt: the bound above. */
 
 /* flags */
 #define QR_FLAG_AUTO_RESET   1u /* re-sample a done env inside the same launch (train distribution) */

@@ -1037,3 +1037,39 @@ def test_rollout_ignores_the_callers_reset_promise(kind):
         for t in range(40):
             e.step(acts[t])
     assert torch.equal(a.get_current_state(), b.get_current_state())
+
+
+def test_default_autotune_times_once_near_the_threshold_and_then_reads_the_cache(tmp_path, monkeypatch):
+    """The constructor's default (autotune=None): away from the launch rule's threshold nothing is timed or read; within +-25 % of
+    it the env times both step() instantiations once (~0.2 s), records the choice in the launch cache, and the next env of the same
+    (device, library, kind, size, ...) takes it from there.  Whatever is picked, no bit changes; QR_AUTOTUNE=0 and an explicit
+    `helper=` switch it off."""
+    import json
+    cache = tmp_path / "launch.json"
+    monkeypatch.setenv("QR_LAUNCH_CACHE", str(cache))
+    far = _env("quad", 64 * 700, seed=2, auto_reset=True)
+    assert far.autotune_report is None and not cache.exists()                  # 700 tiles against 2560: the rule is unambiguous
+    n = 64 * 2600                                                              # 2600 tiles: 1.6 % above Quad-v0's threshold
+    a = _env("quad", n, seed=2, auto_reset=True)
+    assert a.autotune_report["source"] == "timed" and a.autotune_report["helper"] > 0 and a.autotune_report["no_helper"] > 0
+    entries = json.loads(cache.read_text())["entries"]
+    assert len(entries) == 1 and list(entries.values())[0]["picked"] == a.autotune_report["picked"]
+    assert int(a._reset_count.abs().sum()) == 0 and int(a._episode.sum()) == 0  # tuning left no trace in the env
+    b = _env("quad", n, seed=2, auto_reset=True)
+    assert b.autotune_report["source"] == "cache" and b.autotune_report["picked"] == a.autotune_report["picked"]
+    assert b.kernel_info() == a.kernel_info()
+    c = _env("quad", n, seed=2, auto_reset=True, helper=(a.kernel_info()[2] != 128))   # the OTHER instantiation, pinned
+    assert c.autotune_report is None and c.kernel_info()[2] != a.kernel_info()[2]
+    monkeypatch.setenv("QR_AUTOTUNE", "0")
+    d = _env("quad", n, seed=2, auto_reset=True)
+    assert d.autotune_report is None and d.kernel_info()[2] == 64              # the compiled rule: 2600 > 2560 tiles -> plain launch
+    g = torch.Generator(device="cuda"); g.manual_seed(8)
+    for e in (a, b, c, d):
+        e.reset("train")
+    for t in range(12):
+        act = torch.rand(n, 4, device="cuda", generator=g) * 2 - 1
+        outs = [e.step(act) for e in (a, b, c, d)]
+        for o in outs[1:]:
+            assert torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
+    for e in (b, c, d):
+        assert torch.equal(e.get_current_state(), a.get_current_state()) and torch.equal(e._reset_count, a._reset_count)
