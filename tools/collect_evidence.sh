@@ -1,9 +1,9 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): everything DESIGN.md §5 cites, into gpurun_out/<round>/ (copy to profiles/<round>/).
-#   tools/collect_evidence.sh r04 [profiles|bench|ab|tests|all]
+#   tools/collect_evidence.sh r05 [profiles|bench|ab|tests|all]
 # The measurement-only builds are NOT pushed with the repo (.gpurunignore: build/evidence/): they are built here first.
 set -u
-RND=${1:-r04}; WHAT=${2:-all}
+RND=${1:-r05}; WHAT=${2:-all}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$RND
 EV=build/evidence
@@ -29,6 +29,7 @@ prof coupled1M --kind coupled --envs 1048576 --action-batches 16 --steps 60
 prof decoupled1M --kind decoupled --envs 1048576 --action-batches 16 --steps 60
 prof rollout_quad65536_T100 --workload rollout --horizon 100 --steps 2000
 prof rollout_actor_coupled65536_T32 --workload rollout_actor --kind coupled --horizon 32 --steps 960
+prof rollout_actor_sac_coupled65536_T32 --workload rollout_actor --kind coupled --horizon 32 --steps 960 --actor sac
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
 # (2) the bench lines themselves (un-profiled)
@@ -41,9 +42,12 @@ b decoupled262144 --kind decoupled --envs 262144 --action-batches 32 --steps 300
 b coupled1M --kind coupled --envs 1048576 --action-batches 16 --steps 100 ; b decoupled1M --kind decoupled --envs 1048576 --action-batches 16 --steps 100
 b rollout_quad65536_T100 --workload rollout --horizon 100 --steps 2000
 b rollout_actor_coupled65536_T32 --workload rollout_actor --kind coupled --horizon 32 --steps 960
+b rollout_actor_sac_coupled65536_T32 --workload rollout_actor --kind coupled --horizon 32 --steps 960 --actor sac
+b rollout_actor_sac_decoupled65536_T32 --workload rollout_actor --kind decoupled --horizon 32 --steps 960 --actor sac
 b config2 --config 2 ; b config3 --config 3 ; b config4 --config 4
-python3 bench.py --cpu-seconds 12 > "$OUT/bench_full_line.json" 2>> "$OUT/bench.err"
-python3 bench.py --steps 20 --warmup 5 --cpu-seconds 12 > "$OUT/bench_full_line_steps20.json" 2>> "$OUT/bench.err"
+python3 bench.py > "$OUT/bench_full_line.json" 2>> "$OUT/bench.err"
+python3 bench.py --steps 20 --warmup 5 > "$OUT/bench_full_line_steps20.json" 2>> "$OUT/bench.err"
+python3 tools/eager_cost.py > "$OUT/eager_cost.json" 2>> "$OUT/bench.err"
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = ab ]; then
 # (3) build-time ablations (A/B of libraries), run-time A/B, timelines, microbenchmarks
