@@ -428,7 +428,9 @@ def main():
                 break
         finite = bool(torch.isfinite(env.get_current_state()).all())
         done_rate = float(last_done().float().mean())
-        return dev_ms, wall_ms, finite, done_rate, env.kernel_info(H), n_lead * H, copies
+        tuned = env.autotune_report   # None unless the grid lies near a threshold of the launch rule (then: cached or timed choice)
+        launch_rule = "compiled rule" if tuned is None else f"{tuned.get('picked')} ({tuned.get('source', 'timed')})"
+        return dev_ms, wall_ms, finite, done_rate, env.kernel_info(H) + (launch_rule,), n_lead * H, copies
 
     from types import SimpleNamespace as NS
     head = NS(kind=a.kind, envs=N, env_offset=env_offset, substeps=a.substeps, workload=a.workload, horizon=a.horizon, steps=a.steps,
@@ -458,7 +460,7 @@ def main():
         layout = state_b + {"quad": 16 + 4 + 1 + 24, "coupled": 16 + 64 + 92 + 4 + 1 + 24,
                             "decoupled": 20 + 64 + 72 + 8 + 2 + 24}[a.kind]
         achieved = algo * N * H / (launch_us * 1e-6) / 1e9
-        kname, grid, block = kinfo
+        kname, grid, block, launch_rule = kinfo
         traffic = committed_traffic(a.kind, N, a.layout, auto_reset, a.substeps, a.workload, H)
         wl = {"step": "", "rollout": f"; fused rollout, {H} env-steps per qr_rollout launch (state in registers)",
               "rollout_actor": f"; PPO collection, {H} env-steps per qr_rollout_actor launch with the 23->16->16->4 actor (MFMA) and its "
@@ -490,7 +492,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_copy_ceiling": achieved / HBM_COPY_GBS,
                          "copy_ceiling": HBM_COPY_GBS, "traffic": (traffic or {}).get("bytes_per_launch"),
                          "traffic_source": (traffic or {}).get("source"),
-                         "kernel": kname, "grid": grid, "block": block, "avg_launch_us": launch_us,
+                         "kernel": kname, "grid": grid, "block": block, "launch_rule": launch_rule, "avg_launch_us": launch_us,
                          # the committed rocprofv3 --kernel-trace figure of the same command, for comparison: the tool costs
                          # ~4.8 us per dispatch by itself (profiles/r03/rocprof_dispatch_floor.txt) and inflates kernels shorter
                          # than ~6 us; both clocks are listed, `achieved` uses this run's HIP events
@@ -536,7 +538,7 @@ def main():
                              "env_steps_per_launch": w.horizon, "us_per_launch": us_step * w.horizon, "us_per_env_step": us_step,
                              "env_steps_per_s": w.envs / (us_step * 1e-6), "algorithmic_bytes": ab * w.envs * w.horizon,
                              "algorithmic_bytes_per_env_step": ab, "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS,
-                             "frac_of_copy_ceiling": gbs / HBM_COPY_GBS, "grid": kinf[1], "block": kinf[2], "repetitions": len(dms),
+                             "frac_of_copy_ceiling": gbs / HBM_COPY_GBS, "grid": kinf[1], "block": kinf[2], "launch_rule": kinf[3], "repetitions": len(dms),
                              "state_finite": fin, "done_rate_last_step": drate, "measure_s": time.perf_counter() - t_row})
                 torch.cuda.empty_cache()
             out["config"]["baseline_configs"] = rows
