@@ -288,3 +288,32 @@ def test_sac_actor_in_kernel_vs_reference_module(golden, kind):
     det = env.rollout_actor(actors, 1, obs=obs, deterministic=True)
     want_m = np.tanh(np.concatenate([d[f"{t}_mean"] for t in tags], 1).astype(np.float64))
     assert np.abs(_np(det["action"][0]) - want_m).max() <= 3e-6
+
+
+@pytest.mark.parametrize("kind", ["coupled", "decoupled"])
+@pytest.mark.parametrize("algo", ["ppo", "sac"])
+def test_actor_rollout_helper_launch_equals_the_plain_one(kind, algo):
+    """qr_rollout_actor picks a helper-wave instantiation (noise, reset pool and observation rows on a second wavefront per tile) for
+    grids up to 1024 tiles — since round 5 also for the general actor form (SAC's log_std head and tanh-of-sample rule).  The same
+    horizon under helper_rollout=True / False: every output row (observations, actions, log-probs, rewards, flags, terminal
+    observations), the state, the integrators, the parameters and every counter agree to the bit — through in-launch resets,
+    in-kernel noise, a time limit and a ragged last tile."""
+    from gym_rotor_amd import random_actors
+    n, T = 64 * 37 + 21, 48
+    actors = random_actors(kind, "cuda", generator=torch.Generator("cuda").manual_seed(4), log_std=-0.3, algo=algo)
+    outs, envs = [], []
+    for h in (True, False):
+        env = _env(kind, n, seed=9, auto_reset=True, max_episode_steps=30, final_obs=True, helper_rollout=h)
+        env.reset("train")
+        env.get_norm_error_state()
+        assert env.kernel_info(T)[2] == (128 if h else 64)          # (the rollout family's own override bit)
+        o1 = env.rollout_actor(actors, T)
+        o2 = env.rollout_actor(actors, 7)                            # a second launch continues the noise stream and the counters
+        outs.append((o1, o2)); envs.append(env)
+    for a, b in zip(outs[0], outs[1]):
+        for k in ("obs0", "obs1", "action", "logprob", "reward", "terminated", "truncated"):
+            if k in a:
+                assert torch.equal(a[k], b[k]), k
+    assert outs[0][0]["truncated"].any() and int(envs[0]._episode.sum()) >= n     # (the time limit alone ended every episode once)
+    for name in ("_pos_vel", "_att_rate", "_integ", "_params", "_episode", "_steps", "_reset_count"):
+        assert torch.equal(getattr(envs[0], name), getattr(envs[1], name)), name
