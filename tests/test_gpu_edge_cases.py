@@ -519,3 +519,16 @@ def test_captured_step_equals_eager_step_bit_for_bit(kind, kw):
             step()
     with pytest.raises(ValueError):
         cap_env.capture(torch.zeros(n, orc.ACTION_DIM[kind] + 1, device="cuda"))
+
+
+def test_unaligned_shard_offset_with_in_launch_resets_warns():
+    """The in-launch reset stream is keyed by 64-env tiles (quadrotor_hip.h: reset_count): a shard that does not start at a multiple
+    of 64 envs is still deterministic, but not bit-equal to the same envs inside another partition — QuadVecEnv says so once, at
+    construction; aligned shards and envs without in-launch resets stay silent."""
+    import warnings
+    with pytest.warns(UserWarning, match="multiple of 64"):
+        _env("quad", 128, auto_reset=True, env_offset=100)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        _env("quad", 128, auto_reset=True, env_offset=192)
+        _env("quad", 128, env_offset=100)
