@@ -100,7 +100,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int D, bool GENERAL>  // obs_dim 23 (COUPLED) or 15 (DECOUPLED agent 1); hidden 16, 4 actions
 struct ActorMfma {
   static constexpr int KS = (D + 3) / 4;
-  float a1[KS], a2[4], w3[4], w3s[4], bias1[4], bias2[4], bias3[4], bias3s[4], log_std[4];
+  float a1[KS], a2[4], w3[4], w3s[4], bias1[4], bias2[4], bias3[4];
+  float ls_const[4];  // the log_std head's bias (ls_head) or the state-independent log_std parameter: one of the two exists per actor
   bool ls_head;
 
   __device__ __forceinline__ void load(const ActorW& p, int lane) {
@@ -115,8 +116,7 @@ struct ActorMfma {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       bias1[r] = p.fc1_b[4 * g + r]; bias2[r] = p.fc2_b[4 * g + r]; bias3[r] = p.mean_b[r];
-      bias3s[r] = ls_head ? p.ls_b[r] : 0.0f;
-      log_std[r] = p.log_std ? p.log_std[r] : 0.0f;
+      ls_const[r] = ls_head ? p.ls_b[r] : (p.log_std ? p.log_std[r] : 0.0f);
     }
   }
 
@@ -162,7 +162,7 @@ struct ActorMfma {
 #pragma unroll
     for (int r = 0; r < 4; ++r) pre[r] = m0[r] + m1[r];
     if (ls_head) {  // same placement as the mean head: lane (g, c) receives log_std[r] of env 16 g + c
-      f32x4 l0 = f32x4{bias3s[0], bias3s[1], bias3s[2], bias3s[3]}, l1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      f32x4 l0 = f32x4{ls_const[0], ls_const[1], ls_const[2], ls_const[3]}, l1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -176,7 +176,7 @@ struct ActorMfma {
       for (int r = 0; r < 4; ++r) ls[r] = l0[r] + l1[r];
     } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ls[r] = log_std[r];
+      for (int r = 0; r < 4; ++r) ls[r] = ls_const[r];
     }
   }
 };
