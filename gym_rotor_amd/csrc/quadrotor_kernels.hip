@@ -83,9 +83,17 @@ __device__ unsigned long long* g_stamps = nullptr;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory");    \
     if (g_stamps != nullptr && threadIdx.x == 64) g_stamps[((size_t)gridDim.x + blockIdx.x) * 8 + (k)] = t_; \
   } while (0)
+// the multi-step launches (tools/phase_timeline.py): row (tile * n_steps + t) of the buffer, stamp k of step t
+#define QR_PSTAMP(k, dep)                                                                         \
+  do {                                                                                            \
+    unsigned long long t_;                                                                        \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory");    \
+    if (g_stamps != nullptr && lane == 0) g_stamps[((size_t)blockIdx.x * n_steps + t) * 8 + (k)] = t_; \
+  } while (0)
 #else
 #define QR_STAMP(k, dep) do { } while (0)
 #define QR_HSTAMP(k, dep) do { } while (0)
+#define QR_PSTAMP(k, dep) do { } while (0)
 #endif
 
 #ifndef QR_DELTA_STAGES
@@ -540,6 +548,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 
   for (int t = 0; t < n_steps; ++t) {  //@sec action-source
     float act[A];
+    if constexpr (!SINGLE) QR_PSTAMP(0, tid);
     if constexpr (POLICY) {
       float pre[A], ls[A], eps[A], logp[A];
       // the wave's observation rows -> LDS tile [lane][D0] (B operands of the first layer)
@@ -561,7 +570,9 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       }
 #pragma unroll
       for (int j = 0; j < A; ++j) eps[j] = 0.0f;
+      if constexpr (!SINGLE) QR_PSTAMP(1, pre[0] + pre[A - 1]);   // actor heads done
       if constexpr (HELP) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B1(t): see the helper wave
+      if constexpr (!SINGLE) QR_PSTAMP(2, tid);                   // past the noise barrier
       if (!ka.deterministic) {
         if (ka.noise != nullptr) {  // injected draws [T][N][A]
           if (active) {
@@ -621,6 +632,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       traj_goal<kStateful>(w, tr, goal_mode, c, b1d_dot);
     }
     QR_STAMP(2, (float)w.q[0] + (float)w.x[0] + act[0] + w.prm[0] + (float)w.W[2]);
+    if constexpr (!SINGLE) QR_PSTAMP(3, act[0] + act[A - 1]);     // action sampled (policy) / loaded
     // ---- action_wrapper ----  //@sec action-map
     Dyn<T> dyn;
     if constexpr (!kHoistAct) act_consts(w, c, ac);
@@ -688,6 +700,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     // its settled lanes early (below), otherwise after the reset block, when every lane holds what it will store.
     if (early_store) pack_quat(w.q, qp);
     QR_STAMP(3, (float)w.q[0] + (float)w.x[0] + (float)w.v[2] + (float)w.W[0]);
+    if constexpr (!SINGLE) QR_PSTAMP(4, (float)w.q[0] + (float)w.x[0] + (float)w.v[2] + (float)w.W[0]);   // integrated
 #endif
 
     // ---- obs / reward / done ----  //@sec obs-reward-done
@@ -741,6 +754,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       if (dn[g]) rwd[g] = -1.0f;
 
     QR_STAMP(4, rwd[0] + (dn[0] ? 1.0f : 0.0f));
+    if constexpr (!SINGLE) QR_PSTAMP(5, rwd[0] + (dn[0] ? 1.0f : 0.0f));   // observation, reward, done formed
     // ---- time limit + auto-reset ----  //@sec reward-done-stores
     steps += 1;
     const bool trunc = ka.max_episode_steps > 0 && steps >= ka.max_episode_steps;
@@ -768,6 +782,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     // nothing of this wave's own (its reward / done stores in flight) has to be waited for.
     if constexpr (HELP && !kHelpReward) asm volatile("s_barrier" ::: "memory");
     const unsigned long long rmask = __ballot(need_reset);
+    if constexpr (!SINGLE) QR_PSTAMP(6, tid);                     // stores issued, past the pool barrier
     if (rmask) {  // wave-uniform: skipped unless some lane of this wave starts a new episode  //@sec reset-block
       if (early_store) {
         // This wave is about to spend ~0.5 us sampling episode starts.  The state of its lanes that do NOT
@@ -914,6 +929,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       for (int j = 0; j < D1; ++j) po1[j] = o1[j];
     }
     if constexpr (!SINGLE) unpack_quat(qp, w.q);  //@sec unpack-quat  // the next env-step starts from what a single-step launch would have re-loaded
+    if constexpr (!SINGLE) QR_PSTAMP(7, (float)w.q[0] + (rmask ? 1.0f : 0.0f));   // reset block, pack, rows handed over, unpack
   }
 
   if constexpr (HELP && POLICY != 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the last step's tile: see the helper wave
