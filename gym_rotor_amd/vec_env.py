@@ -104,7 +104,9 @@ class QuadVecEnv:
                     before stepping it again — the reference's own training loop (main.py:183-186, 212-230).  No env then
                     starts a step outside the termination bounds, the rate-adaptive path cannot trigger, and step() runs the
                     kernel compiled without it: the same arithmetic, bit for bit, as with auto_reset, 8 % faster than the
-                    free-run default.  Leave False for free runs / evaluation flights that fly on after termination
+                    free-run default.  Leave False for free runs / evaluation flights that fly on after termination.  The promise
+                    is about what happens BETWEEN step() calls: a multi-step rollout() keeps the rate-adaptive kernel whatever
+                    this flag says (nobody can reset an env between two steps of one launch)
     max_episode_steps  >0 sets truncated when an episode reaches that many steps
     env_offset      global index of local env 0 (multi-GPU sharding; part of the RNG key)
     goal_mode       None: goals come from set_goal_state() (hover default).  0..6: the reference's
