@@ -41,11 +41,17 @@ for kind, n in (("quad", 65536), ("coupled", 65536), ("decoupled", 32768)):
         assert bool((env._episode - ep0 == dones).all())
     res[kind] = {"env_steps": steps * n, "episodes": int(dones.sum())}
     if kind != "quad":                 # the policy rollout with its helper wave
-        actors = random_actors(kind, dev, generator=torch.Generator(device=dev).manual_seed(7), log_std=-0.5)
-        for _ in range(max(1, total // 3200)):
-            po = env.rollout_actor(actors, 32)
-            assert bool(torch.isfinite(po["obs0"]).all()) and bool(torch.isfinite(po["logprob"]).all())
-        res[kind]["policy_steps"] = max(1, total // 3200) * 32 * n
+        for algo in ("ppo", "sac"):    # both actor forms (PPO / TD3: parameter log_std; SAC: log_std head, tanh of the sample), both with a helper wave
+            actors = random_actors(kind, dev, generator=torch.Generator(device=dev).manual_seed(7), log_std=-0.5, algo=algo)
+            rc1, ep1 = env._reset_count.clone(), env._episode.clone()
+            n_launch, ended = max(1, total // 6400), torch.zeros(n, dtype=torch.int64, device=dev)
+            for _ in range(n_launch):
+                po = env.rollout_actor(actors, 32)
+                assert bool(torch.isfinite(po["obs0"]).all()) and bool(torch.isfinite(po["logprob"]).all())
+                assert bool((po["action"].abs() <= 1).all())
+                ended += po["terminated"].reshape(32, n, -1).any(dim=2).sum(dim=0)
+            assert bool((env._reset_count - rc1 == n_launch * 32).all()) and bool((env._episode - ep1 == ended).all())
+            res[kind][f"policy_steps_{algo}"] = n_launch * 32 * n
 # the fused goal generator, every TrajectoryGenerator mode (0-6; 2-5 = the stateful ones), with a time limit: steps and rollouts alternating
 gsteps = max(200, total // 10)
 for gm in range(7):
