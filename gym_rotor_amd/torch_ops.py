@@ -158,12 +158,17 @@ def qr_rollout_actor(pos_vel: torch.Tensor, att_rate: torch.Tensor, integ: Optio
 
 @torch.library.custom_op(f"{_NS}::qr_error_obs", mutates_args=("integ", "obs0", "obs1"))
 def qr_error_obs(pos_vel: torch.Tensor, att_rate: torch.Tensor, integ: torch.Tensor, goal: Optional[torch.Tensor],
-                 obs0: torch.Tensor, obs1: Optional[torch.Tensor], cfg: List[int], coeffs: List[float]) -> None:
-    """QuadEnv.get_norm_error_state for all envs (qr_error_obs): advances the integral terms like the reference."""
+                 obs0: torch.Tensor, obs1: Optional[torch.Tensor], cfg: List[int], coeffs: List[float], fmt: int = -1) -> None:
+    """QuadEnv.get_norm_error_state(framework) for all envs (qr_error_obs / qr_error_obs_format): advances the integral terms like
+    the reference.  fmt = -1: the env's own format; 1 (= QR_KIND_COUPLED): MONO rows [N,23]; 2 (= QR_KIND_DECOUPLED): MODUL rows
+    [N,15] + [N,3] — on either wrapper kind (quad.py:452-466)."""
     e = _env_struct(pos_vel, att_rate, integ, None, goal, None, None, None, None, cfg, coeffs)
     e.goal_mode = 0
     with torch.cuda.device(pos_vel.device):
-        _lib.check(_lib.load().qr_error_obs(C.byref(e), obs0.data_ptr(), _p(obs1), _stream(pos_vel)), "qr_error_obs")
+        if fmt < 0:
+            _lib.check(_lib.load().qr_error_obs(C.byref(e), obs0.data_ptr(), _p(obs1), _stream(pos_vel)), "qr_error_obs")
+        else:
+            _lib.check(_lib.load().qr_error_obs_format(C.byref(e), int(fmt), obs0.data_ptr(), _p(obs1), _stream(pos_vel)), "qr_error_obs_format")
 
 
 @torch.library.custom_op(f"{_NS}::qr_reset", mutates_args=("pos_vel", "att_rate", "integ", "params", "episode", "steps"))
@@ -260,9 +265,16 @@ def rollout_actor(env, actors, n_steps: int, obs, out: dict, noise: Optional[tor
                                              deterministic, cfg, co)
 
 
-def error_obs(env) -> None:
+def error_obs(env, framework: Optional[str] = None, out=None) -> None:
+    """get_norm_error_state through the op: the env's own format into its own buffers, or (framework = "MONO" | "MODUL", out = the
+    row tensor(s) to fill) the format the argument names."""
     t, cfg, co = env_args(env)
-    torch.ops.gym_rotor_amd.qr_error_obs(t[0], t[1], env._integ, env._goal, env._obs0, env._obs1, cfg, co)
+    if framework is None or framework == env.framework:
+        torch.ops.gym_rotor_amd.qr_error_obs(t[0], t[1], env._integ, env._goal, env._obs0, env._obs1, cfg, co)
+        return
+    rows = [out] if isinstance(out, torch.Tensor) else list(out)
+    fmt = _lib.KIND_ID["coupled" if framework == "MONO" else "decoupled"]
+    torch.ops.gym_rotor_amd.qr_error_obs(t[0], t[1], env._integ, env._goal, rows[0], rows[1] if len(rows) > 1 else None, cfg, co, fmt)
 
 
 def reset(env, env_type: str = "train", mask: Optional[torch.Tensor] = None) -> None:

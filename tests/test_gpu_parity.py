@@ -1001,6 +1001,15 @@ def test_error_obs_in_either_format_on_either_wrapper(kind, layout, golden):
         assert (env._last_obs is not None) == own
         if own:
             assert rows[0].data_ptr() == env._obs0.data_ptr()
+        # the same through the torch custom op (one op for both entry points): identical rows from an identical start
+        from gym_rotor_amd import torch_ops as ops
+        twin = _env(kind, n, use_UDM=False, layout=layout)
+        twin.set_state(gd["state"], integ=gd["integ"])
+        _set_goal(twin, torch.from_numpy(gd["goal"]).float().cuda())
+        out = [torch.empty_like(r) for r in rows]
+        ops.error_obs(twin, fw, out if not own else None)
+        got = out if not own else [twin._obs0] + ([twin._obs1] if twin._obs1 is not None else [])
+        assert all(torch.equal(a, b) for a, b in zip(got, rows)) and torch.equal(twin._integ, env._integ)
 
 
 @pytest.mark.parametrize("kind", KINDS)
