@@ -840,7 +840,17 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       if (kLazyRole && !HELP) pool_role(role, randomise, eval_reset, c);
       for (int pass = pass0; 12 * pass < total; ++pass) {  // one pass unless more than 12 lanes reset at once
         const int slot = rank - 12 * pass;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // (multi-step kernels) keep the Philox key schedule — 20 seed-derived words — out of the step loop's preamble: made opaque
+        // HERE, the seed's derived values are formed where this rare path uses them instead of being hoisted out of the loop and
+        // spilled into VGPR lanes that the loop then reads back (in-loop v_readlane: Quad-v0 rollout 26 -> 13, Coupled actor rollout
+        // 14 -> 3; bit-identical, rollouts 1-2 % faster: profiles/r05/ab_local_keys.txt)
+        uint64_t seed_here = seed, gfirst_here = gfirst;
+        if constexpr (!SINGLE) asm volatile("" : "+s"(seed_here), "+s"(gfirst_here));
+        make_pool<T>(pool, role, seed_here, gfirst_here, rcount_s + (uint32_t)t, pass);
+#else
         make_pool<T>(pool, role, seed, gfirst, rcount_s + (uint32_t)t, pass);
+#endif
         // through LDS (six 16-byte reads per taking lane) rather than 23 ds_bpermute with all their results in flight at
         // once: 128 instead of 142 VGPRs for the plain Quad-v0 kernel, i.e. four waves per SIMD instead of three
         pool_to_lds(own_pool, pool);
