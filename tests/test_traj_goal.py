@@ -282,3 +282,35 @@ def test_rollout_equals_steps_with_fused_goal(mode):
             assert bool(((flags & 16) != 0).any())             # ... some landings have reached the cut-off height
     with pytest.raises(RuntimeError):
         envs[0].set_goal_state(np.zeros(3), np.zeros(3), np.array([1.0, 0, 0]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,z0s,vz", [(2, [-0.3, -0.4, -0.25, -0.31234], 0.05), (3, [-0.75, -1.25, -0.5, -0.61357], 1.0)])
+def test_stateful_phase_boundaries_within_one_call(mode, z0s, vz):
+    """quadrotor_hip.h, deviation (2) of the stateful goal modes: the device generator clocks its phases with t = calls * dt in
+    float32, the reference accumulates float64 t += dt.  Start heights that put the take-off / landing phase boundary on an EXACT
+    multiple of dt (z0 = -0.3: t_traj = 4 s = 800 dt; landing from -0.75: 0.5 s = 100 dt) and arbitrary ones: at every call the
+    goal agrees with the oracle's (the reference's accumulation, restated) up to at most ONE call's worth of motion, |v| dt; a start
+    height whose boundary is not near a multiple of dt switches at the same call as the reference: exact (float32 round-off)."""
+    from oracle import traj_oracle as tor
+    n = len(z0s)
+    state = np.zeros((n, 18)); state[:, 6] = state[:, 10] = state[:, 14] = 1.0
+    state[:, 0:2] = [[0.1, -0.2]] * n
+    state[:, 2] = z0s
+    env = _mk("decoupled", n, mode)
+    env.set_state(state)
+    env.mark_traj_start()
+    tr = tor.traj_start_batch(state, mode)
+    dt, worst = 0.005, np.zeros(n)
+    T = int(max(abs((-0.5 if mode == 2 else -0.25) - z) / vz for z in z0s) / dt) + 40
+    for t in range(T):
+        got = _np(torch.cat(env.get_desired(), 1))                     # xd, vd, b1d, b1d_dot, Wd
+        want = np.concatenate(tor.get_desired_batch(tr, state), 1)
+        err = np.abs(got[:, 0:3] - want[:, 0:3]).max(1)                 # position goal
+        assert (err <= vz * dt + 2e-6).all(), (t, err)                  # never more than one call's worth of motion apart
+        worst = np.maximum(worst, err)
+    # (the state is held still here, so a goal that froze one call early / late at the switch stays |v| dt off: the worst case of the
+    #  bound, visible at every later call).  Boundaries that are NOT within ~1e-6 s of a multiple of dt switch at the same call: exact.
+    assert worst[3] <= 2e-6, worst
+    print(f"stateful mode {mode}: worst goal difference per start height {np.array2string(worst, precision=2)} m over {T} calls "
+          f"(bound |v| dt = {vz * dt:.1e} m)")
