@@ -115,6 +115,9 @@ __device__ unsigned long long* g_stamps = nullptr;
 //  in the plain wrapper launches (262 144 envs 19.1 -> 16.5 us), role constants formed in the reset block of one-step launches
 //  (142 -> 128 VGPRs), observation rows carried out by the helper wave, per-episode action-map constants in the rollouts
 //  (profiles/r04/ab_hoist_act.txt).  DESIGN.md / docs/EXPERIMENTS.md name the files.)
+#ifndef QR_XCD_GRID
+#define QR_XCD_GRID 1536   // one-step helper-wave launches up to this many tiles give every XCD a contiguous range of tiles (see tile_id); 0 = never
+#endif
 #ifndef QR_HELPER_GRID
 // Grids up to this many tiles run the one-step kernel with a helper wave per tile (HELP).  The limit is an EMPIRICAL crossover,
 // not a residency rule: 2560 tiles are 5120 waves, more than the 4096 wave slots the 120-VGPR kernel has at four waves per SIMD —
@@ -239,7 +242,23 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   __shared__ __attribute__((aligned(16))) float smem[B * (D0 > A ? D0 : A)];
   const int tid = threadIdx.x;
   const unsigned lane = threadIdx.x;
-  const unsigned ufirst = blockIdx.x * (unsigned)B;
+  // XCD-aware tile map.  Workgroups are dealt round-robin over the 8 XCDs (workgroup b runs on XCD b % 8).  With tile = blockIdx.x
+  // an XCD therefore touches every EIGHTH 256- / 512-byte segment of each SoA field — its requests alias onto a few of its L2's
+  // channels.  For the grids whose working set is cache-resident (the one-step helper-wave launches up to QR_XCD_GRID tiles) every XCD
+  // gets a CONTIGUOUS range of tiles instead (a bijection for any tile count: XCD x owns q + (x < r) tiles, q = tiles / 8, r = tiles % 8):
+  // 16 384 ... 81 920 envs 0.5-4 % faster for all three kinds (Quad-v0 65 536: 4.15 -> 4.07 us, Coupled 5.34 -> 5.18, Decoupled 5.17 ->
+  // 4.98; profiles/r05/ab_xcd_map.txt), nothing at <= 8192 envs.  Larger grids stream from HBM, where the default deal keeps the eight
+  // XCDs inside the same DRAM pages: kept there (1 M envs: +1.7 % with contiguous ranges).  Which workgroup steps which tile changes no
+  // result bit (tools/ab_equal.py: identical).
+  unsigned tile_id = blockIdx.x;
+  if constexpr (HELP && SINGLE) {
+    const unsigned n_tiles = ((unsigned)n_envs + 63u) >> 6;
+    if (n_tiles <= (unsigned)QR_XCD_GRID) {
+      const unsigned xcd = blockIdx.x & 7u, q8 = n_tiles >> 3, r8 = n_tiles & 7u;
+      tile_id = xcd * q8 + (xcd < r8 ? xcd : r8) + (blockIdx.x >> 3);
+    }
+  }
+  const unsigned ufirst = tile_id * (unsigned)B;
   const int64_t first = (int64_t)ufirst;
   const int64_t i = first + tid;
   const int64_t N = a.n, L = a.ld;
@@ -293,7 +312,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       float* const hrew = ka.reward;
       float* const hraw = ka.reward_raw;
       asm volatile("" ::"s"(hob0), "s"(hob1), "s"(hrew), "s"(hraw));
-      const uint32_t rc = (uint32_t)reset_count[blockIdx.x];
+      const uint32_t rc = (uint32_t)reset_count[tile_id];
       const uint32_t hflags = ka.flags;
       const uint64_t hseed = ka.seed;
       const uint64_t hgfirst = (uint64_t)(ka.env_offset + first);
@@ -446,7 +465,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   // a vector load at the end of the wave's load queue 5.71 us, at its front 5.70 us, a load deferred until the working set
   // has been consumed 6.12 us — against 5.42 us, although scalar loads return out of order and the first use of a kernarg
   // coefficient therefore also waits for this one: the in-kernel timelines of those variants are shorter, their launches not.)
-  if (!HELP && auto_reset) rcount_s = (uint32_t)reset_count[blockIdx.x];
+  if (!HELP && auto_reset) rcount_s = (uint32_t)reset_count[tile_id];
   // (kLateLoads) The plain one-step wrapper kernel serves grids of several waves per SIMD, where a load's latency is
   // other waves' time: it requests the 20 words only the error observation wants (goal, integrators) AFTER the
   // integration instead of holding them across it — registers for occupancy.
@@ -831,7 +850,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         pass0 = 1;
         if (total > 12) {  // more than 12 lanes reset at once (rare): this wave samples the further passes itself
           pool_role(role, randomise, eval_reset, c);
-          rcount_s = (uint32_t)reset_count[blockIdx.x];  // (still this launch's base: advanced only at the end)
+          rcount_s = (uint32_t)reset_count[tile_id];  // (still this launch's base: advanced only at the end)
         }
       }
       // (one-step launches) the lane's role constants are formed HERE, not while the loads are in flight: twelve values
@@ -974,9 +993,9 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     }
   }
   if constexpr (HELP) {  // (the helper wave read the counter; this wave only advances it)
-    if (lane == 0) __hip_atomic_fetch_add(a.reset_count + blockIdx.x, n_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_fetch_add(a.reset_count + tile_id, n_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else if (auto_reset && lane == 0) {
-    a.reset_count[blockIdx.x] = (int32_t)(rcount_s + (uint32_t)n_steps);  // never reuse a (tile, counter)
+    a.reset_count[tile_id] = (int32_t)(rcount_s + (uint32_t)n_steps);  // never reuse a (tile, counter)
   }
   QR_STAMP(6, tid);
 }
