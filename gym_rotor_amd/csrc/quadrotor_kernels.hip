@@ -90,10 +90,21 @@ __device__ unsigned long long* g_stamps = nullptr;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory");    \
     if (g_stamps != nullptr && lane == 0) g_stamps[((size_t)blockIdx.x * n_steps + t) * 8 + (k)] = t_; \
   } while (0)
+// where the hardware put each wave (tools/wave_placement.py): HW_ID | XCC_ID << 32, row blockIdx.x, column = wave of the workgroup
+__device__ unsigned long long* g_hwid = nullptr;
+#define QR_HWID()                                                                                 \
+  do {                                                                                            \
+    unsigned h_, x_;                                                                              \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(h_));                              \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x_));                             \
+    if (g_hwid != nullptr && (threadIdx.x & 63u) == 0)                                            \
+      g_hwid[(size_t)blockIdx.x * 2 + (threadIdx.x >> 6)] = (unsigned long long)h_ | ((unsigned long long)x_ << 32); \
+  } while (0)
 #else
 #define QR_STAMP(k, dep) do { } while (0)
 #define QR_HSTAMP(k, dep) do { } while (0)
 #define QR_PSTAMP(k, dep) do { } while (0)
+#define QR_HWID() do { } while (0)
 #endif
 
 #ifndef QR_DELTA_STAGES
@@ -261,6 +272,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   const unsigned ufirst = tile_id * (unsigned)B;
   const int64_t first = (int64_t)ufirst;
   const int64_t i = first + tid;
+  QR_HWID();
   const int64_t N = a.n, L = a.ld;
   const int rows = min(n_envs - (int)ufirst, B);   // (n_envs < 2^31: checked on the host)
   const bool active = tid < rows;
@@ -1557,6 +1569,10 @@ extern "C" {
 int qr_debug_set_stamps(void* buf) {  // diagnostic builds only: device buffer of 8 x uint64 per wave (NULL = off)
   unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(qr::g_stamps), &p, sizeof(p));
+}
+int qr_debug_set_hwid(void* buf) {  // 2 x uint64 per workgroup: HW_ID | XCC_ID << 32 of its stepping and helper wave (NULL = off)
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(qr::g_hwid), &p, sizeof(p));
 }
 #endif
 
