@@ -90,8 +90,10 @@ struct ActorLds {
 //            D_b = h1[b][r] = H1[4 g + r][env 16 b + c].
 //   layer 2: the lane's h1[b][s] IS a B operand if k-step s is given the hidden units
 //            k(s, g) = 4 g + s, so A = W2[c][4 g + s]: no data movement between layers.
-//   layer 3: block b uses A_b = W3 placed in rows 4 b .. 4 b + 3 (zero elsewhere) and all blocks
-//            accumulate into ONE D: lane (g, c) then holds mean[r] of env 16 g + c — its own env.
+//   layer 3 (4 outputs: a 16 x 16 tile would be three quarters zeros — 512 clocks of the matrix pipe per head, measured
+//            3.84 against 3.69 us per env-step of the PPO collection step, profiles/r05/ab_l3_blocks.txt): the 16-block
+//            instruction v_mfma_f32_4x4x1 on the lane's own h2 values, then a transpose-reduce over the four 16-lane
+//            rows with v_permlane16_swap / v_permlane32_swap; lane (g, c) ends with mean[f] of env 16 g + c — its own env.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // GENERAL = false: the PPO / TD3 form only (no log_std head, tanh-of-mean rule) — what the launcher
@@ -149,31 +151,33 @@ struct ActorMfma {
 #pragma unroll
       for (int b = 0; b < 4; ++b) h2[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[s], fmaxf(h1[b][s], 0.0f), h2[b], 0, 0, 0);
     }
-    f32x4 m0 = f32x4{bias3[0], bias3[1], bias3[2], bias3[3]}, m1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};  // two chains
+    // Layer 3 on the 16-block instruction v_mfma_f32_4x4x1 (8 clocks of the matrix pipe against 32): a block is four neighbouring
+    // lanes (one hidden group g, four envs), A = W3[f = lane & 3][4 g + s] (the same w3[s]), B = the lane's own relu(h2[b][s]):
+    // D[f] of lane (g, c) = the partial sum over hidden group g for env 16 b + c.  The sum over g and the move of block b's
+    // result to row g' = b is a 4 x 4 transpose-reduce over the wave's four 16-lane rows: v_permlane16_swap exchanges the odd
+    // rows of one register with the even rows of another, v_permlane32_swap the upper half with the lower half.
+    auto head = [&](const float (&w)[4], const float (&bias)[4], float (&out)[4]) {
+      f32x4 P[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+      for (int b = 0; b < 4; ++b) P[b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const float w = ((c >> 2) == b) ? w3[s] : 0.0f;
-        f32x4& m = (b & 1) ? m1 : m0;
-        m = __builtin_amdgcn_mfma_f32_16x16x4f32(w, fmaxf(h2[b][s], 0.0f), m, 0, 0, 0);
-      }
-    }
+      for (int s = 0; s < 4; ++s) {  // (four independent chains, interleaved)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) pre[r] = m0[r] + m1[r];
-    if (ls_head) {  // same placement as the mean head: lane (g, c) receives log_std[r] of env 16 g + c
-      f32x4 l0 = f32x4{ls_const[0], ls_const[1], ls_const[2], ls_const[3]}, l1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const float w = ((c >> 2) == b) ? w3s[s] : 0.0f;
-          f32x4& l = (b & 1) ? l1 : l0;
-          l = __builtin_amdgcn_mfma_f32_16x16x4f32(w, fmaxf(h2[b][s], 0.0f), l, 0, 0, 0);
-        }
+        for (int b = 0; b < 4; ++b) P[b] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[s], fmaxf(h2[b][s], 0.0f), P[b], 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ls[r] = l0[r] + l1[r];
+      for (int f = 0; f < 4; ++f) {
+        const auto s01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(P[0][f]), __float_as_uint(P[1][f]), false, false);
+        const auto s23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(P[2][f]), __float_as_uint(P[3][f]), false, false);
+        const float q01 = __uint_as_float(s01[0]) + __uint_as_float(s01[1]);  // rows: P0 (g 0+1), P1 (g 0+1), P0 (g 2+3), P1 (g 2+3)
+        const float q23 = __uint_as_float(s23[0]) + __uint_as_float(s23[1]);  //       P2 (g 0+1), P3 (g 0+1), P2 (g 2+3), P3 (g 2+3)
+        const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(q01), __float_as_uint(q23), false, false);
+        out[f] = bias[f] + (__uint_as_float(t[0]) + __uint_as_float(t[1]));   // row b: block b summed over the four g
+      }
+    };
+    head(w3, bias3, pre);
+    if (ls_head) {
+      head(w3s, ls_const, ls);
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) ls[r] = ls_const[r];
