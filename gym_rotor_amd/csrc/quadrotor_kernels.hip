@@ -1396,14 +1396,22 @@ static void launch_kind(const Args& a, hipStream_t s) {
         // per tile (noise, reset pool, observation rows).  Measured, Coupled 65 536 envs, T = 32: 5.37 -> 4.51 us per step;
         // with the fused goal generator the same split measured SLOWER (5.65 -> 6.25 us per step, tools/ppo_rollout_bench.py;
         // both waves of a tile must be resident, which caps the kernel at 256 registers) and is not instantiated.
+        // Stage arithmetic: like every other launch, the plain (non-adaptive) instantiation whenever adaptivity provably cannot
+        // trigger (in-launch resets, w_adapt >= 2.5 W_lim) — the actor rollout then computes the same bits as qr_step on the
+        // actions it sampled, and the delta-form stages are off its path (65 536 envs: 3.70 -> 3.56 us per env-step,
+        // profiles/r05/ab_actor_plain.txt).  External goals only: with the fused generator the actor launches stay rate-adaptive.
         if (QR_HELP_POLICY && !traj && (a.flags & QR_FLAG_AUTO_RESET) && helper_choice(a, grid.x, tuning().helper_grid_rollout)) {
-          if (!general) {
-            hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 1, false, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
-            return;
-          }
-          // (the general form — SAC's log_std head and rule — with the same split: 256 VGPRs, both waves of a tile resident; measured,
-          //  profiles/r05/ab_sac_helper.txt, 65 536 envs, T = 32: Coupled 4.95 -> 4.38 us per env-step, Decoupled 5.54 -> 4.87, bit-identical)
-          hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 2, false, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
+          // (the general form — SAC's log_std head and rule — with the same split; measured, profiles/r05/ab_sac_helper.txt,
+          //  65 536 envs, T = 32: Coupled 4.95 -> 4.38 us per env-step, Decoupled 5.54 -> 4.87, bit-identical)
+          if (!general && !adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 1, false, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
+          else if (!general) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 1, false, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
+          else if (!adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 2, false, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
+          else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 2, false, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
+          return;
+        }
+        if (!traj && !adapt) {
+          if (general) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 2>), grid, dim3(64), 0, s, QR_STEP_ARGS);
+          else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 1>), grid, dim3(64), 0, s, QR_STEP_ARGS);
           return;
         }
       }

@@ -329,3 +329,33 @@ def test_actor_rollout_helper_launch_equals_the_plain_one(kind, algo):
     assert outs[0][0]["truncated"].any() and int(envs[0]._episode.sum()) >= n     # (the time limit alone ended every episode once)
     for name in ("_pos_vel", "_att_rate", "_integ", "_params", "_episode", "_steps", "_reset_count"):
         assert torch.equal(getattr(envs[0], name), getattr(envs[1], name)), name
+
+
+@pytest.mark.parametrize("kind", ["coupled", "decoupled"])
+@pytest.mark.parametrize("helper", [True, False])
+def test_actor_rollout_equals_steps_on_the_actions_it_sampled(kind, helper):
+    """With in-launch resets rate adaptivity cannot trigger (every env that leaves the regime is re-sampled at the end of that
+    step; w_adapt >= 2.5 W_lim), so qr_rollout_actor runs the plain stage arithmetic — the instantiation family of qr_step — and
+    a horizon of it IS T calls of env.step() on the actions it sampled: observations, rewards, flags, state, integrators,
+    parameters and counters agree to the bit, through in-launch resets and a time limit, with and without the helper wave."""
+    from gym_rotor_amd import random_actors
+    n, T = 64 * 9 + 5, 40
+    actors = random_actors(kind, "cuda", generator=torch.Generator("cuda").manual_seed(6), log_std=-0.3)
+    a = _env(kind, n, seed=11, auto_reset=True, max_episode_steps=25, helper_rollout=helper)
+    a.reset("train")
+    a.get_norm_error_state()
+    po = a.rollout_actor(actors, T)
+    b = _env(kind, n, seed=11, auto_reset=True, max_episode_steps=25)
+    b.reset("train")
+    b.get_norm_error_state()
+    for t in range(T):
+        o, r, d, tr, _ = b.step(po["action"][t])
+        obs = [o] if isinstance(o, torch.Tensor) else list(o)
+        for j, ob in enumerate(obs):
+            assert torch.equal(ob, po[f"obs{j}"][t]), (t, j)
+        assert torch.equal(torch.as_tensor(r).reshape(-1), po["reward"][t].reshape(-1)), t
+        assert torch.equal(torch.as_tensor(d).reshape(-1), po["terminated"][t].reshape(-1)), t
+        assert torch.equal(tr.reshape(-1), po["truncated"][t].reshape(-1)), t
+    assert po["truncated"].any() and int(a._episode.sum()) >= n           # (the time limit alone ended every episode once)
+    for name in ("_pos_vel", "_att_rate", "_integ", "_params", "_episode", "_steps", "_reset_count"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
