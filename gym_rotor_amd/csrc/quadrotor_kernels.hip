@@ -107,6 +107,12 @@ __device__ unsigned long long* g_hwid = nullptr;
 #define QR_HWID() do { } while (0)
 #endif
 
+#ifndef QR_STEP_PRIO
+#define QR_STEP_PRIO 3  // s_setprio of the stepping wave in the helper-wave launches (0: the A/B arm without it)
+#endif
+#ifndef QR_PRIO_SINGLE_TILES
+#define QR_PRIO_SINGLE_TILES 768
+#endif
 #ifndef QR_DELTA_STAGES
 #define QR_DELTA_STAGES 1  // 0: the rate-adaptive instantiations use the plain stage arithmetic (numerics: tools/numerics_delta.py and the free-run rows of
                            // profiles/r03/parity_summary.txt, 6.8e-6 -> 2.4e-6; cost: the "free run in regime" rows of profiles/r03/runtime_ab.json, 4.39 against 4.03 us)
@@ -423,6 +429,17 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       }
       return;
     }
+  }
+  // Issue priority of the stepping wave over the helper wave it shares a SIMD with (and over its own helper in the CU's shared
+  // front end): the helper then runs in the slots the stepping wave leaves empty instead of taking every other one.  Multi-step
+  // launches: for the whole launch — the helper's work per step is a third of the stepping wave's and is asked for a step later
+  // (65 536 envs, per env-step: Quad-v0 rollout 1.44 -> 1.29 us, Coupled 2.25 -> 2.12, PPO collection step 3.55 -> 3.17).
+  // One-step launches: the helper's pool is wanted within the same microsecond and its reward / rows trail the launch, so only
+  // up to the pool barrier and only on grids of at most 768 tiles (32 768 envs: wrappers -3.7 %, Quad-v0 -1.5 %; 65 536 envs
+  // +0.3...3 %, 98 304 +9 % with it).  Changes no result.  profiles/r05/ab_step_prio.txt
+  if constexpr (HELP && !SINGLE) __builtin_amdgcn_s_setprio(QR_STEP_PRIO);
+  if constexpr (HELP && SINGLE) {
+    if ((((unsigned)n_envs + 63u) >> 6) <= (unsigned)QR_PRIO_SINGLE_TILES) __builtin_amdgcn_s_setprio(QR_STEP_PRIO);
   }
   QR_STAMP(0, tid);  //@sec prologue-loads
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -750,6 +767,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         for (int j = 0; j < 4; ++j) ps.q[j][lane] = w.q[j];
         dn[0] = quad_done<T, X>(w.x, w.v, w.q, w.W, c);  // (formed while the LDS writes land)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (SINGLE) __builtin_amdgcn_s_setprio(0);
         rraw[0] = rwd[0] = 0.0f;
       } else {
         const float r = quad_reward_raw<T, X>(w.x, w.v, w.q, w.W, w.goal, c);
@@ -812,6 +830,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     // (HELP) the helper wave's pool is in LDS: it got there while this wave waited for its loads.  A bare s_barrier:
     // nothing of this wave's own (its reward / done stores in flight) has to be waited for.
     if constexpr (HELP && !kHelpReward) asm volatile("s_barrier" ::: "memory");
+    if constexpr (HELP && !kHelpReward && SINGLE) __builtin_amdgcn_s_setprio(0);
     const unsigned long long rmask = __ballot(need_reset);
     if constexpr (!SINGLE) QR_PSTAMP(6, tid);                     // stores issued, past the pool barrier
     if (rmask) {  // wave-uniform: skipped unless some lane of this wave starts a new episode  //@sec reset-block

@@ -1,0 +1,13 @@
+#!/bin/bash
+# one-step helper launches: stepping-wave priority variants by kind and size
+for kind in quad coupled decoupled; do
+  k=${kind:0:1}
+  for n in 8192 16384 32768 49152 65536 98304; do
+    line="$kind $n:"
+    for v in base s1 prio base s1 prio; do
+      t=$(QR_LIB=$PWD/build/ab/${k}_$v.so python bench.py --kind $kind --envs $n --cpu-seconds 0 --extras 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step']*1e3,3))")
+      line="$line $v=$t"
+    done
+    echo "$line"
+  done
+done
