@@ -110,6 +110,9 @@ __device__ unsigned long long* g_hwid = nullptr;
 #ifndef QR_STEP_PRIO
 #define QR_STEP_PRIO 3  // s_setprio of the stepping wave in the helper-wave launches (0: the A/B arm without it)
 #endif
+#ifndef QR_PRIO_SUBSTEPS
+#define QR_PRIO_SUBSTEPS 2
+#endif
 #ifndef QR_PRIO_SINGLE_TILES
 #define QR_PRIO_SINGLE_TILES 768
 #endif
@@ -731,6 +734,12 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       }
     } else {
       const int nsub = ka.substeps;
+      // (one-step helper launch with two or more substeps: priority for the chain from here to the pool barrier, on any grid —
+      //  Quad-v0 131 072 envs x 10 substeps 9.66 -> 9.21 us, x 4: 7.04 -> 6.67, x 2: 5.97 -> 5.78; with ONE substep it loses
+      //  at 65 536 envs (+1.2 %) and is left out: profiles/r05/ab_step_prio.txt)
+      if constexpr (HELP && SINGLE) {
+        if (nsub >= QR_PRIO_SUBSTEPS) __builtin_amdgcn_s_setprio(QR_STEP_PRIO);
+      }
       integrate(w.x, w.v, w.q, w.W, dyn, nsub, T(c.dt) * recip(T(nsub)));
     }
     renorm_quat(w.q);  //@sec renorm-late-loads-pack
