@@ -367,9 +367,9 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       };
       ResetPool<T> hp;
       if constexpr (POLICY != 0) {
-        // qr_rollout_actor.  Per env-step t the helper meets the stepping wave twice: B1(t), when the step's noise is in
-        // LDS and the tile holds the observation rows of step t-1 (which this wave then carries out), and B2(t), when the
-        // step's reset pool and the NEXT step's noise are in LDS.
+        // qr_rollout_actor.  Per env-step t the helper meets the stepping wave twice: B1(t), at the top of the step — the
+        // step's noise is in LDS and the tile holds the observation rows of step t-1 (which this wave then carries out while
+        // the stepping wave evaluates the actor) — and B2(t), when the step's reset pool and the NEXT step's noise are in LDS.
         const int hsteps = ka.n_steps;
         const int hl = (int)threadIdx.x - B;
         const bool own_noise = !ka.deterministic && ka.noise == nullptr;
@@ -608,6 +608,12 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         for (int j = 0; j < D0; ++j) smem[tid * D0 + j] = po0[j];
         tile_sync<B>();
       }
+      // B1(t), BEFORE the heads: the tile already holds the rows of step t - 1 (written at the end of that step) and the step's
+      // noise was sampled before B2(t - 1), so the helper carries the rows out and samples the step's pool and the next step's
+      // noise while this wave waits on the matrix pipe — in slots that are empty.  (Behind the heads, as before round 5, the
+      // helper's work was the critical section between B1 and B2: Decoupled PPO collection 4.16 -> 3.43 us per env-step, SAC forms
+      // -5...7 %, Coupled PPO -1.4 %; identical bits.  profiles/r05/ab_b1_early.txt)
+      if constexpr (HELP) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       {
         float p0[4], l0[4];
         actor0.heads(smem, tid, p0, l0);
@@ -622,7 +628,6 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 #pragma unroll
       for (int j = 0; j < A; ++j) eps[j] = 0.0f;
       if constexpr (!SINGLE) QR_PSTAMP(1, pre[0] + pre[A - 1]);   // actor heads done
-      if constexpr (HELP) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B1(t): see the helper wave
       if constexpr (!SINGLE) QR_PSTAMP(2, tid);                   // past the noise barrier
       if (!ka.deterministic) {
         if (ka.noise != nullptr) {  // injected draws [T][N][A]

@@ -5,7 +5,7 @@
     QR_LIB=build/ab/c_phases.so python tools/phase_timeline.py --kind coupled --workload rollout_actor [--actor sac] [--horizon 32]
 
 Every stepping wave records s_memrealtime (100 MHz, chip-wide: 10 ns resolution) at eight points of every env-step t:
-  0 top of the step | 1 actor heads done (MFMA) | 2 past the noise barrier B1 | 3 action sampled / loaded | 4 integrated
+  0 top of the step | 1 barrier B1 passed and actor heads done (MFMA) | 2 (same point since B1 moved to the top of the step) | 3 action sampled / loaded | 4 integrated
   5 observation, reward, done formed | 6 stores issued, past the pool barrier B2 | 7 reset block, pack, row hand-over, unpack done
 CAVEAT, measured: each stamp is an s_memrealtime round trip + a store on a lone wave's path — the stamped Coupled actor rollout runs
 6.2 us per env-step against the product's 3.89, so read the output as PROPORTIONS of a step (and subtract ~0.2-0.3 us of stamp from
@@ -66,7 +66,7 @@ trunc = (out["truncated"] if a.workload == "rollout" else pout["truncated"]).cpu
 rows = (done | trunc)
 pad = np.zeros((T, nw * 64), bool); pad[:, :a.envs] = rows
 wave_reset = pad.reshape(T, nw, 64).any(-1).T                          # [tile, step]
-names = ["actor heads (MFMA)", "noise barrier B1", "sample + action stores" if a.workload == "rollout_actor" else "action row",
+names = ["barrier B1 + actor heads (MFMA)", "(B1: now at the top)", "sample + action stores" if a.workload == "rollout_actor" else "action row",
          "action map + integrate", "observation, reward, done", "stores + pool barrier B2", "reset block, pack, rows, unpack"]
 if a.workload == "rollout":                                             # (no actor: stamps 1 and 2 do not exist — the top of the step stands in)
     st[:, :, 1] = st[:, :, 0]; st[:, :, 2] = st[:, :, 0]
