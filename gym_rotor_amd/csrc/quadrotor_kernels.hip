@@ -310,6 +310,12 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   // is on the stepping wave's path (65 536 envs: 6.03 -> 6.15 us with it).
   constexpr bool kEarlyTile = SINGLE && !HELP && !POLICY && KIND != QR_KIND_QUAD;
   __shared__ __attribute__((aligned(16))) float smem1[(kHelpRows || kEarlyTile || (HELP && POLICY)) && KT::D1 > 0 ? B * D1 : 4];  // (Decoupled: both tiles at once)
+  // (rollouts of the wrappers with a helper wave) the observation rows of step t go to tile t & 1 at the end of the step and the
+  // helper carries them out behind the next step's pool barrier: 91 vector instructions and 24 stores per env-step off the
+  // stepping wave (65 536 envs, T = 100: Coupled and Decoupled 2.14 -> 1.89 us per env-step; identical bits; profiles/r05/ab_roll_rows.txt)
+  constexpr bool kRollRows = HELP && !SINGLE && !POLICY && KIND != QR_KIND_QUAD;
+  __shared__ __attribute__((aligned(16))) float rtile0[kRollRows ? 2 * B * D0 : 4];
+  __shared__ __attribute__((aligned(16))) float rtile1[kRollRows && KT::D1 > 0 ? 2 * B * D1 : 4];
   if constexpr (HELP) {
     // (the wave's first lane decides: a wave-uniform branch in the compiler's eyes too — on threadIdx.x itself everything
     // after it counts as divergent control flow, and scalar offsets of the loads below were re-derived per lane)
@@ -411,6 +417,19 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
           pool_to_lds(pool_lds[t & 1], hp);
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
           help_reward(t);  // (Quad-v0) this step's reward, before the next step's pool
+          if constexpr (kRollRows) {  // (wrappers) the rows of step t - 1: complete in their tile since the end of that step
+            if (t > 0) {
+              const int hl = (int)threadIdx.x - B;
+              lds_to_rows<B, D0, AUX>(hob0 + ((int64_t)(t - 1) * n_envs + first) * D0, rtile0 + ((t - 1) & 1) * (B * D0), hl, rows);
+              if constexpr (KT::D1 > 0) lds_to_rows<B, D1, AUX>(hob1 + ((int64_t)(t - 1) * n_envs + first) * D1, rtile1 + ((t - 1) & 1) * (B * D1), hl, rows);
+            }
+          }
+        }
+        if constexpr (kRollRows) {  // the last step's rows
+          asm volatile("s_barrier" ::: "memory");
+          const int hl = (int)threadIdx.x - B;
+          lds_to_rows<B, D0, AUX>(hob0 + ((int64_t)(hsteps - 1) * n_envs + first) * D0, rtile0 + ((hsteps - 1) & 1) * (B * D0), hl, rows);
+          if constexpr (KT::D1 > 0) lds_to_rows<B, D1, AUX>(hob1 + ((int64_t)(hsteps - 1) * n_envs + first) * D1, rtile1 + ((hsteps - 1) & 1) * (B * D1), hl, rows);
         }
         return;
       }
@@ -843,7 +862,8 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     }
     // (HELP) the helper wave's pool is in LDS: it got there while this wave waited for its loads.  A bare s_barrier:
     // nothing of this wave's own (its reward / done stores in flight) has to be waited for.
-    if constexpr (HELP && !kHelpReward) asm volatile("s_barrier" ::: "memory");
+    if constexpr (kRollRows) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (+ the previous step's tile has landed)
+    else if constexpr (HELP && !kHelpReward) asm volatile("s_barrier" ::: "memory");
     if constexpr (HELP && !kHelpReward && SINGLE) __builtin_amdgcn_s_setprio(0);
     const unsigned long long rmask = __ballot(need_reset);
     if constexpr (!SINGLE) QR_PSTAMP(6, tid);                     // stores issued, past the pool barrier
@@ -981,6 +1001,9 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       rows_to_lds<D0>(o0, smem, tid);
       if constexpr (KT::D1 > 0) rows_to_lds<D1>(o1, smem1, tid);
       tile_sync<B>();
+    } else if constexpr (kRollRows) {  // tile t & 1; the helper carries it out behind the next pool barrier
+      rows_to_lds<D0>(o0, rtile0 + (t & 1) * (B * D0), tid);
+      if constexpr (KT::D1 > 0) rows_to_lds<D1>(o1, rtile1 + (t & 1) * (B * D1), tid);
     } else {
     if constexpr (KIND == QR_KIND_QUAD) {
       if (ka.obs0 != nullptr) {  // next state in the reference's order (x, v, vec_F(R), W)
@@ -1006,7 +1029,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     if constexpr (!SINGLE) QR_PSTAMP(7, (float)w.q[0] + (rmask ? 1.0f : 0.0f));   // reset block, pack, rows handed over, unpack
   }
 
-  if constexpr (HELP && POLICY != 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the last step's tile: see the helper wave
+  if constexpr ((HELP && POLICY != 0) || kRollRows) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the last step's tile: see the helper wave
   // ---- write the working set back ----  //@sec epilogue-stores
   if (active) {
     if (!(SINGLE && stored_early)) {
