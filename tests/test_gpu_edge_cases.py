@@ -532,3 +532,43 @@ def test_unaligned_shard_offset_with_in_launch_resets_warns():
         warnings.simplefilter("error")
         _env("quad", 128, auto_reset=True, env_offset=192)
         _env("quad", 128, env_offset=100)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["quad", "coupled", "decoupled"])
+def test_rollout_helper_launch_equals_the_plain_one_and_the_steps(kind):
+    """qr_rollout with in-launch resets under helper_rollout=True / False (since round 5 the helper wave also carries the wrappers'
+    observation rows out, from two alternating LDS tiles) and as T calls of step(): every row, flag, the state and the counters
+    agree to the bit — on a ragged batch whose size is odd (the row blocks of odd steps are not 16-byte aligned: the helper's
+    scalar store path), through resets, a time limit and two launches in a row."""
+    from gym_rotor_amd import QuadVecEnv
+    n, T = 64 * 21 + 37, 33
+    kw = dict(device="cuda", seed=4, auto_reset=True, obs_rows=True, max_episode_steps=20)
+    envs = [QuadVecEnv(kind, n, helper_rollout=True, **kw), QuadVecEnv(kind, n, helper_rollout=False, **kw), QuadVecEnv(kind, n, **kw)]
+    g = torch.Generator(device="cuda"); g.manual_seed(8)
+    acts = torch.rand(T + 6, n, envs[0].action_dim, device="cuda", generator=g) * 2 - 1
+    for e in envs:
+        e.reset("train")
+        if kind != "quad":
+            e.get_norm_error_state()
+    assert envs[0].kernel_info(T)[2] == 128 and envs[1].kernel_info(T)[2] == 64
+    ra = [envs[0].rollout(acts[:T]), envs[0].rollout(acts[T:])]
+    rb = [envs[1].rollout(acts[:T]), envs[1].rollout(acts[T:])]
+    as_list = lambda o: [o] if isinstance(o, torch.Tensor) else list(o)
+    for x, y in zip(ra, rb):
+        for k in ("reward", "terminated", "truncated"):
+            assert torch.equal(x[k], y[k]), k
+        for p, q in zip(as_list(x["obs"]), as_list(y["obs"])):
+            assert torch.equal(p, q)
+    for t in range(T + 6):
+        o, r, d, tr, _ = envs[2].step(acts[t])
+        src, tt = (ra[0], t) if t < T else (ra[1], t - T)
+        for p, q in zip(as_list(o), as_list(src["obs"])):
+            assert torch.equal(p, q[tt]), t
+        assert torch.equal(torch.as_tensor(r).reshape(-1), src["reward"][tt].reshape(-1)), t
+        assert torch.equal(torch.as_tensor(d).reshape(-1), src["terminated"][tt].reshape(-1)) and torch.equal(tr.reshape(-1), src["truncated"][tt].reshape(-1)), t
+    assert ra[0]["truncated"].any()
+    for name in ("_pos_vel", "_att_rate", "_integ", "_params", "_episode", "_steps", "_reset_count"):
+        for e in envs[1:]:
+            if getattr(envs[0], name) is not None:            # (Quad-v0 has no integrator words)
+                assert torch.equal(getattr(envs[0], name), getattr(e, name)), name
