@@ -91,7 +91,7 @@ struct Args {
   float max_action;
   int32_t deterministic;
   int32_t dry_run;        // qr_check_state: set_state_kernel validates and counts, writes nothing
-  int32_t pad0;
+  int32_t tile_base;      // multi-step helper launches split into chunks of resident tiles: the first tile of this launch (else 0)
   Coeffs c;
 };
 

@@ -278,6 +278,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       tile_id = xcd * q8 + (xcd < r8 ? xcd : r8) + (blockIdx.x >> 3);
     }
   }
+  if constexpr (HELP && !SINGLE) tile_id += (unsigned)ka.tile_base;  // (a chunk of a larger grid: launch_kind)
   const unsigned ufirst = tile_id * (unsigned)B;
   const int64_t first = (int64_t)ufirst;
   const int64_t i = first + tid;
@@ -1414,8 +1415,8 @@ static inline bool helper_choice(const Args& a, unsigned tiles, unsigned limit) 
   if (a.flags & (multi ? QR_FLAG_FORCE_HELPER_ROLLOUT : QR_FLAG_FORCE_HELPER)) return true;
   return tiles <= limit;
 }
-static inline bool wants_helper(const Args& a, int kind, int layout) {  // a helper wave per tile (HELP)
-  const unsigned tiles = (unsigned)((a.n + 63) / 64);
+static inline bool wants_helper(const Args& a, int kind, int layout, unsigned tiles_of_launch = 0) {  // a helper wave per tile (HELP)
+  const unsigned tiles = tiles_of_launch ? tiles_of_launch : (unsigned)((a.n + 63) / 64);
   // (the multi-step instantiations hold the loop's state across steps: 181-216 VGPRs = two waves per SIMD, so a stepping
   // and a helper wave per tile are all resident only up to 1024 tiles; beyond, measured: Quad-v0 98 304 envs 3.52 against
   // 2.97 us per env-step plain, Coupled 5.06 against 3.74)
@@ -1432,9 +1433,35 @@ static inline bool wants_helper_traj(const Args& a, int kind) {  // the same wit
          helper_choice(a, tiles, kind == QR_KIND_QUAD ? tn.helper_grid : tn.helper_grid_wrap);
 }
 
+// qr_rollout_actor beyond the grid on which a stepping AND a helper wave per tile are all resident: instead of the plain
+// instantiation over the whole grid, the helper-wave instantiation over chunks of that many tiles, one launch after the other (each
+// runs all n_steps of its envs; results do not depend on the split).  Measured, profiles/r05/ab_chunked_rollouts.txt: Coupled PPO
+// collection 98 304 / 131 072 / 262 144 envs 8.00 / 8.13 / 16.3 -> 6.28 / 6.40 / 13.3 us per env-step, Decoupled 262 144 18.1 -> 14.1.
+// Not for the plain rollouts, whose two stepping waves per SIMD use the vector unit better than chunks do (Coupled 262 144: 6.77
+// against 7.60 us chunked).
+static inline unsigned rollout_chunk(const Args& a, int kind, int layout) {
+  const unsigned tiles = (unsigned)((a.n + 63) / 64), limit = tuning().helper_grid_rollout;
+  if (a.act_out == nullptr || !QR_HELP_POLICY || kind == QR_KIND_QUAD || layout != QR_LAYOUT_MIXED || tiles <= limit || limit == 0) return 0;
+  if ((a.flags & QR_FLAG_NO_HELPER_ROLLOUT) || !(a.flags & QR_FLAG_AUTO_RESET) || a.goal_mode != QR_GOAL_EXTERNAL) return 0;
+  return limit;
+}
+
 template <int KIND, typename XV, typename QW>
-static void launch_kind(const Args& a, hipStream_t s) {
-  const dim3 grid((unsigned)((a.n + 63) / 64));
+static void launch_kind(const Args& a, hipStream_t s, unsigned tiles_of_launch = 0) {
+  if constexpr (std::is_same<XV, float>::value && std::is_same<QW, double>::value) {
+    if (tiles_of_launch == 0) {
+      if (const unsigned chunk = rollout_chunk(a, KIND, QR_LAYOUT_MIXED)) {
+        const unsigned tiles = (unsigned)((a.n + 63) / 64);
+        for (unsigned base = 0; base < tiles; base += chunk) {
+          Args b = a;
+          b.tile_base = (int32_t)base;
+          launch_kind<KIND, XV, QW>(b, s, tiles - base < chunk ? tiles - base : chunk);
+        }
+        return;
+      }
+    }
+  }
+  const dim3 grid(tiles_of_launch ? tiles_of_launch : (unsigned)((a.n + 63) / 64));
   // Rate adaptivity can only trigger when an env starts a step with max|W_i| > w_adapt.  With
   // AUTO_RESET every env whose rate error left its bound was re-sampled at the end of the step
   // that took it there (done): Quad-v0 |W_i| < W_lim, Coupled |W_i - Wd_i| < W_lim, Decoupled
@@ -1481,7 +1508,7 @@ static void launch_kind(const Args& a, hipStream_t s) {
   }
   // qr_step in the default layout: the instantiation without the loop over env-steps
   constexpr bool kHasSingle = std::is_same<XV, float>::value && std::is_same<QW, double>::value;
-  const bool help = kHasSingle && wants_helper(a, KIND, QR_LAYOUT_MIXED);
+  const bool help = kHasSingle && wants_helper(a, KIND, QR_LAYOUT_MIXED, tiles_of_launch);
   const bool help_traj = kHasSingle && a.n_steps == 1 && wants_helper_traj(a, KIND);  // (fused goal generator: one-step launches only)
   if constexpr (kHasSingle) {
     if (a.n_steps == 1) {

@@ -359,3 +359,27 @@ def test_actor_rollout_equals_steps_on_the_actions_it_sampled(kind, helper):
     assert po["truncated"].any() and int(a._episode.sum()) >= n           # (the time limit alone ended every episode once)
     for name in ("_pos_vel", "_att_rate", "_integ", "_params", "_episode", "_steps", "_reset_count"):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
+
+
+@pytest.mark.parametrize("kind", ["coupled", "decoupled"])
+def test_actor_rollout_in_chunks_of_resident_tiles_equals_the_single_launch(kind):
+    """Beyond 1024 tiles qr_rollout_actor runs its helper-wave instantiation over chunks of 1024 tiles, one launch after the other
+    (QrEnv flag bit QR_FLAG_NO_HELPER_ROLLOUT: the plain instantiation over the whole grid in one launch).  The split changes no
+    result: a ragged grid of 2.6 chunks, in-launch resets, a time limit, in-kernel noise, two launches in a row."""
+    from gym_rotor_amd import random_actors
+    n, T = 64 * 2700 + 29, 24
+    actors = random_actors(kind, "cuda", generator=torch.Generator("cuda").manual_seed(12), log_std=-0.4)
+    outs, envs = [], []
+    for h in (None, False):
+        env = _env(kind, n, seed=21, auto_reset=True, max_episode_steps=15, helper_rollout=h)
+        env.reset("train")
+        env.get_norm_error_state()
+        outs.append((env.rollout_actor(actors, T), env.rollout_actor(actors, 5)))
+        envs.append(env)
+    for a, b in zip(outs[0], outs[1]):
+        for k in ("obs0", "obs1", "action", "logprob", "reward", "terminated", "truncated"):
+            if k in a:
+                assert torch.equal(a[k], b[k]), k
+    assert outs[0][0]["truncated"].any()
+    for name in ("_pos_vel", "_att_rate", "_integ", "_params", "_episode", "_steps", "_reset_count"):
+        assert torch.equal(getattr(envs[0], name), getattr(envs[1], name)), name

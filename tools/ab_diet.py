@@ -22,6 +22,12 @@ CONFIGS = {
     "actor_coupled_sac": ["--workload", "rollout_actor", "--kind", "coupled", "--envs", "65536", "--horizon", "32", "--steps", "960", "--actor", "sac"],
     "actor_decoupled_sac": ["--workload", "rollout_actor", "--kind", "decoupled", "--envs", "65536", "--horizon", "32", "--steps", "960", "--actor", "sac"],
     "actor_coupled262k": ["--workload", "rollout_actor", "--kind", "coupled", "--envs", "262144", "--horizon", "32", "--steps", "320"],
+    "actor_coupled131k": ["--workload", "rollout_actor", "--kind", "coupled", "--envs", "131072", "--horizon", "32", "--steps", "640"],
+    "actor_coupled98k": ["--workload", "rollout_actor", "--kind", "coupled", "--envs", "98304", "--horizon", "32", "--steps", "640"],
+    "actor_decoupled262k": ["--workload", "rollout_actor", "--kind", "decoupled", "--envs", "262144", "--horizon", "32", "--steps", "320"],
+    "rollout_coupled262k": ["--workload", "rollout", "--kind", "coupled", "--envs", "262144", "--horizon", "100", "--steps", "500"],
+    "rollout_coupled98k": ["--workload", "rollout", "--kind", "coupled", "--envs", "98304", "--horizon", "100", "--steps", "1000"],
+    "rollout_decoupled262k": ["--workload", "rollout", "--kind", "decoupled", "--envs", "262144", "--horizon", "100", "--steps", "500"],
     "quad65536": ["--kind", "quad", "--envs", "65536", "--steps", "1000"],
     "quad1M": ["--kind", "quad", "--envs", "1048576", "--steps", "300", "--action-batches", "16"],
     "quad1Mx10": ["--kind", "quad", "--envs", "1048576", "--substeps", "10", "--steps", "150", "--action-batches", "16"],
