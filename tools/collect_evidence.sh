@@ -30,6 +30,8 @@ prof decoupled1M --kind decoupled --envs 1048576 --action-batches 16 --steps 60
 prof rollout_quad65536_T100 --workload rollout --horizon 100 --steps 2000
 prof rollout_actor_coupled65536_T32 --workload rollout_actor --kind coupled --horizon 32 --steps 960
 prof rollout_actor_sac_coupled65536_T32 --workload rollout_actor --kind coupled --horizon 32 --steps 960 --actor sac
+prof rollout_coupled65536_T100 --workload rollout --kind coupled --horizon 100 --steps 1000
+prof rollout_actor_coupled262144_T32 --workload rollout_actor --kind coupled --envs 262144 --horizon 32 --steps 320
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
 # (2) the bench lines themselves (un-profiled)
@@ -44,6 +46,9 @@ b rollout_quad65536_T100 --workload rollout --horizon 100 --steps 2000
 b rollout_actor_coupled65536_T32 --workload rollout_actor --kind coupled --horizon 32 --steps 960
 b rollout_actor_sac_coupled65536_T32 --workload rollout_actor --kind coupled --horizon 32 --steps 960 --actor sac
 b rollout_actor_sac_decoupled65536_T32 --workload rollout_actor --kind decoupled --horizon 32 --steps 960 --actor sac
+b rollout_actor_decoupled65536_T32 --workload rollout_actor --kind decoupled --horizon 32 --steps 960
+b rollout_coupled65536_T100 --workload rollout --kind coupled --horizon 100 --steps 1000
+b rollout_actor_coupled262144_T32 --workload rollout_actor --kind coupled --envs 262144 --horizon 32 --steps 320
 b config2 --config 2 ; b config3 --config 3 ; b config4 --config 4
 python3 bench.py > "$OUT/bench_full_line.json" 2>> "$OUT/bench.err"
 python3 bench.py --steps 20 --warmup 5 > "$OUT/bench_full_line_steps20.json" 2>> "$OUT/bench.err"
