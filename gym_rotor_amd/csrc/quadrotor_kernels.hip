@@ -110,6 +110,9 @@ __device__ unsigned long long* g_hwid = nullptr;
 #ifndef QR_STEP_PRIO
 #define QR_STEP_PRIO 3  // s_setprio of the stepping wave in the helper-wave launches (0: the A/B arm without it)
 #endif
+#ifndef QR_HELP_REWARD_TILES
+#define QR_HELP_REWARD_TILES 1408  // one-step Quad-v0 helper launches beyond this many tiles form the reward on the stepping wave
+#endif
 #ifndef QR_PRIO_SUBSTEPS
 #define QR_PRIO_SUBSTEPS 2
 #endif
@@ -142,9 +145,13 @@ __device__ unsigned long long* g_hwid = nullptr;
 // Grids up to this many tiles run the one-step kernel with a helper wave per tile (HELP).  The limit is an EMPIRICAL crossover,
 // not a residency rule: 2560 tiles are 5120 waves, more than the 4096 wave slots the 120-VGPR kernel has at four waves per SIMD —
 // the helper waves are short-lived and the launch still wins there (profiles/r03/ab_helper_thresholds.txt, with the write-through
-// stores of DESIGN.md 3.5: Quad-v0 163 840 envs 7.3 against 8.3 us plain, 196 608 equal, 262 144 10.3 against 9.9).  The environment
-// variable QR_HELPER_GRID and the QR_FLAG_*_HELPER bits override it (see `tuning`).
-#define QR_HELPER_GRID 2560
+// stores of DESIGN.md 3.5: Quad-v0 163 840 envs 7.3 against 8.3 us plain, 196 608 equal, 262 144 10.3 against 9.9).  Round 5, with
+// the reward on the stepping wave beyond QR_HELP_REWARD_TILES (one substep): 196 608 envs 8.0-8.2 against 8.8-8.9 plain, 229 376
+// 8.6-9.2 against 9.7-9.8, 245 760 9.1-9.9 against 9.9-10.1, 262 144 9.8-10.6 against 10.1-10.3 (profiles/r05/ab_step_prio.txt):
+// 3328 tiles for one substep; launches with more substeps keep 2560.  The environment variable QR_HELPER_GRID and the
+// QR_FLAG_*_HELPER bits override it (see `tuning`).
+#define QR_HELPER_GRID 3328
+#define QR_HELPER_GRID_SUBSTEPS 2560
 #endif
 #ifndef QR_HELPER_GRID_ROLLOUT
 #define QR_HELPER_GRID_ROLLOUT (QR_HELPER_GRID < 1024 ? QR_HELPER_GRID : 1024)  // qr_rollout / qr_rollout_actor (two waves per SIMD)
@@ -228,7 +235,7 @@ struct PostLds {
 // a lone wave issues one VALU instruction per ~5.6 cycles, two waves on a SIMD one per ~2.9 (tools/valu_microbench.hip),
 // so the helper runs in issue slots that are otherwise empty, and the stepping wave's reset block shrinks from
 // ~230 instructions (Philox, role scaling, attitude, 24 cross-lane reads) to six LDS reads.
-template <int KIND, typename XV, typename QW, int B, int TRAJ, bool ADAPT, int POLICY = 0, bool SINGLE = false, bool HELP = false>
+template <int KIND, typename XV, typename QW, int B, int TRAJ, bool ADAPT, int POLICY = 0, bool SINGLE = false, bool HELP = false, bool HREW = true>
 __global__ __launch_bounds__(B + (HELP ? 64 : 0), ((HELP && POLICY) ? 2 : (TRAJ || POLICY) ? 1 : 2))  // (HELP: both waves of every tile resident)
 void step_kernel(void* pos_vel, void* att_rate, const float* action, float* params, float* integ, int32_t* reset_count,
                  int32_t n_envs, int32_t ld_envs, const Args a_in) {
@@ -300,7 +307,8 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   // (POLICY with a helper wave) the step's exploration noise, sampled a step ahead by the helper: [t & 1][lane][8]
   __shared__ __attribute__((aligned(16))) float eps_lds[HELP && POLICY ? 2 * 64 * 8 : 4];
   // Quad-v0's reward (an atan2, a sqrt: ~90 instructions) is formed by the helper wave as well
-  constexpr bool kHelpReward = HELP && !POLICY && !TRAJ && KIND == QR_KIND_QUAD && QR_HELP_REWARD;  // (TRAJ: the goal lives in the stepping wave's registers)
+  // (HREW = false: the one-step Quad-v0 launch on grids where some SIMDs hold a second stepping wave — launch_kind)
+  constexpr bool kHelpReward = HELP && !POLICY && !TRAJ && KIND == QR_KIND_QUAD && QR_HELP_REWARD && HREW;  // (TRAJ: the goal lives in the stepping wave's registers)
   __shared__ typename std::conditional<kHelpReward, PostLds<T, X>, char>::type post_lds[SINGLE ? 1 : 2];  // (a rollout alternates)
   __shared__ PoolLds<T> own_pool;  // pools this wave samples itself (no helper; or a tile's 13th.. resetting lane)
   constexpr bool kHelpRows = HELP && SINGLE;
@@ -1421,7 +1429,8 @@ static inline bool wants_helper(const Args& a, int kind, int layout, unsigned ti
   // and a helper wave per tile are all resident only up to 1024 tiles; beyond, measured: Quad-v0 98 304 envs 3.52 against
   // 2.97 us per env-step plain, Coupled 5.06 against 3.74)
   const Tuning& tn = tuning();
-  const unsigned limit = a.n_steps > 1 ? tn.helper_grid_rollout : (kind == QR_KIND_QUAD ? tn.helper_grid : tn.helper_grid_wrap);
+  const unsigned quad_limit = a.substeps <= 1 || tn.helper_grid < (unsigned)QR_HELPER_GRID_SUBSTEPS ? tn.helper_grid : (unsigned)QR_HELPER_GRID_SUBSTEPS;
+  const unsigned limit = a.n_steps > 1 ? tn.helper_grid_rollout : (kind == QR_KIND_QUAD ? quad_limit : tn.helper_grid_wrap);
   return layout == QR_LAYOUT_MIXED && a.act_out == nullptr && a.goal_mode == QR_GOAL_EXTERNAL && !wants_adapt(a) &&
          (a.flags & QR_FLAG_AUTO_RESET) && helper_choice(a, tiles, limit);
 }
@@ -1430,7 +1439,8 @@ static inline bool wants_helper_traj(const Args& a, int kind) {  // the same wit
   const unsigned tiles = (unsigned)((a.n + 63) / 64);
   const Tuning& tn = tuning();
   return a.act_out == nullptr && a.goal_mode != QR_GOAL_EXTERNAL && a.goal_mode < QR_GOAL_MODE2 && !wants_adapt(a) && (a.flags & QR_FLAG_AUTO_RESET) &&
-         helper_choice(a, tiles, kind == QR_KIND_QUAD ? tn.helper_grid : tn.helper_grid_wrap);
+         helper_choice(a, tiles, kind == QR_KIND_QUAD ? (tn.helper_grid < (unsigned)QR_HELPER_GRID_SUBSTEPS ? tn.helper_grid : (unsigned)QR_HELPER_GRID_SUBSTEPS)
+                                                      : tn.helper_grid_wrap);
 }
 
 // qr_rollout_actor beyond the grid on which a stepping AND a helper wave per tile are all resident: instead of the plain
@@ -1521,7 +1531,19 @@ static void launch_kind(const Args& a, hipStream_t s, unsigned tiles_of_launch =
         else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, false, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
       } else if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
       else if (help)
-        hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 0, true, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
+      {
+        // (Quad-v0, one substep, more than QR_HELP_REWARD_TILES tiles: the reward stays on the stepping wave — measured with the
+        //  product's other choices in place, profiles/r05/ab_step_prio.txt: 98 304 envs 5.12 -> 4.92 us, 163 840 envs 7.31 -> 6.57;
+        //  identical bits)
+        bool on_stepping_wave = false;
+        if constexpr (KIND == QR_KIND_QUAD) {
+          if (a.substeps == 1 && grid.x > (unsigned)QR_HELP_REWARD_TILES) {
+            on_stepping_wave = true;
+            hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 0, true, true, false>), grid, dim3(128), 0, s, QR_STEP_ARGS);
+          }
+        }
+        if (!on_stepping_wave) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 0, true, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
+      }
       else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
       return;
     }

@@ -590,7 +590,7 @@ def test_helper_wave_launch_equals_the_plain_one(kind):
     shard small enough for the helper launch and inside a batch too large for it give the same bits — state,
     observation rows, rewards (also the raw ones), dones, terminal observations, episode counters — and so does a
     rollout, whose helper wave hands over one pool per env-step."""
-    n, shard, rank, T = 294912, 32768, 3, 160       # 4608 tiles: beyond every helper-wave limit (2560 Quad-v0 / 2048 wrappers)
+    n, shard, rank, T = 294912, 32768, 3, 160       # 4608 tiles: beyond every helper-wave limit (3328 Quad-v0 / 2048 wrappers)
     adim = 5 if kind == "decoupled" else 4
     g = torch.Generator(device="cuda"); g.manual_seed(17)
     acts = torch.rand(T, n, adim, device="cuda", generator=g) * 2 - 1
@@ -1057,8 +1057,8 @@ def test_default_autotune_times_once_near_the_threshold_and_then_reads_the_cache
     cache = tmp_path / "launch.json"
     monkeypatch.setenv("QR_LAUNCH_CACHE", str(cache))
     far = _env("quad", 64 * 700, seed=2, auto_reset=True)
-    assert far.autotune_report is None and not cache.exists()                  # 700 tiles against 2560: the rule is unambiguous
-    n = 64 * 2600                                                              # 2600 tiles: 1.6 % above Quad-v0's threshold
+    assert far.autotune_report is None and not cache.exists()                  # 700 tiles against 3328: the rule is unambiguous
+    n = 64 * 3400                                                              # 3400 tiles: 2 % above Quad-v0's threshold
     a = _env("quad", n, seed=2, auto_reset=True)
     assert a.autotune_report["source"] == "timed" and a.autotune_report["helper"] > 0 and a.autotune_report["no_helper"] > 0
     entries = json.loads(cache.read_text())["entries"]
@@ -1071,7 +1071,7 @@ def test_default_autotune_times_once_near_the_threshold_and_then_reads_the_cache
     assert c.autotune_report is None and c.kernel_info()[2] != a.kernel_info()[2]
     monkeypatch.setenv("QR_AUTOTUNE", "0")
     d = _env("quad", n, seed=2, auto_reset=True)
-    assert d.autotune_report is None and d.kernel_info()[2] == 64              # the compiled rule: 2600 > 2560 tiles -> plain launch
+    assert d.autotune_report is None and d.kernel_info()[2] == 64              # the compiled rule: 3400 > 3328 tiles -> plain launch
     g = torch.Generator(device="cuda"); g.manual_seed(8)
     for e in (a, b, c, d):
         e.reset("train")
