@@ -113,6 +113,9 @@ __device__ unsigned long long* g_hwid = nullptr;
 #ifndef QR_HELP_REWARD_TILES
 #define QR_HELP_REWARD_TILES 1408  // one-step Quad-v0 helper launches beyond this many tiles form the reward on the stepping wave
 #endif
+#ifndef QR_HELP_ROWS_TILES
+#define QR_HELP_ROWS_TILES 1600  // one-step wrapper helper launches beyond this many tiles store their rows from the stepping wave
+#endif
 #ifndef QR_PRIO_SUBSTEPS
 #define QR_PRIO_SUBSTEPS 2
 #endif
@@ -157,9 +160,11 @@ __device__ unsigned long long* g_hwid = nullptr;
 #define QR_HELPER_GRID_ROLLOUT (QR_HELPER_GRID < 1024 ? QR_HELPER_GRID : 1024)  // qr_rollout / qr_rollout_actor (two waves per SIMD)
 #endif
 #ifndef QR_HELPER_GRID_WRAP
-#define QR_HELPER_GRID_WRAP (QR_HELPER_GRID < 2048 ? QR_HELPER_GRID : 2048)  // the wrappers: ahead of the plain launch up to 262 144 envs while the action rows come
+#define QR_HELPER_GRID_WRAP (QR_HELPER_GRID < 2560 ? QR_HELPER_GRID : 2560)  // the wrappers: ahead of the plain launch up to 262 144 envs while the action rows come
 // from cache (r03/ab_helper_thresholds.txt, 8 slabs: 14.9 against 15.7 us), behind it beyond 131 072 envs when they stream from HBM (r03/ab_helper_wave.txt, 64 slabs:
-// 131 072 envs 9.4 against 9.1 us, 262 144 envs 18.4 against 16.5 — three stepping waves per SIMD hide less latency than four)
+// 131 072 envs 9.4 against 9.1 us, 262 144 envs 18.4 against 16.5 — three stepping waves per SIMD hide less latency than four).  Round 5, with the rows on
+// the stepping wave beyond QR_HELP_ROWS_TILES: ahead up to 163 840 envs with either action source (10.2-10.4 against 10.5-10.7), mixed at 196 608: 2560 tiles
+// (one substep; 2048 with more and with the fused goal generator)
 #endif
 // ------------------------------------------------------------------------------------
 // Quad-v0 reward and termination (quad.py:274-318) from the post-step state
@@ -311,7 +316,8 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
   constexpr bool kHelpReward = HELP && !POLICY && !TRAJ && KIND == QR_KIND_QUAD && QR_HELP_REWARD && HREW;  // (TRAJ: the goal lives in the stepping wave's registers)
   __shared__ typename std::conditional<kHelpReward, PostLds<T, X>, char>::type post_lds[SINGLE ? 1 : 2];  // (a rollout alternates)
   __shared__ PoolLds<T> own_pool;  // pools this wave samples itself (no helper; or a tile's 13th.. resetting lane)
-  constexpr bool kHelpRows = HELP && SINGLE;
+  // (HREW = false for a wrapper: the rows stay with the stepping wave — one-step grids beyond QR_HELP_ROWS_TILES tiles, launch_kind)
+  constexpr bool kHelpRows = HELP && SINGLE && (KIND == QR_KIND_QUAD || HREW);
   // (plain one-step wrapper kernels: large grids) the observation rows go to their LDS tile as soon as they are formed,
   // BEFORE the reset block, and a re-sampled env overwrites its row there: the 18-23 row registers need not survive the
   // reset block.  With the late loads below: Coupled 150 -> 114 VGPRs, Decoupled 148 -> 115, i.e. four waves per SIMD
@@ -1430,7 +1436,8 @@ static inline bool wants_helper(const Args& a, int kind, int layout, unsigned ti
   // 2.97 us per env-step plain, Coupled 5.06 against 3.74)
   const Tuning& tn = tuning();
   const unsigned quad_limit = a.substeps <= 1 || tn.helper_grid < (unsigned)QR_HELPER_GRID_SUBSTEPS ? tn.helper_grid : (unsigned)QR_HELPER_GRID_SUBSTEPS;
-  const unsigned limit = a.n_steps > 1 ? tn.helper_grid_rollout : (kind == QR_KIND_QUAD ? quad_limit : tn.helper_grid_wrap);
+  const unsigned wrap_limit = a.substeps <= 1 || tn.helper_grid_wrap < 2048u ? tn.helper_grid_wrap : 2048u;  // (2560 measured with one substep only)
+  const unsigned limit = a.n_steps > 1 ? tn.helper_grid_rollout : (kind == QR_KIND_QUAD ? quad_limit : wrap_limit);
   return layout == QR_LAYOUT_MIXED && a.act_out == nullptr && a.goal_mode == QR_GOAL_EXTERNAL && !wants_adapt(a) &&
          (a.flags & QR_FLAG_AUTO_RESET) && helper_choice(a, tiles, limit);
 }
@@ -1440,7 +1447,7 @@ static inline bool wants_helper_traj(const Args& a, int kind) {  // the same wit
   const Tuning& tn = tuning();
   return a.act_out == nullptr && a.goal_mode != QR_GOAL_EXTERNAL && a.goal_mode < QR_GOAL_MODE2 && !wants_adapt(a) && (a.flags & QR_FLAG_AUTO_RESET) &&
          helper_choice(a, tiles, kind == QR_KIND_QUAD ? (tn.helper_grid < (unsigned)QR_HELPER_GRID_SUBSTEPS ? tn.helper_grid : (unsigned)QR_HELPER_GRID_SUBSTEPS)
-                                                      : tn.helper_grid_wrap);
+                                                      : (tn.helper_grid_wrap < 2048u ? tn.helper_grid_wrap : 2048u));
 }
 
 // qr_rollout_actor beyond the grid on which a stepping AND a helper wave per tile are all resident: instead of the plain
@@ -1536,6 +1543,15 @@ static void launch_kind(const Args& a, hipStream_t s, unsigned tiles_of_launch =
         //  product's other choices in place, profiles/r05/ab_step_prio.txt: 98 304 envs 5.12 -> 4.92 us, 163 840 envs 7.31 -> 6.57;
         //  identical bits)
         bool on_stepping_wave = false;
+        // (the wrappers, one substep, more than QR_HELP_ROWS_TILES tiles: the helper only samples the pool, the rows go out with the
+        //  stepping wave — 114 688 envs Coupled 8.14 -> 6.98 us, Decoupled 8.21 -> 6.97; 131 072: 9.07 -> 8.61 / 9.11 -> 8.69;
+        //  98 304 envs and below are better with the helper's rows; profiles/r05/ab_step_prio.txt)
+        if constexpr (KIND != QR_KIND_QUAD) {
+          if (a.substeps == 1 && grid.x > (unsigned)QR_HELP_ROWS_TILES) {
+            on_stepping_wave = true;
+            hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 0, true, true, false>), grid, dim3(128), 0, s, QR_STEP_ARGS);
+          }
+        }
         if constexpr (KIND == QR_KIND_QUAD) {
           if (a.substeps == 1 && grid.x > (unsigned)QR_HELP_REWARD_TILES) {
             on_stepping_wave = true;

@@ -590,7 +590,7 @@ def test_helper_wave_launch_equals_the_plain_one(kind):
     shard small enough for the helper launch and inside a batch too large for it give the same bits — state,
     observation rows, rewards (also the raw ones), dones, terminal observations, episode counters — and so does a
     rollout, whose helper wave hands over one pool per env-step."""
-    n, shard, rank, T = 294912, 32768, 3, 160       # 4608 tiles: beyond every helper-wave limit (3328 Quad-v0 / 2048 wrappers)
+    n, shard, rank, T = 294912, 32768, 3, 160       # 4608 tiles: beyond every helper-wave limit (3328 Quad-v0 / 2560 wrappers)
     adim = 5 if kind == "decoupled" else 4
     g = torch.Generator(device="cuda"); g.manual_seed(17)
     acts = torch.rand(T, n, adim, device="cuda", generator=g) * 2 - 1

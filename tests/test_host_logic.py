@@ -233,7 +233,7 @@ def test_abi_argument_errors_under_sanitizers(tmp_path):
 def test_launch_geometry_rule_without_gpu():
     """qr_step_kernel_info (host-only) reports the launch the step launcher would use: one 64-lane wavefront per 64-env
     tile, plus a helper wavefront (128 threads per workgroup) exactly for: in-launch auto-reset, default layout, no rate
-    adaptivity in reach, and grids of <= 3328 tiles (Quad-v0, one substep; 2560 with more) / <= 2048 (wrappers) / <= 1024 (rollouts); with the fused
+    adaptivity in reach, and grids of <= 3328 tiles (Quad-v0, one substep; 2560 with more) / <= 2560 (wrappers; 2048 with more substeps) / <= 1024 (rollouts); with the fused
     goal generator only for one-step launches."""
     L = _lib()
     lib = L.load()
@@ -256,7 +256,7 @@ def test_launch_geometry_rule_without_gpu():
     assert info(0, 65536, AR) == ("qr::step_kernel<0,...>", 1024, 128)
     assert info(0, 65536 + 1, AR)[1:] == (1025, 128)                      # ragged tail: one more tile
     assert info(0, 212992, AR)[2] == 128 and info(0, 212992 + 64, AR)[2] == 64   # 3328 tiles (one substep)
-    assert info(1, 131072, AR)[2] == 128 and info(1, 131072 + 64, AR)[2] == 64
+    assert info(1, 163840, AR)[2] == 128 and info(1, 163840 + 64, AR)[2] == 64   # 2560 tiles (one substep)
     assert info(2, 32768, AR)[2] == 128 and info(2, 131072, AR)[2] == 128 and info(2, 262144, AR)[2] == 64
     assert info(0, 65536, 0)[2] == 64                                      # no in-launch reset: nothing for a helper to sample
     assert info(0, 65536, AR, layout=1)[2] == 64 and info(0, 65536, AR, layout=2)[2] == 64
@@ -278,7 +278,7 @@ def test_launch_geometry_rule_without_gpu():
     assert info(0, 1 << 20, AR | flag["FORCE_HELPER_ROLLOUT"])[2] == 64
     # the thresholds the host-side autotuner reads
     thr = L.launch_thresholds()
-    assert thr == {"step_quad": 3328, "step_wrappers": 2048, "rollout": 1024} or any(k in os.environ for k in ("QR_HELPER_GRID", "QR_HELPER_GRID_WRAP", "QR_HELPER_GRID_ROLLOUT"))
+    assert thr == {"step_quad": 3328, "step_wrappers": 2560, "rollout": 1024} or any(k in os.environ for k in ("QR_HELPER_GRID", "QR_HELPER_GRID_WRAP", "QR_HELPER_GRID_ROLLOUT"))
     assert info(0, 65536, AR | flag["FORCE_HELPER"], layout=1)[2] == 64 and info(0, 65536, AR | flag["FORCE_HELPER"], w_adapt=3.0)[2] == 64
     assert info(0, 65536, flag["FORCE_HELPER"])[2] == 64                   # no such instantiation without in-launch resets: ignored
 
