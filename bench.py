@@ -80,6 +80,12 @@ BASELINE_CONFIGS = [
     dict(name="rollout T=100 Quad-v0 65 536 (SURVEY 8(d) config 2, fused)", kind="quad", envs=65536, substeps=1, workload="rollout", horizon=100, steps=1000, slabs=4),
     dict(name="rollout_actor T=32 CoupledWrapper 65 536 (configs[2] PPO collection, actor in the kernel)", kind="coupled", envs=65536, substeps=1, workload="rollout_actor", horizon=32, steps=960, slabs=4),
 ]
+# fused launches beside BASELINE.json's configurations that DESIGN.md quotes (same harness; `config.other_fused_launches`)
+OTHER_FUSED = [
+    dict(name="rollout T=100 CoupledWrapper 65 536 (rows carried out by the helper wave)", kind="coupled", envs=65536, substeps=1, workload="rollout", horizon=100, steps=1000, slabs=4),
+    dict(name="rollout_actor T=32 DecoupledWrapper 65 536 (MODUL: the reference's default framework)", kind="decoupled", envs=65536, substeps=1, workload="rollout_actor", horizon=32, steps=960, slabs=4),
+    dict(name="rollout_actor T=32 CoupledWrapper 262 144 (in chunks of 1024 tiles)", kind="coupled", envs=262144, substeps=1, workload="rollout_actor", horizon=32, steps=320, slabs=4),
+]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 HBM_COPY_GBS = 6290.0  # that measured copy ceiling: SURVEY.md 8(d) asks for the fraction of both
 
@@ -308,7 +314,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     _ensure_library(dist, local_rank)
-    from gym_rotor_amd import QuadVecEnv, shard_range
+    from gym_rotor_amd import QuadVecEnv, shard_range, _lib
     if a.scaling == "strong":      # a fixed global batch, this rank's 64-aligned shard of it (no collective on the step path either way)
         G = a.global_envs
         lo, hi = shard_range(G, rank, world)
@@ -430,7 +436,17 @@ def main():
         done_rate = float(last_done().float().mean())
         tuned = env.autotune_report   # None unless the grid lies near a threshold of the launch rule (then: cached or timed choice)
         launch_rule = "compiled rule" if tuned is None else f"{tuned.get('picked')} ({tuned.get('source', 'timed')})"
-        return dev_ms, wall_ms, finite, done_rate, env.kernel_info(H) + (launch_rule,), n_lead * H, copies
+        kinfo = env.kernel_info(H)
+        if w.workload == "rollout_actor" and ar and w.helper != "off":
+            # (qr_step_kernel_info describes qr_step / qr_rollout.)  qr_rollout_actor with in-launch resets runs its helper-wave
+            # instantiation — on grids beyond the rollout threshold in chunks of that many tiles, one launch after the other
+            thr = _lib.launch_thresholds()["rollout"]
+            if w.helper == "on" or thr > 0:
+                tiles = kinfo[1]
+                launches = 1 if (thr <= 0 or tiles <= thr) else -(-tiles // thr)
+                kinfo = (kinfo[0], tiles if launches == 1 else thr, 128)
+                launch_rule += "" if launches == 1 else f"; {launches} launches of <= {thr} tiles per horizon"
+        return dev_ms, wall_ms, finite, done_rate, kinfo + (launch_rule,), n_lead * H, copies
 
     from types import SimpleNamespace as NS
     head = NS(kind=a.kind, envs=N, env_offset=env_offset, substeps=a.substeps, workload=a.workload, horizon=a.horizon, steps=a.steps,
@@ -523,7 +539,7 @@ def main():
             # every other BASELINE.json config (per-GPU and one-GPU shapes), the fused rollout and the PPO collection loop, each
             # through the SAME harness as the headline: hipGraph, lead-in, >= 20 repetitions, HIP events, median
             rows = []
-            for spec in BASELINE_CONFIGS:
+            for spec in BASELINE_CONFIGS + OTHER_FUSED:
                 if a.extras < 2 and time.perf_counter() - t_extra > a.extras_budget:
                     rows.append({"name": spec["name"], "skipped": f"--extras-budget {a.extras_budget:g} s spent"})
                     continue
@@ -541,7 +557,8 @@ def main():
                              "frac_of_copy_ceiling": gbs / HBM_COPY_GBS, "grid": kinf[1], "block": kinf[2], "launch_rule": kinf[3], "repetitions": len(dms),
                              "state_finite": fin, "done_rate_last_step": drate, "measure_s": time.perf_counter() - t_row})
                 torch.cuda.empty_cache()
-            out["config"]["baseline_configs"] = rows
+            out["config"]["baseline_configs"] = rows[:len(BASELINE_CONFIGS)]
+            out["config"]["other_fused_launches"] = rows[len(BASELINE_CONFIGS):]
             out["config"]["baseline_configs_note"] = ("same harness as the headline (hipGraph of the K env-steps, untimed lead-in, >= 20 repetitions and >= 50 ms "
                                                       "of timed work, HIP events, median); auto_reset=True, UDM parameters, 16-64 action slabs cycled")
             out["config"]["extras_s"] = time.perf_counter() - t_extra

@@ -462,7 +462,9 @@ def test_bench_presets_and_scaling_flags_without_gpu(monkeypatch):
     assert shapes == [("coupled", 65536, 1, "step", 1), ("decoupled", 32768, 1, "step", 1), ("decoupled", 262144, 1, "step", 1),
                       ("quad", 131072, 10, "step", 1), ("quad", 1048576, 10, "step", 1), ("quad", 1048576, 1, "step", 1),
                       ("quad", 65536, 1, "rollout", 100), ("coupled", 65536, 1, "rollout_actor", 32)]
-    assert all(c["steps"] % c["horizon"] == 0 and c["slabs"] * c["envs"] * 20 < 2 ** 31 for c in bench.BASELINE_CONFIGS)
+    assert all(c["steps"] % c["horizon"] == 0 and c["slabs"] * c["envs"] * 20 < 2 ** 31 for c in bench.BASELINE_CONFIGS + bench.OTHER_FUSED)
+    assert [(c["kind"], c["envs"], c["workload"]) for c in bench.OTHER_FUSED] == [("coupled", 65536, "rollout"), ("decoupled", 65536, "rollout_actor"),
+                                                                                 ("coupled", 262144, "rollout_actor")]
     assert [bench.algo_bytes_per_env_step(k) for k in ("quad", "coupled", "decoupled")] == [189, 345, 334]
     assert abs(bench.algo_bytes_per_env_step("quad", "rollout", 100) - (21 + 168 / 100)) < 1e-12
     assert abs(bench.algo_bytes_per_env_step("coupled", "rollout_actor", 32) - (129 + 232 / 32)) < 1e-12
