@@ -36,9 +36,10 @@ K is) is reported beside it as `wall_ms_per_step`; `--steps 20` and `--steps 100
 agree.  `roofline.traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed under
 profiles/ (tools/profile.sh), when one exists for this configuration.
 
-Secondary figures under `config` (rank 0, --extras 1): the other reset mode, the fused `rollout(T=100)`,
-and `policy_rollout_coupled_T32` — BASELINE configs[2]'s PPO collection loop with the actor inside the
-step kernel (qr_rollout_actor).
+Secondary figures under `config` (rank 0, --extras 1), all through the same harness as the headline: `other_reset_mode` (named),
+`baseline_configs` — every other BASELINE.json configuration in its per-GPU and one-GPU shape, the fused `rollout(T=100)` and
+configs[2]'s PPO collection loop with the actor inside the step kernel (qr_rollout_actor) — and `other_fused_launches` (the
+wrappers' rollout, the Decoupled PPO collection, a 262 144-env collection that runs in chunks).
 
 Other runs, one flag each: `--config 2|3|4` = BASELINE.json configs[2..4] in their per-GPU shape (CoupledWrapper
 65 536; DecoupledWrapper 32 768 per GPU; Quad-v0 131 072 per GPU x 10 substeps), `--scaling strong` = a fixed global batch (the
