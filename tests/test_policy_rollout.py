@@ -374,7 +374,9 @@ def test_actor_rollout_in_chunks_of_resident_tiles_equals_the_single_launch(kind
         env = _env(kind, n, seed=21, auto_reset=True, max_episode_steps=15, helper_rollout=h)
         env.reset("train")
         env.get_norm_error_state()
-        outs.append((env.rollout_actor(actors, T), env.rollout_actor(actors, 5)))
+        eps = torch.randn(4, n, env.action_dim, device="cuda", generator=torch.Generator("cuda").manual_seed(3))
+        outs.append((env.rollout_actor(actors, T), env.rollout_actor(actors, 5), env.rollout_actor(actors, 4, noise=eps),
+                     env.rollout_actor(actors, 3, deterministic=True)))          # in-kernel noise, injected draws, the mean action
         envs.append(env)
     for a, b in zip(outs[0], outs[1]):
         for k in ("obs0", "obs1", "action", "logprob", "reward", "terminated", "truncated"):
