@@ -36,10 +36,13 @@ K is) is reported beside it as `wall_ms_per_step`; `--steps 20` and `--steps 100
 agree.  `roofline.traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed under
 profiles/ (tools/profile.sh), when one exists for this configuration.
 
-Secondary figures under `config` (rank 0, --extras 1), all through the same harness as the headline: `other_reset_mode` (named),
-`baseline_configs` — every other BASELINE.json configuration in its per-GPU and one-GPU shape, the fused `rollout(T=100)` and
-configs[2]'s PPO collection loop with the actor inside the step kernel (qr_rollout_actor) — and `other_fused_launches` (the
-wrappers' rollout, the Decoupled PPO collection, a 262 144-env collection that runs in chunks).
+Secondary figures (rank 0, --extras 1), all through the same harness as the headline and all FLAT scalars under `config` (the
+driver's record keeps scalars and drops nested lists; the whole line stays under 6 KB): `free_run_us` (the other reset mode), and
+per BASELINE.json configuration `<tag>_us` (us per launch), `<tag>_frac` (SURVEY 8(d) algorithmic bytes / time / 8 TB/s) and
+`<tag>_noop_us` (qr_touch over the same buffers: the do-nothing kernel that moves the step's bytes) for
+c2_coupled65536, c3_share32768, c3_262144, c4_share131072x10, c4_1Mx10, quad1Mx1; the fused launches per env-step
+(`rollout_T100_us_per_env_step`, `ppo_collect_T32_us_per_env_step`, ...); and the float64 layout beside the default one
+(`f64_quad65536_us`, `f64_quad1Mx1_us`, `f64_coupled65536_us`).  What each row is and what binds it: DESIGN.md 5.
 
 Other runs, one flag each: `--config 2|3|4` = BASELINE.json configs[2..4] in their per-GPU shape (CoupledWrapper
 65 536; DecoupledWrapper 32 768 per GPU; Quad-v0 131 072 per GPU x 10 substeps), `--scaling strong` = a fixed global batch (the
@@ -68,25 +71,44 @@ PRESETS = {1: dict(kind="quad", envs=65536, substeps=1, total=65536, slabs=64, n
            2: dict(kind="coupled", envs=65536, substeps=1, total=65536, slabs=64, name="configs[2]: CoupledWrapper 65 536 envs + reward/done"),
            3: dict(kind="decoupled", envs=32768, substeps=1, total=262144, slabs=64, name="configs[3]: DecoupledWrapper two-agent, 262 144 envs over 8 GPUs = 32 768 per GPU"),
            4: dict(kind="quad", envs=131072, substeps=10, total=1048576, slabs=32, name="configs[4]: Quad-v0 1 048 576 envs over 8 GPUs = 131 072 per GPU, 10 substeps")}
-# What the default 1-GPU run measures BESIDE the headline (config.baseline_configs), each through the same run() harness — hipGraph,
-# lead-in, >= 20 repetitions, HIP events — as the headline itself: the other BASELINE.json configs in their per-GPU and one-GPU
-# shapes, SURVEY.md 8(d)'s fused rollout, and configs[2]'s PPO collection loop.  `steps` = env-steps per timed repetition.
+# What the default 1-GPU run measures BESIDE the headline, each through the same run() harness — hipGraph, lead-in, >= 20
+# repetitions, HIP events — as the headline itself: the other BASELINE.json configs in their per-GPU and one-GPU shapes, SURVEY.md
+# 8(d)'s fused rollout, configs[2]'s PPO collection loop, and the float64 layout.  `steps` = env-steps per timed repetition;
+# `tag` = the prefix of the row's flat keys in `config` (tag_us, tag_frac[, tag_noop_us]; fused launches: tag_us_per_env_step).
 BASELINE_CONFIGS = [
-    dict(name="configs[2] CoupledWrapper 65 536", kind="coupled", envs=65536, substeps=1, workload="step", horizon=1, steps=300, slabs=64),
-    dict(name="configs[3] DecoupledWrapper 32 768 (per-GPU share of 262 144)", kind="decoupled", envs=32768, substeps=1, workload="step", horizon=1, steps=300, slabs=64),
-    dict(name="configs[3] DecoupledWrapper 262 144 (one GPU)", kind="decoupled", envs=262144, substeps=1, workload="step", horizon=1, steps=300, slabs=32),
-    dict(name="configs[4] Quad-v0 131 072 x 10 substeps (per-GPU share of 1 048 576)", kind="quad", envs=131072, substeps=10, workload="step", horizon=1, steps=300, slabs=32),
-    dict(name="configs[4] Quad-v0 1 048 576 x 10 substeps (one GPU)", kind="quad", envs=1048576, substeps=10, workload="step", horizon=1, steps=150, slabs=16),
-    dict(name="Quad-v0 1 048 576 x 1 substep (one GPU, the HBM-roofline row)", kind="quad", envs=1048576, substeps=1, workload="step", horizon=1, steps=300, slabs=16),
-    dict(name="rollout T=100 Quad-v0 65 536 (SURVEY 8(d) config 2, fused)", kind="quad", envs=65536, substeps=1, workload="rollout", horizon=100, steps=1000, slabs=4),
-    dict(name="rollout_actor T=32 CoupledWrapper 65 536 (configs[2] PPO collection, actor in the kernel)", kind="coupled", envs=65536, substeps=1, workload="rollout_actor", horizon=32, steps=960, slabs=4),
+    dict(tag="c2_coupled65536", kind="coupled", envs=65536, substeps=1, workload="step", horizon=1, steps=300, slabs=64),
+    dict(tag="c3_share32768", kind="decoupled", envs=32768, substeps=1, workload="step", horizon=1, steps=300, slabs=64),
+    dict(tag="c3_262144", kind="decoupled", envs=262144, substeps=1, workload="step", horizon=1, steps=300, slabs=32),
+    dict(tag="c4_share131072x10", kind="quad", envs=131072, substeps=10, workload="step", horizon=1, steps=300, slabs=32),
+    dict(tag="c4_1Mx10", kind="quad", envs=1048576, substeps=10, workload="step", horizon=1, steps=150, slabs=16),
+    dict(tag="quad1Mx1", kind="quad", envs=1048576, substeps=1, workload="step", horizon=1, steps=300, slabs=16),
+    dict(tag="rollout_T100", kind="quad", envs=65536, substeps=1, workload="rollout", horizon=100, steps=1000, slabs=4),
+    dict(tag="ppo_collect_T32", kind="coupled", envs=65536, substeps=1, workload="rollout_actor", horizon=32, steps=960, slabs=4),
 ]
-# fused launches beside BASELINE.json's configurations that DESIGN.md quotes (same harness; `config.other_fused_launches`)
-OTHER_FUSED = [
-    dict(name="rollout T=100 CoupledWrapper 65 536 (rows carried out by the helper wave)", kind="coupled", envs=65536, substeps=1, workload="rollout", horizon=100, steps=1000, slabs=4),
-    dict(name="rollout_actor T=32 DecoupledWrapper 65 536 (MODUL: the reference's default framework)", kind="decoupled", envs=65536, substeps=1, workload="rollout_actor", horizon=32, steps=960, slabs=4),
-    dict(name="rollout_actor T=32 CoupledWrapper 262 144 (in chunks of 1024 tiles)", kind="coupled", envs=262144, substeps=1, workload="rollout_actor", horizon=32, steps=320, slabs=4),
+# the float64 layout beside the default one (what the precision choice costs: DESIGN.md 4), and the fused launches DESIGN.md quotes
+OTHER_ROWS = [
+    dict(tag="f64_quad65536", kind="quad", envs=65536, substeps=1, workload="step", horizon=1, steps=300, slabs=64, layout="f64"),
+    dict(tag="f64_coupled65536", kind="coupled", envs=65536, substeps=1, workload="step", horizon=1, steps=300, slabs=64, layout="f64"),
+    dict(tag="f64_quad1Mx1", kind="quad", envs=1048576, substeps=1, workload="step", horizon=1, steps=300, slabs=16, layout="f64"),
+    dict(tag="rollout_T100_coupled", kind="coupled", envs=65536, substeps=1, workload="rollout", horizon=100, steps=1000, slabs=4),
+    dict(tag="ppo_collect_T32_decoupled", kind="decoupled", envs=65536, substeps=1, workload="rollout_actor", horizon=32, steps=960, slabs=4),
+    dict(tag="ppo_collect_T32_coupled262144", kind="coupled", envs=262144, substeps=1, workload="rollout_actor", horizon=32, steps=320, slabs=4),
 ]
+
+
+def secondary_keys():
+    """The flat `config` keys a full default run adds beside the headline (tests pin them; DESIGN.md 5 explains each)."""
+    keys = ["free_run_us"]
+    for spec in BASELINE_CONFIGS + OTHER_ROWS:
+        tag = spec["tag"]
+        if spec["workload"] == "step":
+            keys += [f"{tag}_us", f"{tag}_frac"] + ([] if "layout" in spec else [f"{tag}_noop_us"])
+        else:
+            keys += [f"{tag}_us_per_env_step", f"{tag}_frac"]
+    return keys + ["extras_s"]
+
+
+MAX_LINE_BYTES = 6144  # the driver keeps 8 KB of stdout: the JSON line must fit with room to spare (asserted before printing)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 HBM_COPY_GBS = 6290.0  # that measured copy ceiling: SURVEY.md 8(d) asks for the fraction of both
 
@@ -108,13 +130,14 @@ def parse():
     p.add_argument("--action-batches", type=int, default=64, help="distinct pre-generated [N,A] action slabs cycled through (64 x 1 MiB > L2: every step streams its actions)")
     p.add_argument("--extras", type=int, default=1, help="0: only the headline measurement (used under rocprofv3); 1: + config.other_reset_mode and "
                                                          "config.baseline_configs within --extras-budget; 2: all of them whatever they take")
-    p.add_argument("--extras-budget", type=float, default=60.0, help="seconds after which the remaining baseline_configs rows are skipped (--extras 1)")
+    p.add_argument("--extras-budget", type=float, default=60.0, help="seconds after which the remaining secondary rows are skipped (--extras 1)")
     p.add_argument("--actor", default="ppo", choices=["ppo", "sac"], help="--workload rollout_actor: the actor form (ppo: parameter log_std, "
                                                                             "tanh-of-mean rule; sac: state-dependent log_std head, tanh-of-sample rule = the POLICY=2 kernel)")
-    p.add_argument("--workload", default="step", choices=["step", "rollout", "rollout_actor"],
+    p.add_argument("--workload", default="step", choices=["step", "rollout", "rollout_actor", "touch"],
                    help="step: one qr_step launch per env-step (the metric's configuration).  rollout: --horizon env-steps per qr_rollout "
                         "launch, state in registers (SURVEY.md 8(d) config 2).  rollout_actor: the PPO collection loop with the actor inside "
-                        "the step kernel (qr_rollout_actor; BASELINE configs[2]; --kind coupled|decoupled).  --steps counts env-steps in all three")
+                        "the step kernel (qr_rollout_actor; BASELINE configs[2]; --kind coupled|decoupled).  touch: qr_touch, the do-nothing kernel that "
+                        "moves one step's bytes (the yardstick of roofline.frac_of_noop_kernel).  --steps counts env-steps in all of them")
     p.add_argument("--horizon", type=int, default=0, help="env-steps per launch of the rollout workloads (default 100 / 32)")
     p.add_argument("--helper", default="auto", choices=["auto", "on", "off"], help="launch rule override: a helper wavefront per tile (QR_FLAG_FORCE_HELPER / QR_FLAG_NO_HELPER; their _ROLLOUT twins for the rollout workloads)")
     p.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4],
@@ -136,8 +159,8 @@ def parse():
     if a.workload == "rollout_actor" and a.kind == "quad":
         a.kind = "coupled"
     if a.horizon <= 0:
-        a.horizon = {"step": 1, "rollout": 100, "rollout_actor": 32}[a.workload]
-    if a.workload == "step":
+        a.horizon = {"step": 1, "touch": 1, "rollout": 100, "rollout_actor": 32}[a.workload]
+    if a.workload in ("step", "touch"):
         a.horizon = 1
     a.steps = -(-a.steps // a.horizon) * a.horizon   # whole launches
     return a
@@ -201,11 +224,13 @@ def cpu_baseline(kind: str, seconds: float):
     except Exception:
         pass
     return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n} single-env {kind} steps (NumPy RHS + scipy DOP853 + ensure_SO3, random actions, "
-                      f"reset-on-done) in {dt:.1f}s on 1 core; vectorised NumPy oracle at N=65536: {vec:.0f} env-steps/s",
+            "sample": f"{n} single-env {kind} steps of oracle.RefEnv (NumPy RHS + scipy DOP853, reset-on-done) in {dt:.1f}s, 1 core",
             "vectorised_numpy_value": vec, "multi_process_value": all_cores, "multi_process_procs": procs, "host_cores": cores,
-            "cpu_model": cpu,
-            "numpy": np.__version__, "scipy": scipy.__version__}
+            "cpu_model": cpu, "numpy": np.__version__, "scipy": scipy.__version__,
+            # `value` is the ORACLE's port of the single-env step on this box.  The reference itself, timed in the survey
+            # container: 0.5-0.7 k steps/s per core — its own Python overhead (ensure_SO3 through
+            # np.isclose, scipy Rotation objects) is larger than the port's
+            "reference_itself_steps_per_s_per_core": "500-700 (survey container, BASELINE.md 1)"}
 
 
 def committed_traffic(kind, envs, layout, auto_reset, substeps=1, workload="step", horizon=1):
@@ -336,8 +361,8 @@ def main():
         steps, then repetitions of exactly K = w.steps timed env-steps; returns the per-repetition (HIP-event ms, wall ms) lists
         and a few facts about the final state.  timed=False: no cross-rank barrier (rank-0-only secondary measurements)."""
         H, K, n = w.horizon, w.steps, w.envs
-        env = QuadVecEnv(w.kind, n, device=dev, seed=0, substeps=w.substeps, layout=a.layout, use_UDM=True,
-                         auto_reset=ar, env_offset=w.env_offset, **{"helper" if w.workload == "step" else "helper_rollout": TRI[w.helper]},
+        env = QuadVecEnv(w.kind, n, device=dev, seed=0, substeps=w.substeps, layout=getattr(w, "layout", a.layout), use_UDM=True,
+                         auto_reset=ar, env_offset=w.env_offset, **{"helper" if w.workload in ("step", "touch") else "helper_rollout": TRI[w.helper]},
                          **({"obs_rows": True} if w.workload == "rollout_actor" else {}))
 
         def fresh():  # the timed steps start from reset-distribution states (configs[1])
@@ -347,9 +372,12 @@ def main():
 
         fresh()
         gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
-        if w.workload == "step":
+        if w.workload in ("step", "touch"):
             acts = [torch.rand(n, env.action_dim, device=dev, generator=gen) * 2 - 1 for _ in range(w.slabs)]
-            launch = lambda i: env.step(acts[i % len(acts)])                      # noqa: E731
+            if w.workload == "step":
+                launch = lambda i: env.step(acts[i % len(acts)])                  # noqa: E731
+            else:   # the do-nothing kernel over the same buffers and action slabs: what moving the step's bytes costs on this box
+                launch = lambda i: env.touch(acts[i % len(acts)])                 # noqa: E731
             last_done = lambda: env._done                                          # noqa: E731
         elif w.workload == "rollout":   # [H, N, A] action slabs (4 x 105 MB at H = 100: streamed from HBM) and preallocated outputs
             acts = [torch.rand(H, n, env.action_dim, device=dev, generator=gen) * 2 - 1 for _ in range(min(w.slabs, 4))]
@@ -435,23 +463,16 @@ def main():
                 break
         finite = bool(torch.isfinite(env.get_current_state()).all())
         done_rate = float(last_done().float().mean())
-        tuned = env.autotune_report   # None unless the grid lies near a threshold of the launch rule (then: cached or timed choice)
+        tuned = env.autotune_report   # None unless a recorded choice of the launch cache applies (grids near a threshold of the launch rule)
         launch_rule = "compiled rule" if tuned is None else f"{tuned.get('picked')} ({tuned.get('source', 'timed')})"
-        kinfo = env.kernel_info(H)
-        if w.workload == "rollout_actor" and ar and w.helper != "off":
-            # (qr_step_kernel_info describes qr_step / qr_rollout.)  qr_rollout_actor with in-launch resets runs its helper-wave
-            # instantiation — on grids beyond the rollout threshold in chunks of that many tiles, one launch after the other
-            thr = _lib.launch_thresholds()["rollout"]
-            if w.helper == "on" or thr > 0:
-                tiles = kinfo[1]
-                launches = 1 if (thr <= 0 or tiles <= thr) else -(-tiles // thr)
-                kinfo = (kinfo[0], tiles if launches == 1 else thr, 128)
-                launch_rule += "" if launches == 1 else f"; {launches} launches of <= {thr} tiles per horizon"
-        return dev_ms, wall_ms, finite, done_rate, kinfo + (launch_rule,), n_lead * H, copies
+        plan = env.launch_plan(H, actor=(w.actor if w.workload == "rollout_actor" else None))   # the launcher's own decision, this env's substeps
+        if w.workload == "touch":
+            plan = dict(plan, name=f"qr::touch_kernel<{_lib.KIND_ID[w.kind]},...>", block=64, launches=1)
+        return dev_ms, wall_ms, finite, done_rate, (plan, launch_rule), n_lead * H, copies
 
     from types import SimpleNamespace as NS
     head = NS(kind=a.kind, envs=N, env_offset=env_offset, substeps=a.substeps, workload=a.workload, horizon=a.horizon, steps=a.steps,
-              slabs=a.action_batches, helper=a.helper, actor=a.actor)
+              slabs=a.action_batches, helper=a.helper, actor=a.actor, layout=a.layout)
     dev_ms, wall_ms, finite, done_rate, kinfo, n_lead, copies = run(head, auto_reset, True)
     reps = len(dev_ms)
     med_dev, med_wall = float(np.median(dev_ms)), float(np.median(wall_ms))
@@ -470,102 +491,90 @@ def main():
         ms_per_step = med_dev / a.steps              # THE clock of this line: HIP events around the K steps
         launch_us = ms_per_step * 1e3 * H            # duration of one launch (= H env-steps)
         wall_ms_per_step = med_wall / (a.steps * copies + n_lead)
-        algo = algo_bytes_per_env_step(a.kind, a.workload, H)
-        # bytes this layout really moves per env-step: 12-word state r/w (x, v, smallest-three quaternion, W), action, [integ r/w, obs rows],
-        # reward, done, params
-        state_b = {"mixed": 6 * 4 + 6 * 8, "f64": 12 * 8, "f32": 12 * 4}[a.layout] * 2
-        layout = state_b + {"quad": 16 + 4 + 1 + 24, "coupled": 16 + 64 + 92 + 4 + 1 + 24,
-                            "decoupled": 20 + 64 + 72 + 8 + 2 + 24}[a.kind]
+        algo = algo_bytes_per_env_step(a.kind, "step" if a.workload == "touch" else a.workload, H)
         achieved = algo * N * H / (launch_us * 1e-6) / 1e9
-        kname, grid, block, launch_rule = kinfo
+        plan, launch_rule = kinfo
         traffic = committed_traffic(a.kind, N, a.layout, auto_reset, a.substeps, a.workload, H)
-        wl = {"step": "", "rollout": f"; fused rollout, {H} env-steps per qr_rollout launch (state in registers)",
-              "rollout_actor": f"; PPO collection, {H} env-steps per qr_rollout_actor launch with the 23->16->16->4 actor (MFMA) and its "
-                               "action sampling inside the step kernel"}[a.workload]
+        # the committed profile's clock for this configuration: rocprofv3 --kernel-trace for kernels it does not inflate (>= ~6 us),
+        # for the shorter ones the in-kernel real-time-clock span + launch gap of the QR_SPAN build (tools/span_timeline.py), both
+        # in profiles/rNN_traffic.json (`profile_period_us`)
+        prof_us = (traffic or {}).get("profile_period_us") or (traffic or {}).get("rocprofv3_kernel_mean_us")
+        what = {"step": "one qr_step launch per env-step", "touch": "qr_touch: the step's bytes, no arithmetic",
+                "rollout": f"fused rollout, {H} env-steps per qr_rollout launch",
+                "rollout_actor": f"PPO collection, {H} env-steps per qr_rollout_actor launch, actor inside"}[a.workload]
+        cfg = {"workload": (f"configs[1]: Quad-v0 {N} envs/GPU, random actions, fp32 I/O, "
+                            + ("in-launch resets" if auto_reset else "free run") if a.kind == "quad" and not a.config else
+                            (PRESETS[a.config]["name"] if a.config else f"{a.kind} wrapper, {N} envs/GPU"))[:118],
+               "launch": what, "workload_kind": a.workload, "env_steps_per_launch": H,
+               "baseline_config": (PRESETS[a.config]["name"][:118] if a.config else None), "kind": a.kind, "envs_per_gpu": N, "global_envs": G,
+               "substeps": a.substeps, "state_layout": a.layout, "io_dtype": "f32", "auto_reset": auto_reset,
+               "done_rate_last_step": round(done_rate, 5), "launch_mode": a.mode,
+               "parallelism": f"env-shard x{n_gpus}, no collective" + (f", strong scaling of {G} envs" if a.scaling == "strong" else ""),
+               "state_finite": finite, "n_ranks_rccl": n_ranks_rccl, "reps": reps, "lead_in_steps": n_lead,
+               "wall_ms_per_step": round(wall_ms_per_step, 7)}
         out = {
             "metric": "quadrotor env-steps/sec at 65 536 envs; 1/2/4/8 MI355X + CPU ref",
             "value": G / (ms_per_step * 1e-3), "unit": "env-steps/s", "n_gpus": n_gpus, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": {"mixed": "mixed f32/f64", "f64": "f64", "f32": "f32"}[a.layout], "data": "synthetic",
-            "config": {"workload": (f"BASELINE.json configs[1]: Quad-v0 batched {N} envs per GPU, random actions, fp32 I/O, "
-                                    + ("terminated envs re-sampled in the launch" if auto_reset else "free run from one reset")
-                                    if a.kind == "quad" else f"{a.kind} wrapper, {N} envs per GPU, random actions, fp32 I/O") + wl,
-                       "workload_kind": a.workload, "env_steps_per_launch": H,
-                       "baseline_config": (PRESETS[a.config]["name"] if a.config else None),
-                       "kind": a.kind, "envs_per_gpu": N, "global_envs": G, "substeps": a.substeps,
-                       "integrator": "RK4 per substep on (v, unit quaternion, W): W and the q accumulation in float64, stage quaternions in "
-                                     "float32; substeps x ceil(max|W|/16 rad/s) per wavefront", "state_layout": a.layout, "io_dtype": "f32",
-                       "auto_reset": auto_reset, "done_rate_last_step": done_rate, "launch_mode": a.mode,
-                       "parallelism": f"env-shard x{n_gpus}, no collective" + (f" (strong scaling: {G} envs cut at multiples of 64; rank 0 holds {N})"
-                                                                                       if a.scaling == "strong" else ""), "state_finite": finite,
-                       "n_ranks_rccl": n_ranks_rccl},
-            "timing": {"clock": "HIP events on the launch stream around the K steps of one repetition; median over repetitions, max over ranks",
-                       "repetitions": reps, "timed_ms_total": float(sum(dev_ms)) * copies, "lead_in_steps_untimed": n_lead,
-                       "copies_of_the_K_steps_per_timed_graph": copies,
-                       "ms_per_rep_min_median_max": [float(min(dev_ms)), float(np.median(dev_ms)), float(max(dev_ms))],
-                       "wall_ms_per_step": wall_ms_per_step,
-                       "wall_note": "host clock around lead-in + K steps incl. graph submission and synchronize, / (K + lead-in)"},
+            "config": cfg,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "frac_of_copy_ceiling": achieved / HBM_COPY_GBS,
-                         "copy_ceiling": HBM_COPY_GBS, "traffic": (traffic or {}).get("bytes_per_launch"),
-                         "traffic_source": (traffic or {}).get("source"),
-                         "kernel": kname, "grid": grid, "block": block, "launch_rule": launch_rule, "avg_launch_us": launch_us,
-                         # the committed rocprofv3 --kernel-trace figure of the same command, for comparison: the tool costs
-                         # ~4.8 us per dispatch by itself (profiles/r03/rocprof_dispatch_floor.txt) and inflates kernels shorter
-                         # than ~6 us; both clocks are listed, `achieved` uses this run's HIP events
-                         "committed_profile": {k: (traffic or {}).get(k) for k in ("rocprofv3_kernel_mean_us", "rocprofv3_kernel_median_us",
-                                                                                     "bench_py_us_per_step_under_rocprofv3", "valu")},
-                         # the SAME algorithmic bytes on the committed profile's clock (rocprofv3 --kernel-trace mean of this configuration
-                         # under profiles/): what follows from profiles/ alone; null when no profile of this configuration is committed
-                         "frac_profile_clock": (algo * N * H / (traffic["rocprofv3_kernel_mean_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
-                                                if traffic and traffic.get("rocprofv3_kernel_mean_us") else None),
-                         "algorithmic_bytes_per_env_step": algo, "layout_bytes_per_env_step": layout,
-                         "achieved_layout_GBs": layout * N / (launch_us * 1e-6) / 1e9,
-                         "note": "algorithmic bytes = SURVEY.md 8(d) (165 B + 24 B per-env params for Quad-v0); "
-                                 "avg_launch_us = launch-to-launch time of back-to-back launches (an empty launch: 1.6 us; "
-                                 "x env_steps_per_launch for the rollout workloads, whose algorithmic bytes are the per-step rows plus 1/H of "
-                                 "the working set); block 128 = a 64-lane stepping wavefront plus a 64-lane helper wavefront per 64-env "
-                                 "tile (reset pool, Quad-v0 reward, observation rows); DESIGN.md 3.5, 5"},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": (traffic or {}).get("bytes_per_launch"),
+                         "kernel": plan["name"], "grid": plan["grid"], "block": plan["block"], "launches_per_step": plan["launches"],
+                         "launch_rule": launch_rule, "avg_launch_us": launch_us,
+                         "algorithmic_bytes_per_env_step": algo,
+                         "frac_of_copy_ceiling": round(achieved / HBM_COPY_GBS, 4), "copy_ceiling": HBM_COPY_GBS,
+                         # the same bytes moved by a kernel that computes nothing (qr_touch), measured below on this box: the
+                         # ceiling of ANY one-launch-per-step design at this size; null when extras are off
+                         "noop_kernel_us": None, "frac_of_noop_kernel": None,
+                         # the SAME algorithmic bytes on the committed profile's clock (profiles/): null without a committed profile
+                         "profile_period_us": prof_us,
+                         "frac_profile_clock": (round(algo * N * H / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if prof_us else None)},
         }
         if n_gpus == 1 and a.extras and a.workload == "step":
             t_extra = time.perf_counter()
+
+            def us_per_launch(w, ar=True):
+                dms = run(w, ar, False)[0]
+                torch.cuda.empty_cache()
+                return float(np.median(dms)) * 1e3 / w.steps * w.horizon
+
+            def touch_of(w):   # the do-nothing kernel over the same configuration
+                return NS(**{**vars(w), "workload": "touch", "horizon": 1, "steps": 300})
+
+            noop = us_per_launch(touch_of(head))
+            out["roofline"]["noop_kernel_us"] = round(noop, 4)
+            out["roofline"]["frac_of_noop_kernel"] = round(noop / launch_us, 4)
             # the other reset mode of the headline workload (no reset inside step = the reference's own semantics: the population
             # flies on beyond termination and the rate-adaptive kernel is the one launched)
-            d2 = run(head, not auto_reset, False)[0]
-            us2 = float(np.median(d2)) * 1e3 / a.steps
-            out["config"]["other_reset_mode"] = {
-                "mode": ("free run from one reset: auto_reset=False, reset_on_done=False (rate-adaptive kernel), the K steps that follow a reset"
-                         if auto_reset else "auto_reset=True: terminated envs re-sampled in the launch"),
-                "auto_reset": not auto_reset, "env_steps_per_s": N / (us2 * 1e-6), "avg_launch_us": us2}
-            # every other BASELINE.json config (per-GPU and one-GPU shapes), the fused rollout and the PPO collection loop, each
-            # through the SAME harness as the headline: hipGraph, lead-in, >= 20 repetitions, HIP events, median
-            rows = []
-            for spec in BASELINE_CONFIGS + OTHER_FUSED:
+            cfg["free_run_us" if auto_reset else "auto_reset_us"] = round(us_per_launch(head, not auto_reset), 4)
+            # every other BASELINE.json config (per-GPU and one-GPU shapes), the fused launches and the float64 layout
+            skipped = []
+            for spec in BASELINE_CONFIGS + OTHER_ROWS:
+                tag = spec["tag"]
                 if a.extras < 2 and time.perf_counter() - t_extra > a.extras_budget:
-                    rows.append({"name": spec["name"], "skipped": f"--extras-budget {a.extras_budget:g} s spent"})
+                    skipped.append(tag)
                     continue
                 w = NS(kind=spec["kind"], envs=spec["envs"], env_offset=0, substeps=spec["substeps"], workload=spec["workload"],
-                       horizon=spec["horizon"], steps=spec["steps"], slabs=spec["slabs"], helper="auto", actor="ppo")
-                t_row = time.perf_counter()
-                dms, _, fin, drate, kinf, _, _ = run(w, True, False)
-                us_step = float(np.median(dms)) * 1e3 / w.steps          # per env-step of the whole batch
+                       horizon=spec["horizon"], steps=spec["steps"], slabs=spec["slabs"], helper="auto", actor="ppo",
+                       layout=spec.get("layout", a.layout))
+                us = us_per_launch(w)
                 ab = algo_bytes_per_env_step(w.kind, w.workload, w.horizon)
-                gbs = ab * w.envs / (us_step * 1e-6) / 1e9
-                rows.append({"name": spec["name"], "kind": w.kind, "envs": w.envs, "substeps": w.substeps, "workload": w.workload,
-                             "env_steps_per_launch": w.horizon, "us_per_launch": us_step * w.horizon, "us_per_env_step": us_step,
-                             "env_steps_per_s": w.envs / (us_step * 1e-6), "algorithmic_bytes": ab * w.envs * w.horizon,
-                             "algorithmic_bytes_per_env_step": ab, "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS,
-                             "frac_of_copy_ceiling": gbs / HBM_COPY_GBS, "grid": kinf[1], "block": kinf[2], "launch_rule": kinf[3], "repetitions": len(dms),
-                             "state_finite": fin, "done_rate_last_step": drate, "measure_s": time.perf_counter() - t_row})
-                torch.cuda.empty_cache()
-            out["config"]["baseline_configs"] = rows[:len(BASELINE_CONFIGS)]
-            out["config"]["other_fused_launches"] = rows[len(BASELINE_CONFIGS):]
-            out["config"]["baseline_configs_note"] = ("same harness as the headline (hipGraph of the K env-steps, untimed lead-in, >= 20 repetitions and >= 50 ms "
-                                                      "of timed work, HIP events, median); auto_reset=True, UDM parameters, 16-64 action slabs cycled")
-            out["config"]["extras_s"] = time.perf_counter() - t_extra
+                frac = ab * w.envs * w.horizon / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                if w.workload == "step":
+                    cfg[f"{tag}_us"], cfg[f"{tag}_frac"] = round(us, 3), round(frac, 4)
+                    if "layout" not in spec:
+                        cfg[f"{tag}_noop_us"] = round(us_per_launch(touch_of(w)), 3)
+                else:
+                    cfg[f"{tag}_us_per_env_step"], cfg[f"{tag}_frac"] = round(us / w.horizon, 4), round(frac, 4)
+            if skipped:
+                cfg["rows_skipped"] = ",".join(skipped)[:118]
+            cfg["extras_s"] = round(time.perf_counter() - t_extra, 2)
         if n_gpus == 1 and a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(a.kind, a.cpu_seconds)
-        print(json.dumps(out))
+        line = json.dumps(out)
+        assert len(line) <= MAX_LINE_BYTES, f"bench line is {len(line)} bytes (> {MAX_LINE_BYTES}): the driver's record would lose its tail"
+        print(line)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

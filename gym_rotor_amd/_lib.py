@@ -19,7 +19,7 @@ FLAG_AUTO_RESET, FLAG_EVAL_RESET, FLAG_NO_UDM = 1, 2, 4
 FLAG_FORCE_HELPER, FLAG_NO_HELPER = 8, 16   # launch-rule overrides of the one-step launch (speed only)
 FLAG_CALLER_RESETS = 32                     # the caller resets every done env before stepping it again (one-step launches)
 FLAG_FORCE_HELPER_ROLLOUT, FLAG_NO_HELPER_ROLLOUT = 64, 128   # the same overrides for qr_rollout / qr_rollout_actor
-ABI_VERSION = 13
+ABI_VERSION = 14
 GOAL_EXTERNAL, GOAL_MODE0, GOAL_MODE1, GOAL_MODE6, GOAL_MODE2, GOAL_MODE3, GOAL_MODE4, GOAL_MODE5 = 0, 1, 2, 3, 4, 5, 6, 7
 GOAL_ID = {None: 0, 0: 1, 1: 2, 6: 3, 2: 4, 3: 5, 4: 6, 5: 7}  # TrajectoryGenerator mode -> QR_GOAL_*
 LAYOUT_ID = {"mixed": 0, "f64": 1, "f32": 2}
@@ -30,7 +30,8 @@ ERRORS = {-1: "QR_E_NULL: a required pointer is NULL", -2: "QR_E_KIND: bad env k
 # every symbol include/quadrotor_hip.h declares
 SYMBOLS = ("qr_step", "qr_rollout", "qr_rollout_actor", "qr_error_obs", "qr_error_obs_format", "qr_reset", "qr_get_state", "qr_set_state", "qr_check_state",
            "qr_traj_start", "qr_get_desired", "qr_gae",
-           "qr_default_coeffs", "qr_abi_version", "qr_step_kernel_info", "qr_launch_thresholds")
+           "qr_default_coeffs", "qr_abi_version", "qr_step_kernel_info", "qr_launch_thresholds",
+           "qr_launch_plan", "qr_launch_stats", "qr_instance_table", "qr_touch")
 
 
 class QrCoeffs(C.Structure):
@@ -71,6 +72,12 @@ class QrPolicyRollout(C.Structure):
     _fields_ = [("actors", C.POINTER(QrActor)), ("obs0_in", C.c_void_p), ("obs1_in", C.c_void_p), ("noise", C.c_void_p),
                 ("noise_seed", C.c_uint64), ("step_base", C.c_uint64), ("max_action", C.c_float), ("deterministic", C.c_int32),
                 ("action_out", C.c_void_p), ("logprob_out", C.c_void_p)]
+
+
+class QrLaunchPlan(C.Structure):
+    _fields_ = [("grid", C.c_int32), ("block", C.c_int32), ("launches", C.c_int32),
+                ("traj", C.c_int32), ("adapt", C.c_int32), ("policy", C.c_int32), ("single", C.c_int32), ("help", C.c_int32), ("hrew", C.c_int32),
+                ("key", C.c_uint32), ("name", C.c_char * 96)]
 
 
 class QuadrotorLibError(RuntimeError):
@@ -125,6 +132,14 @@ def load():
                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.qr_step_kernel_info.restype = C.c_char_p
     lib.qr_step_kernel_info.argtypes = [P(QrEnv), C.c_int32, P(C.c_int32), P(C.c_int32)]
+    lib.qr_launch_plan.restype = C.c_int
+    lib.qr_launch_plan.argtypes = [P(QrEnv), C.c_int32, C.c_int32, C.c_int32, P(QrLaunchPlan)]
+    lib.qr_launch_stats.restype = C.c_int32
+    lib.qr_launch_stats.argtypes = [P(C.c_uint32), P(C.c_uint32), C.c_int32, C.c_int32]
+    lib.qr_instance_table.restype = C.c_int32
+    lib.qr_instance_table.argtypes = [P(C.c_uint32), C.c_int32]
+    lib.qr_touch.restype = C.c_int
+    lib.qr_touch.argtypes = [P(QrEnv), C.c_void_p, P(QrStepOut), C.c_void_p]
     lib.qr_launch_thresholds.restype = None
     lib.qr_launch_thresholds.argtypes = [P(C.c_int32), P(C.c_int32), P(C.c_int32)]
     if lib.qr_abi_version() != ABI_VERSION:
@@ -152,3 +167,32 @@ def launch_thresholds() -> dict:
     q, w, r = C.c_int32(), C.c_int32(), C.c_int32()
     load().qr_launch_thresholds(C.byref(q), C.byref(w), C.byref(r))
     return {"step_quad": q.value, "step_wrappers": w.value, "rollout": r.value}
+
+
+LAYOUT_NAME = {v: k for k, v in LAYOUT_ID.items()}
+KIND_NAME = {v: k for k, v in KIND_ID.items()}
+
+
+def describe_key(key: int) -> str:
+    """'layout/kind TRAJ=.. ADAPT=.. POLICY=.. SINGLE=.. HELP=.. HREW=..' of a qr_launch_stats / qr_instance_table key."""
+    b = key & 0xFF
+    return (f"{LAYOUT_NAME[key >> 16]}/{KIND_NAME[(key >> 8) & 0xFF]} TRAJ={b & 3} ADAPT={(b >> 2) & 1} POLICY={(b >> 3) & 3} "
+            f"SINGLE={(b >> 5) & 1} HELP={(b >> 6) & 1} HREW={(b >> 7) & 1}")
+
+
+def launch_stats(reset: bool = False) -> dict:
+    """{key: launches} of every step-kernel instantiation this process has launched (qr_launch_stats)."""
+    lib = load()
+    cap = 512
+    keys, counts = (C.c_uint32 * cap)(), (C.c_uint32 * cap)()
+    n = lib.qr_launch_stats(keys, counts, cap, int(reset))
+    return {int(keys[i]): int(counts[i]) for i in range(min(n, cap))}
+
+
+def instance_table() -> list:
+    """Keys of every step-kernel instantiation the library holds (qr_instance_table)."""
+    lib = load()
+    cap = 512
+    keys = (C.c_uint32 * cap)()
+    n = lib.qr_instance_table(keys, cap)
+    return [int(keys[i]) for i in range(min(n, cap))]

@@ -42,9 +42,11 @@
 //   this file      step / rollout kernel, auxiliary kernels, host launchers and the C-ABI
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "quadrotor_hip.h"
@@ -154,7 +156,9 @@ __device__ unsigned long long* g_hwid = nullptr;
 // 3328 tiles for one substep; launches with more substeps keep 2560.  The environment variable QR_HELPER_GRID and the
 // QR_FLAG_*_HELPER bits override it (see `tuning`).
 #define QR_HELPER_GRID 3328
-#define QR_HELPER_GRID_SUBSTEPS 2560
+#endif
+#ifndef QR_HELPER_GRID_SUBSTEPS
+#define QR_HELPER_GRID_SUBSTEPS 2560  // Quad-v0 with >= 2 substeps or the fused goal generator (its own guard: a build may set QR_HELPER_GRID alone)
 #endif
 #ifndef QR_HELPER_GRID_ROLLOUT
 #define QR_HELPER_GRID_ROLLOUT (QR_HELPER_GRID < 1024 ? QR_HELPER_GRID : 1024)  // qr_rollout / qr_rollout_actor (two waves per SIMD)
@@ -1273,6 +1277,76 @@ __global__ __launch_bounds__(64) void get_desired_kernel(const Args a) {
 }
 
 // ------------------------------------------------------------------------------------
+// qr_touch: the step's memory traffic and nothing else — the yardstick bench.py prices a step against (roofline.noop_kernel_us).
+// Per env exactly what qr_step moves: state in and out (same SoA accesses, same widths), parameters, action row, [goal],
+// [integrator words in and out], [observation rows out], reward and done rows out; no arithmetic beyond one sum that keeps
+// the loads alive.  One wavefront per 64-env tile, plain stores.  The state is written back as read (bit for bit); the
+// output rows hold zeros afterwards.
+// ------------------------------------------------------------------------------------
+template <int KIND, typename XV, typename QW>
+__global__ __launch_bounds__(64) void touch_kernel(const Args a) {
+  using KT = KindTraits<KIND>;
+  constexpr int A = KT::A, D0 = KT::D0, D1 = KT::D1, NAG = KT::NAG;
+  const unsigned first = blockIdx.x * 64u, lane = threadIdx.x;
+  const int rows = min((int)(a.n - (int64_t)first), 64);
+  const unsigned ll = min(lane, (unsigned)(rows - 1));
+  const bool active = (int)lane < rows;
+  const SoA<XV> pv(a.pos_vel, 6, a.ld);
+  const SoA<QW> ar(a.att_rate, 6, a.ld);
+  const SoA<float> prm(a.params, 6, a.ld), integ(a.integ, 8, a.ld), goal(a.goal, 12, a.ld);
+  XV x[6]; QW q[6]; float ig[8];
+  float s = 0.0f;
+#pragma unroll
+  for (int f = 0; f < 6; ++f) q[f] = ar.load(f, first, ll);
+#pragma unroll
+  for (int f = 0; f < 6; ++f) x[f] = pv.load(f, first, ll);
+#pragma unroll
+  for (int f = 0; f < 6; ++f) s += prm.load(f, first, ll);
+  const float* abase = a.action + (int64_t)first * A;
+  if constexpr (A == 4) {
+    const float4 v = reinterpret_cast<const float4*>(abase)[ll];
+    s += (v.x + v.y) + (v.z + v.w);
+  } else {
+#pragma unroll
+    for (int j = 0; j < A; ++j) s += abase[ll * A + j];
+  }
+  if constexpr (KIND != QR_KIND_QUAD) {
+#pragma unroll
+    for (int f = 0; f < 8; ++f) ig[f] = integ.load(f, first, ll);
+    if (a.goal) {
+#pragma unroll
+      for (int f = 0; f < 12; ++f) s += goal.load(f, first, ll);
+    }
+  }
+  s = s * 0.0f;  // (0 for finite inputs; not foldable without fast-math, so the loads stay)
+  if (active) {
+#pragma unroll
+    for (int f = 0; f < 6; ++f) ar.store(f, first, lane, q[f]);
+#pragma unroll
+    for (int f = 0; f < 6; ++f) pv.store(f, first, lane, x[f]);
+    if constexpr (KIND != QR_KIND_QUAD) {
+#pragma unroll
+      for (int f = 0; f < 8; ++f) integ.store(f, first, lane, ig[f]);
+    }
+    if constexpr (NAG == 1) a.reward[first + lane] = s;
+    else reinterpret_cast<float2*>(a.reward)[first + lane] = make_float2(s, s);
+    if constexpr (NAG == 1) a.done[first + lane] = 0;
+    else reinterpret_cast<uchar2*>(a.done)[first + lane] = make_uchar2(0, 0);
+  }
+  auto rows_out = [&](float* base, int D) {  // the tile's rows as they lie in memory: 16-byte stores, like lds_to_rows
+    if (base == nullptr) return;
+    float* g = base + (int64_t)first * D;
+    if (rows == 64 && (reinterpret_cast<uintptr_t>(g) & 15u) == 0) {
+      for (int idx = (int)lane; idx < 16 * D; idx += 64) reinterpret_cast<float4*>(g)[idx] = make_float4(s, s, s, s);
+    } else {
+      for (int idx = (int)lane; idx < rows * D; idx += 64) g[idx] = s;
+    }
+  };
+  rows_out(a.obs0, D0);
+  if constexpr (D1 > 0) rows_out(a.obs1, D1);
+}
+
+// ------------------------------------------------------------------------------------
 // GAE reverse scan (algos/ppo/ppo.py:134-146): one lane per (env, agent) column, T steps.
 // The recurrence is serial in t but the loads are not: they are issued kU steps ahead so that
 // a wave keeps kU rows in flight instead of paying one memory round-trip per step.
@@ -1467,124 +1541,124 @@ static inline unsigned rollout_chunk(const Args& a, int kind, int layout) {
   return limit;
 }
 
-template <int KIND, typename XV, typename QW>
-static void launch_kind(const Args& a, hipStream_t s, unsigned tiles_of_launch = 0) {
-  if constexpr (std::is_same<XV, float>::value && std::is_same<QW, double>::value) {
-    if (tiles_of_launch == 0) {
-      if (const unsigned chunk = rollout_chunk(a, KIND, QR_LAYOUT_MIXED)) {
-        const unsigned tiles = (unsigned)((a.n + 63) / 64);
-        for (unsigned base = 0; base < tiles; base += chunk) {
-          Args b = a;
-          b.tile_base = (int32_t)base;
-          launch_kind<KIND, XV, QW>(b, s, tiles - base < chunk ? tiles - base : chunk);
-        }
-        return;
-      }
-    }
-  }
-  const dim3 grid(tiles_of_launch ? tiles_of_launch : (unsigned)((a.n + 63) / 64));
+// ------------------------------------------------------------------------------------
+// Which instantiation of step_kernel a launch gets: ONE function decides (launch_kind dispatches on its result, qr_launch_plan
+// reports it), and ONE table (QR_INSTANCES) lists every instantiation that exists.
+// ------------------------------------------------------------------------------------
+struct Pick {
+  int traj; bool adapt; int policy; bool single, help, hrew;
+  // the bits qr_launch_stats counts under (with layout << 16 | kind << 8)
+  unsigned bits() const { return (unsigned)traj | (adapt ? 4u : 0u) | ((unsigned)policy << 3) | (single ? 32u : 0u) | (help ? 64u : 0u) | (hrew ? 128u : 0u); }
+};
+
+// `tiles_of_launch` != 0: one chunk of a chunked qr_rollout_actor (rollout_chunk).
+static inline Pick pick_instance(const Args& a, int kind, int layout, unsigned tiles_of_launch = 0) {
+  const bool mixed = layout == QR_LAYOUT_MIXED;  // the only layout with one-step (SINGLE) and helper-wave (HELP) instantiations
+  const unsigned tiles = tiles_of_launch ? tiles_of_launch : (unsigned)((a.n + 63) / 64);
   // Rate adaptivity can only trigger when an env starts a step with max|W_i| > w_adapt.  With
   // AUTO_RESET every env whose rate error left its bound was re-sampled at the end of the step
   // that took it there (done): Quad-v0 |W_i| < W_lim, Coupled |W_i - Wd_i| < W_lim, Decoupled
   // |W - Wd| < 2 W_lim (|ew12_i| < W_lim and |eW3| < W_lim).  For goal rates |Wd| <= W_lim / 2
   // and w_adapt >= 2.5 W_lim (the default 16 rad/s is) the plain kernel computes the same bits.
   const bool adapt = wants_adapt(a);
+  const bool traj = a.goal_mode != QR_GOAL_EXTERNAL, stateful = a.goal_mode >= QR_GOAL_MODE2;
+  if (kind != QR_KIND_QUAD && a.act_out != nullptr) {  // ---- qr_rollout_actor ----
+    const bool general = a.actor[0].ls_w || a.actor[0].squash != QR_ACTOR_TANH_MEAN ||
+                         (kind == QR_KIND_DECOUPLED && (a.actor[1].ls_w || a.actor[1].squash != QR_ACTOR_TANH_MEAN));
+    if (mixed) {
+      // Actors with in-launch resets and external goals, on grids where every wave is resident: a helper wave
+      // per tile (noise, reset pool, observation rows).  Measured, Coupled 65 536 envs, T = 32: 5.37 -> 4.51 us per step;
+      // with the fused goal generator the same split measured SLOWER (5.65 -> 6.25 us per step, tools/ppo_rollout_bench.py;
+      // both waves of a tile must be resident, which caps the kernel at 256 registers) and is not instantiated.
+      // Stage arithmetic: like every other launch, the plain (non-adaptive) instantiation whenever adaptivity provably cannot
+      // trigger (in-launch resets, w_adapt >= 2.5 W_lim) — the actor rollout then computes the same bits as qr_step on the
+      // actions it sampled, and the delta-form stages are off its path (65 536 envs: 3.70 -> 3.56 us per env-step,
+      // profiles/r05/ab_actor_plain.txt).  External goals only: with the fused generator the actor launches stay rate-adaptive.
+      // (the general form — SAC's log_std head and rule — with the same split; measured, profiles/r05/ab_sac_helper.txt,
+      //  65 536 envs, T = 32: Coupled 4.95 -> 4.38 us per env-step, Decoupled 5.54 -> 4.87, bit-identical)
+      if (QR_HELP_POLICY && !traj && (a.flags & QR_FLAG_AUTO_RESET) && helper_choice(a, tiles, tuning().helper_grid_rollout))
+        return {0, adapt, general ? 2 : 1, false, true, true};
+      if (!traj && !adapt) return {0, false, general ? 2 : 1, false, false, true};
+    }
+    if (stateful) return {2, true, 2, false, false, true};  // stateful goal modes: the general actor form
+    return {traj ? 1 : 0, true, general ? 2 : 1, false, false, true};
+  }
+  const bool help = mixed && wants_helper(a, kind, QR_LAYOUT_MIXED, tiles_of_launch);
+  if (mixed && a.n_steps == 1) {  // ---- qr_step in the default layout: the instantiations without the loop over env-steps ----
+    if (stateful) return {2, adapt, 0, true, false, true};  // take-off, landing, stay, circle: their own instantiations
+    if (traj) {
+      if (adapt) return {1, true, 0, true, false, true};
+      return {1, false, 0, true, wants_helper_traj(a, kind), true};  // (fused goal generator + helper wave: one-step launches only)
+    }
+    if (adapt) return {0, true, 0, true, false, true};
+    if (help) {
+      // (Quad-v0, one substep, more than QR_HELP_REWARD_TILES tiles: the reward stays on the stepping wave — measured with the
+      //  product's other choices in place, profiles/r05/ab_step_prio.txt: 98 304 envs 5.12 -> 4.92 us, 163 840 envs 7.31 -> 6.57;
+      //  identical bits.  The wrappers, one substep, more than QR_HELP_ROWS_TILES tiles: the helper only samples the pool, the
+      //  rows go out with the stepping wave — 114 688 envs Coupled 8.14 -> 6.98 us, Decoupled 8.21 -> 6.97; 131 072: 9.07 -> 8.61 /
+      //  9.11 -> 8.69; 98 304 envs and below are better with the helper's rows; profiles/r05/ab_step_prio.txt)
+      const unsigned lim = kind == QR_KIND_QUAD ? (unsigned)QR_HELP_REWARD_TILES : (unsigned)QR_HELP_ROWS_TILES;
+      return {0, false, 0, true, true, !(a.substeps == 1 && tiles > lim)};
+    }
+    return {0, false, 0, true, false, true};
+  }
+  // ---- qr_rollout (any layout) and qr_step of the uniform layouts ----
+  if (stateful) return {2, adapt, 0, false, false, true};
+  if (traj) return {1, adapt, 0, false, false, true};
+  if (adapt) return {0, true, 0, false, false, true};
+  return {0, false, 0, false, help, true};  // (rollouts in the default layout: a helper wave per tile for grids it pays on)
+}
+
+// Every instantiation: (TRAJ, ADAPT, POLICY, SINGLE, HELP, HREW).  POLICY != 0 exists for the wrappers only; SINGLE, HELP and the
+// non-adaptive actor rollouts for the default layout only (inst_exists) — 16 Quad-v0 + 2 x 27 wrapper kernels in the default
+// layout, 6 + 2 x 11 in each uniform one.  tests/test_gpu_instances.py walks this table and checks that the suite launches all of it.
+#define QR_INSTANCES(X)                                                                                                  \
+  X(0, 0, 0, 0, 0, 1) X(0, 1, 0, 0, 0, 1) X(1, 0, 0, 0, 0, 1) X(1, 1, 0, 0, 0, 1) X(2, 0, 0, 0, 0, 1) X(2, 1, 0, 0, 0, 1) \
+  X(0, 1, 1, 0, 0, 1) X(0, 1, 2, 0, 0, 1) X(1, 1, 1, 0, 0, 1) X(1, 1, 2, 0, 0, 1) X(2, 1, 2, 0, 0, 1)                     \
+  X(0, 0, 1, 0, 0, 1) X(0, 0, 2, 0, 0, 1) X(0, 0, 1, 0, 1, 1) X(0, 1, 1, 0, 1, 1) X(0, 0, 2, 0, 1, 1) X(0, 1, 2, 0, 1, 1) \
+  X(0, 0, 0, 0, 1, 1)                                                                                                    \
+  X(0, 0, 0, 1, 0, 1) X(0, 1, 0, 1, 0, 1) X(1, 0, 0, 1, 0, 1) X(1, 1, 0, 1, 0, 1) X(2, 0, 0, 1, 0, 1) X(2, 1, 0, 1, 0, 1) \
+  X(1, 0, 0, 1, 1, 1) X(0, 0, 0, 1, 1, 1) X(0, 0, 0, 1, 1, 0)
+static constexpr bool inst_exists(int kind, bool mixed, int tr, int ad, int po, int si, int he, int hr) {
+  (void)tr; (void)hr;
+  return !(po != 0 && kind == QR_KIND_QUAD) && (mixed || !(si || he || (po != 0 && !ad)));
+}
+
+// Host-side launch counters, one per (layout, kind, instantiation): which kernels a process really ran (qr_launch_stats).
+static std::atomic<uint32_t> g_launches[3][3][256];
+
+template <int KIND, typename XV, typename QW>
+static int launch_kind(const Args& a, hipStream_t s, unsigned tiles_of_launch = 0) {
+  constexpr bool kMixed = std::is_same<XV, float>::value && std::is_same<QW, double>::value;
+  constexpr int kLayout = kMixed ? QR_LAYOUT_MIXED : (std::is_same<XV, double>::value ? QR_LAYOUT_F64 : QR_LAYOUT_F32);
+  if constexpr (kMixed) {
+    if (tiles_of_launch == 0) {
+      if (const unsigned chunk = rollout_chunk(a, KIND, QR_LAYOUT_MIXED)) {
+        const unsigned tiles = (unsigned)((a.n + 63) / 64);
+        for (unsigned base = 0; base < tiles; base += chunk) {
+          Args b = a;
+          b.tile_base = (int32_t)base;
+          if (int rc = launch_kind<KIND, XV, QW>(b, s, tiles - base < chunk ? tiles - base : chunk)) return rc;
+        }
+        return 0;
+      }
+    }
+  }
+  const dim3 grid(tiles_of_launch ? tiles_of_launch : (unsigned)((a.n + 63) / 64));
+  const Pick p = pick_instance(a, KIND, kLayout, tiles_of_launch);
 #define QR_STEP_ARGS a.pos_vel, a.att_rate, a.action, a.params, a.integ, ((a.flags & QR_FLAG_AUTO_RESET) ? a.reset_count : nullptr), (int32_t)a.n, (int32_t)a.ld, a
-  if constexpr (KIND != QR_KIND_QUAD) {
-    if (a.act_out != nullptr) {  // qr_rollout_actor
-      const bool general = a.actor[0].ls_w || a.actor[0].squash != QR_ACTOR_TANH_MEAN ||
-                           (KIND == QR_KIND_DECOUPLED && (a.actor[1].ls_w || a.actor[1].squash != QR_ACTOR_TANH_MEAN));
-      const bool traj = a.goal_mode != QR_GOAL_EXTERNAL;
-      if constexpr (std::is_same<XV, float>::value && std::is_same<QW, double>::value) {
-        // Actors with in-launch resets and external goals, on grids where every wave is resident: a helper wave
-        // per tile (noise, reset pool, observation rows).  Measured, Coupled 65 536 envs, T = 32: 5.37 -> 4.51 us per step;
-        // with the fused goal generator the same split measured SLOWER (5.65 -> 6.25 us per step, tools/ppo_rollout_bench.py;
-        // both waves of a tile must be resident, which caps the kernel at 256 registers) and is not instantiated.
-        // Stage arithmetic: like every other launch, the plain (non-adaptive) instantiation whenever adaptivity provably cannot
-        // trigger (in-launch resets, w_adapt >= 2.5 W_lim) — the actor rollout then computes the same bits as qr_step on the
-        // actions it sampled, and the delta-form stages are off its path (65 536 envs: 3.70 -> 3.56 us per env-step,
-        // profiles/r05/ab_actor_plain.txt).  External goals only: with the fused generator the actor launches stay rate-adaptive.
-        if (QR_HELP_POLICY && !traj && (a.flags & QR_FLAG_AUTO_RESET) && helper_choice(a, grid.x, tuning().helper_grid_rollout)) {
-          // (the general form — SAC's log_std head and rule — with the same split; measured, profiles/r05/ab_sac_helper.txt,
-          //  65 536 envs, T = 32: Coupled 4.95 -> 4.38 us per env-step, Decoupled 5.54 -> 4.87, bit-identical)
-          if (!general && !adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 1, false, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
-          else if (!general) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 1, false, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
-          else if (!adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 2, false, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
-          else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 2, false, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
-          return;
-        }
-        if (!traj && !adapt) {
-          if (general) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 2>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-          else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 1>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-          return;
-        }
-      }
-      if (a.goal_mode >= QR_GOAL_MODE2) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, 2, true, 2>), grid, dim3(64), 0, s, QR_STEP_ARGS);  // stateful goal modes: the general actor form
-      else if (traj && general) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true, 2>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-      else if (traj) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true, 1>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-      else if (general) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 2>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-      else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 1>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-      return;
-    }
+#define QR_X(TR, AD, PO, SI, HE, HR)                                                                                              \
+  if constexpr (inst_exists(KIND, kMixed, TR, AD, PO, SI, HE, HR)) {                                                              \
+    if (p.traj == TR && p.adapt == (bool)AD && p.policy == PO && p.single == (bool)SI && p.help == (bool)HE && p.hrew == (bool)HR) { \
+      g_launches[kLayout][KIND][p.bits()].fetch_add(1u, std::memory_order_relaxed);                                              \
+      hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, TR, (bool)AD, PO, (bool)SI, (bool)HE, (bool)HR>), grid, dim3(HE ? 128 : 64), 0, s, QR_STEP_ARGS); \
+      return 0;                                                                                                                   \
+    }                                                                                                                             \
   }
-  // qr_step in the default layout: the instantiation without the loop over env-steps
-  constexpr bool kHasSingle = std::is_same<XV, float>::value && std::is_same<QW, double>::value;
-  const bool help = kHasSingle && wants_helper(a, KIND, QR_LAYOUT_MIXED, tiles_of_launch);
-  const bool help_traj = kHasSingle && a.n_steps == 1 && wants_helper_traj(a, KIND);  // (fused goal generator: one-step launches only)
-  if constexpr (kHasSingle) {
-    if (a.n_steps == 1) {
-      if (a.goal_mode >= QR_GOAL_MODE2) {  // the generator's stateful modes (take-off, landing, stay, circle): their own instantiations
-        if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, 2, true, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-        else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, 2, false, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-      } else if (a.goal_mode != QR_GOAL_EXTERNAL) {
-        if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-        else if (help_traj) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, false, 0, true, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
-        else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, false, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-      } else if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-      else if (help)
-      {
-        // (Quad-v0, one substep, more than QR_HELP_REWARD_TILES tiles: the reward stays on the stepping wave — measured with the
-        //  product's other choices in place, profiles/r05/ab_step_prio.txt: 98 304 envs 5.12 -> 4.92 us, 163 840 envs 7.31 -> 6.57;
-        //  identical bits)
-        bool on_stepping_wave = false;
-        // (the wrappers, one substep, more than QR_HELP_ROWS_TILES tiles: the helper only samples the pool, the rows go out with the
-        //  stepping wave — 114 688 envs Coupled 8.14 -> 6.98 us, Decoupled 8.21 -> 6.97; 131 072: 9.07 -> 8.61 / 9.11 -> 8.69;
-        //  98 304 envs and below are better with the helper's rows; profiles/r05/ab_step_prio.txt)
-        if constexpr (KIND != QR_KIND_QUAD) {
-          if (a.substeps == 1 && grid.x > (unsigned)QR_HELP_ROWS_TILES) {
-            on_stepping_wave = true;
-            hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 0, true, true, false>), grid, dim3(128), 0, s, QR_STEP_ARGS);
-          }
-        }
-        if constexpr (KIND == QR_KIND_QUAD) {
-          if (a.substeps == 1 && grid.x > (unsigned)QR_HELP_REWARD_TILES) {
-            on_stepping_wave = true;
-            hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 0, true, true, false>), grid, dim3(128), 0, s, QR_STEP_ARGS);
-          }
-        }
-        if (!on_stepping_wave) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 0, true, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
-      }
-      else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 0, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-      return;
-    }
-  }
-  if (a.goal_mode >= QR_GOAL_MODE2) {
-    if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, 2, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-    else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, 2, false>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-  } else if (a.goal_mode != QR_GOAL_EXTERNAL) {
-    if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-    else hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, true, false>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-  } else if (adapt) hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, true>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-  else {
-    if constexpr (kHasSingle) {  // rollouts in the default layout: a helper wave per tile for grids it pays on
-      if (help) {
-        hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false, 0, false, true>), grid, dim3(128), 0, s, QR_STEP_ARGS);
-        return;
-      }
-    }
-    hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, false, false>), grid, dim3(64), 0, s, QR_STEP_ARGS);
-  }
+  QR_INSTANCES(QR_X)
+#undef QR_X
 #undef QR_STEP_ARGS
+  return QR_E_KIND;  // (unreachable: pick_instance only returns rows of the table)
 }
 
 // QR_ONLY_KIND / QR_ONLY_LAYOUT: experiment builds that instantiate one env kind / one layout only
@@ -1594,15 +1668,16 @@ static int launch_step(const Args& a, int kind, hipStream_t s) {
   if (a.n == 0) return 0;
 #ifdef QR_ONLY_KIND
   if (kind != QR_ONLY_KIND) return QR_E_KIND;
-  launch_kind<QR_ONLY_KIND, XV, QW>(a, s);
+  int rc = launch_kind<QR_ONLY_KIND, XV, QW>(a, s);
 #else
+  int rc = 0;
   switch (kind) {
-    case QR_KIND_QUAD: launch_kind<QR_KIND_QUAD, XV, QW>(a, s); break;
-    case QR_KIND_COUPLED: launch_kind<QR_KIND_COUPLED, XV, QW>(a, s); break;
-    default: launch_kind<QR_KIND_DECOUPLED, XV, QW>(a, s); break;
+    case QR_KIND_QUAD: rc = launch_kind<QR_KIND_QUAD, XV, QW>(a, s); break;
+    case QR_KIND_COUPLED: rc = launch_kind<QR_KIND_COUPLED, XV, QW>(a, s); break;
+    default: rc = launch_kind<QR_KIND_DECOUPLED, XV, QW>(a, s); break;
   }
 #endif
-  return (int)hipGetLastError();
+  return rc ? rc : (int)hipGetLastError();
 }
 
 #ifdef QR_ONLY_LAYOUT
@@ -1620,6 +1695,16 @@ template <typename XV, typename QW>
 static void launch_error_obs(const Args& a, int kind, unsigned grid, hipStream_t s) {
   if (kind == QR_KIND_COUPLED) hipLaunchKernelGGL((error_obs_kernel<QR_KIND_COUPLED, XV, QW>), dim3(grid), dim3(64), 0, s, a);
   else hipLaunchKernelGGL((error_obs_kernel<QR_KIND_DECOUPLED, XV, QW>), dim3(grid), dim3(64), 0, s, a);
+}
+template <typename XV, typename QW>
+static void launch_touch(const Args& a, int kind, unsigned grid, hipStream_t s) {
+#ifdef QR_ONLY_KIND
+  hipLaunchKernelGGL((touch_kernel<QR_ONLY_KIND, XV, QW>), dim3(grid), dim3(64), 0, s, a);
+  return;
+#endif
+  if (kind == QR_KIND_QUAD) hipLaunchKernelGGL((touch_kernel<QR_KIND_QUAD, XV, QW>), dim3(grid), dim3(64), 0, s, a);
+  else if (kind == QR_KIND_COUPLED) hipLaunchKernelGGL((touch_kernel<QR_KIND_COUPLED, XV, QW>), dim3(grid), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL((touch_kernel<QR_KIND_DECOUPLED, XV, QW>), dim3(grid), dim3(64), 0, s, a);
 }
 template <typename XV, typename QW>
 static void launch_reset(const Args& a, unsigned grid, hipStream_t s) {
@@ -1851,20 +1936,91 @@ void qr_launch_thresholds(int32_t* step_quad, int32_t* step_wrappers, int32_t* r
   if (rollout) *rollout = (int32_t)tn.helper_grid_rollout;
 }
 
-const char* qr_step_kernel_info(const QrEnv* env, int32_t n_steps, int32_t* grid, int32_t* block) {
+int qr_launch_plan(const QrEnv* env, int32_t n_steps, int32_t substeps, int32_t actor, QrLaunchPlan* plan) {
+  if (!plan) return QR_E_NULL;
+  memset(plan, 0, sizeof(*plan));
   qr::Args a{};
-  if (qr::fill_env(a, env) != 0) return "";
-  a.n_steps = n_steps;
-  if (grid) *grid = (int32_t)((a.n + 63) / 64);
-  const bool helper = qr::wants_helper(a, env->kind, env->layout) ||
-                      (env->layout == QR_LAYOUT_MIXED && n_steps == 1 && qr::wants_helper_traj(a, env->kind));
-  if (block) *block = helper ? 128 : 64;
+  if (int rc = qr::fill_env(a, env)) return rc;
+  if (n_steps < 1 || substeps < 1 || actor < 0 || actor > 2) return QR_E_SIZE;
+  if (actor && env->kind == QR_KIND_QUAD) return QR_E_KIND;
+  a.n_steps = n_steps; a.substeps = substeps;
+  if (actor) {  // qr_rollout_actor: what the decision reads of the policy block
+    static float dummy;
+    a.act_out = &dummy;
+    a.actor[0].squash = a.actor[1].squash = actor == 2 ? QR_ACTOR_TANH_SAMPLE : QR_ACTOR_TANH_MEAN;
+  }
+  const unsigned tiles = (unsigned)((a.n + 63) / 64);
+  const unsigned chunk = env->layout == QR_LAYOUT_MIXED ? qr::rollout_chunk(a, env->kind, env->layout) : 0u;
+  const qr::Pick p = qr::pick_instance(a, env->kind, env->layout, chunk);
+  plan->grid = (int32_t)(chunk ? chunk : tiles);
+  plan->block = p.help ? 128 : 64;
+  plan->launches = chunk ? (int32_t)((tiles + chunk - 1) / chunk) : 1;
+  plan->traj = p.traj; plan->adapt = p.adapt; plan->policy = p.policy; plan->single = p.single; plan->help = p.help; plan->hrew = p.hrew;
+  plan->key = ((uint32_t)env->layout << 16) | ((uint32_t)env->kind << 8) | p.bits();
+  static const char* const kXV[3] = {"float", "double", "float"};
+  static const char* const kQW[3] = {"double", "double", "float"};
+  snprintf(plan->name, sizeof(plan->name), "qr::step_kernel<%d,%s,%s,64,%d,%d,%d,%d,%d,%d>", (int)env->kind, kXV[env->layout], kQW[env->layout],
+           p.traj, (int)p.adapt, p.policy, (int)p.single, (int)p.help, (int)p.hrew);
+  return 0;
+}
+
+const char* qr_step_kernel_info(const QrEnv* env, int32_t n_steps, int32_t* grid, int32_t* block) {
+  QrLaunchPlan plan;
+  if (qr_launch_plan(env, n_steps < 1 ? 1 : n_steps, 1, 0, &plan) != 0) return "";
+  if (grid) *grid = plan.grid;
+  if (block) *block = plan.block;
   switch (env->kind) {
     case QR_KIND_QUAD: return "qr::step_kernel<0,...>";
     case QR_KIND_COUPLED: return "qr::step_kernel<1,...>";
     case QR_KIND_DECOUPLED: return "qr::step_kernel<2,...>";
     default: return "";
   }
+}
+
+int32_t qr_launch_stats(uint32_t* keys, uint32_t* counts, int32_t capacity, int32_t reset) {
+  int32_t n = 0;
+  for (int l = 0; l < 3; ++l)
+    for (int k = 0; k < 3; ++k)
+      for (int b = 0; b < 256; ++b) {
+        const uint32_t c = reset ? qr::g_launches[l][k][b].exchange(0u, std::memory_order_relaxed) : qr::g_launches[l][k][b].load(std::memory_order_relaxed);
+        if (c == 0) continue;
+        if (n < capacity && keys && counts) { keys[n] = ((uint32_t)l << 16) | ((uint32_t)k << 8) | (uint32_t)b; counts[n] = c; }
+        ++n;
+      }
+  return n;
+}
+
+int32_t qr_instance_table(uint32_t* keys, int32_t capacity) {
+  int32_t n = 0;
+  for (int l = 0; l < 3; ++l)
+    for (int k = 0; k < 3; ++k) {
+#define QR_X(TR, AD, PO, SI, HE, HR)                                                                   \
+  if (qr::inst_exists(k, l == QR_LAYOUT_MIXED, TR, AD, PO, SI, HE, HR)) {                              \
+    if (n < capacity && keys) keys[n] = ((uint32_t)l << 16) | ((uint32_t)k << 8) | qr::Pick{TR, (bool)AD, PO, (bool)SI, (bool)HE, (bool)HR}.bits(); \
+    ++n;                                                                                               \
+  }
+      QR_INSTANCES(QR_X)
+#undef QR_X
+    }
+  return n;
+}
+
+int qr_touch(const QrEnv* env, const float* action, const QrStepOut* out, void* stream) {
+  qr::Args a{};
+  if (int rc = qr::fill_env(a, env)) return rc;
+  if (!action || !out || !out->reward || !out->done) return QR_E_NULL;
+  if (env->kind != QR_KIND_QUAD && (!env->integ || !out->obs0)) return QR_E_NULL;
+  if (env->kind == QR_KIND_DECOUPLED && !out->obs1) return QR_E_NULL;
+  if (reinterpret_cast<uintptr_t>(action) & (env->kind == QR_KIND_DECOUPLED ? 3u : 15u)) return QR_E_ALIGN;
+  a.action = action; a.obs0 = out->obs0; a.obs1 = out->obs1; a.reward = out->reward; a.done = out->done;
+  const unsigned grid = (unsigned)((a.n + 63) / 64);
+  if (grid == 0) return 0;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#ifdef QR_ONLY_KIND
+  if (env->kind != QR_ONLY_KIND) return QR_E_KIND;
+#endif
+  QR_DISPATCH_LAYOUT(env->layout, (qr::launch_touch<XV, QW>(a, env->kind, grid, s)));
+  return (int)hipGetLastError();
 }
 
 }  // extern "C"

@@ -2,7 +2,8 @@
 
 One small JSON file, `~/.cache/gym_rotor_amd/launch.json` (QR_LAUNCH_CACHE=<path> moves it, QR_LAUNCH_CACHE=off disables reading
 and writing): {key: {"picked": "default" | "helper" | "no_helper", "us": {candidate: us per launch}}} with
-key = device name | library identity (ABI version, file size) | kind | tiles | layout | goal source | action source.
+key = device name | library identity (ABI version, file size) | kind | tiles | layout | goal source | action source | variant
+(substeps, optional rows).
 Speed only: no entry changes a result bit (every candidate is the same arithmetic; tests/test_gpu_parity.py).  Host logic only —
 nothing here touches the GPU.
 """
@@ -32,8 +33,9 @@ def _read(p: str) -> dict:
         return {}
 
 
-def key(device_name: str, lib_id: str, kind: str, tiles: int, layout: str, goal: str, action_source: str) -> str:
-    return "|".join([device_name, lib_id, kind, str(int(tiles)), layout, goal, action_source])
+def key(device_name: str, lib_id: str, kind: str, tiles: int, layout: str, goal: str, action_source: str, variant: str = "s1") -> str:
+    """`variant`: what else selects the instantiation — substeps, Quad-v0 observation rows, terminal-observation rows."""
+    return "|".join([device_name, lib_id, kind, str(int(tiles)), layout, goal, action_source, variant])
 
 
 def lookup(k: str) -> Optional[dict]:

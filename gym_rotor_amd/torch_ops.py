@@ -26,6 +26,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
+from .constants import OBS_DIMS
 
 _NS = "gym_rotor_amd"
 _COEFF_NAMES = [n for n, _ in _lib.QrCoeffs._fields_]
@@ -272,7 +273,18 @@ def error_obs(env, framework: Optional[str] = None, out=None) -> None:
     if framework is None or framework == env.framework:
         torch.ops.gym_rotor_amd.qr_error_obs(t[0], t[1], env._integ, env._goal, env._obs0, env._obs1, cfg, co)
         return
+    if framework not in ("MONO", "MODUL"):
+        raise ValueError(f"framework must be 'MONO' or 'MODUL', got {framework!r}")
+    dims = OBS_DIMS["coupled" if framework == "MONO" else "decoupled"]
+    if out is None:
+        raise ValueError(f"error_obs(framework={framework!r}) on a {env.framework} env writes the OTHER format: pass out= the row tensor(s) "
+                         f"to fill, float32 {[(env.num_envs, d) for d in dims]}")
     rows = [out] if isinstance(out, torch.Tensor) else list(out)
+    if len(rows) != len(dims):
+        raise ValueError(f"framework {framework!r} has {len(dims)} row tensor(s), got {len(rows)}")
+    for r, d in zip(rows, dims):
+        if tuple(r.shape) != (env.num_envs, d) or r.dtype != torch.float32 or r.device != env.device or not r.is_contiguous():
+            raise ValueError(f"out rows must be contiguous float32 [{env.num_envs}, {d}] on {env.device}")
     fmt = _lib.KIND_ID["coupled" if framework == "MONO" else "decoupled"]
     torch.ops.gym_rotor_amd.qr_error_obs(t[0], t[1], env._integ, env._goal, rows[0], rows[1] if len(rows) > 1 else None, cfg, co, fmt)
 

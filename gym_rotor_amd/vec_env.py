@@ -124,11 +124,13 @@ class QuadVecEnv:
                     forbid it.  helper_rollout: the same for rollout() / rollout_actor(), a separate choice (their crossover
                     is a different one; a choice timed on step() says nothing about them)
     autotune        the launch rule's compiled-in thresholds are crossovers measured on other boxes; boxes differ.  None (default):
-                    if `helper` is None and this env's grid lies within +-25 % of the rule's threshold, use the choice recorded for
-                    (device, library, kind, size, ...) in ~/.cache/gym_rotor_amd/launch.json (launch_cache.py; QR_LAUNCH_CACHE
-                    moves / disables it) — and if there is none yet, time both instantiations once (autotune_launch(), ~0.2 s)
-                    and record it; away from the threshold the rule is unambiguous and nothing is timed or read.  True: always
-                    time (and record).  False (or QR_AUTOTUNE=0 in the environment): the rule as compiled, never the cache
+                    if `helper` is None and this env's grid lies within +-25 % of the rule's threshold, use the choice RECORDED for
+                    (device, library, kind, size, substeps, ...) in ~/.cache/gym_rotor_amd/launch.json (launch_cache.py;
+                    QR_LAUNCH_CACHE moves / disables it) — a file read, no launch; without a record the compiled rule stays in
+                    force (QR_AUTOTUNE=time in the environment: time it then and record).  Away from the threshold the rule is
+                    unambiguous and nothing is read.  True: time both instantiations now (autotune_launch(), ~0.2 s, a hipGraph
+                    capture and a synchronise: not something a constructor should do unasked) and record the result.
+                    False (or QR_AUTOTUNE=0 in the environment): the rule as compiled, never the cache
     obs_rows        write float32 observation rows [N,D].  Always on for the wrappers.  For
                     kind='quad' the observation is the next state (quad.py:269-271): True writes
                     it as float32 [N,18] rows each step; False (default) writes nothing and
@@ -270,7 +272,7 @@ class QuadVecEnv:
         if autotune:
             self.autotune_launch()
         elif autotune is None and helper is None:
-            self._autotune_from_cache()
+            self._autotune_from_cache(time_if_absent=os.environ.get("QR_AUTOTUNE", "").lower() in ("time", "timed"))
 
     # ------------------------------------------------------------------------------
     @staticmethod
@@ -550,9 +552,14 @@ class QuadVecEnv:
                 raise ValueError(f"the static action buffer must be contiguous and {self._act_align}-byte aligned (it is read in place by every replay)")
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(dev)
-        side.wait_stream(cur)
+        saved = last = None
         if body is not None and warmup > 0:
+            # the snapshot is taken on the CURRENT stream, BEFORE the side stream is made to wait for it: the warm-up body below then
+            # runs strictly after these clones (taken after the wait, the clones and the body's writes could overlap)
             saved, last = self.state_dict(), self._last_obs
+        policy_steps = self._policy_steps
+        side.wait_stream(cur)
+        if saved is not None:
             outs = [t for t in (self._obs0, self._obs1, self._reward, self._reward_raw, self._done, self._trunc, self._final0, self._final1)
                     if t is not None]                       # the env's output buffers: a body typically reads its action from them
             with torch.cuda.stream(side):
@@ -577,6 +584,13 @@ class QuadVecEnv:
         if self._epoch != epoch:
             raise RuntimeError("capture(body=...): the body changed the env's buffers / launch configuration (set_goal_state, reset(seed=), ...): "
                                "do that before capturing")
+        if self._policy_steps != policy_steps:
+            # rollout_actor() bakes the position of its exploration-noise stream (step_base) into the launch: every replay would draw
+            # the SAME noise again
+            self._policy_steps = policy_steps
+            raise RuntimeError("capture(body=...): the body called rollout_actor(), whose in-kernel action-noise stream position is a launch "
+                               "argument — a replay would repeat the same noise.  Capture step() (with the policy in torch), or call "
+                               "rollout_actor() eagerly / pass noise= from a tensor the caller refreshes")
         return CapturedStep(self, graph, actions, ret, n_steps)
 
     def reset(self, env_type: str = "train", seed: Optional[int] = None, options: Optional[dict] = None,
@@ -819,21 +833,32 @@ class QuadVecEnv:
     def _launch_cache_key(self, action_source: str = "default") -> str:
         lib_id = f"abi{_lib.ABI_VERSION}:{os.path.getsize(_lib.LIB_PATH) if os.path.exists(_lib.LIB_PATH) else 0}"
         goal = "external" if self.goal_mode is None else f"mode{self.goal_mode}"
+        variant = f"s{self.substeps}" + ("+rows" if (self.kind == "quad" and self.obs_rows) else "") + ("+final" if self._final0 is not None else "")
         return launch_cache.key(torch.cuda.get_device_name(self.device), lib_id, self.kind, (self.num_envs + 63) // 64, self.layout,
-                                goal, action_source)
+                                goal, action_source, variant)
 
     def _has_both_step_launches(self) -> bool:
         """Does qr_step have a helper-wave AND a plain instantiation for this env?  (quadrotor_kernels.hip: wants_helper /
         wants_helper_traj — in-launch resets, the default layout, external goals or the stateless generator modes.)"""
         return self.auto_reset and self.layout == "mixed" and self.goal_mode in (None, 0, 1, 6)
 
-    def _autotune_from_cache(self):
-        """The default path of the constructor: nothing unless the grid is near the rule's threshold; then the recorded choice, or
-        one timing run whose result is recorded.  Never raises: a failure leaves the compiled rule in force."""
+    def _effective_step_threshold(self) -> int:
+        """The tile count up to which step() of THIS env takes the helper-wave launch under the compiled rule: the process'
+        thresholds (qr_launch_thresholds) with the launcher's own reductions for >= 2 substeps and the fused goal generator
+        (quadrotor_kernels.hip: wants_helper / wants_helper_traj)."""
+        thr = _lib.launch_thresholds()
+        if self.kind == "quad":
+            return thr["step_quad"] if (self.substeps <= 1 and self.goal_mode is None) else min(thr["step_quad"], 2560)
+        return thr["step_wrappers"] if (self.substeps <= 1 and self.goal_mode is None) else min(thr["step_wrappers"], 2048)
+
+    def _autotune_from_cache(self, time_if_absent: bool = False):
+        """The default path of the constructor: nothing unless the grid is near the rule's threshold; then the choice RECORDED for
+        this (device, library, kind, size, substeps, ...) by an earlier autotune_launch() — reading a small JSON file, no launch,
+        no synchronisation.  Timing is opt-in (autotune=True, or QR_AUTOTUNE=time in the environment).  Never raises: a failure
+        leaves the compiled rule in force."""
         if not self._has_both_step_launches():
             return
-        thr = _lib.launch_thresholds()["step_quad" if self.kind == "quad" else "step_wrappers"]
-        if not launch_cache.near_threshold((self.num_envs + 63) // 64, thr):
+        if not launch_cache.near_threshold((self.num_envs + 63) // 64, self._effective_step_threshold()):
             return
         try:
             key = self._launch_cache_key()
@@ -841,6 +866,8 @@ class QuadVecEnv:
             if hit is not None:
                 self.set_launch({"default": None, "helper": True, "no_helper": False}[hit["picked"]], self._helper_rollout)
                 self.autotune_report = dict(hit.get("us", {}), picked=hit["picked"], source="cache")
+                return
+            if not time_if_absent:
                 return
             report = self.autotune_launch()
             report["source"] = "timed"
@@ -866,7 +893,7 @@ class QuadVecEnv:
         cands, seen, report = {"default": None, "helper": True, "no_helper": False}, {}, {}
         for name, h in cands.items():
             self.set_launch(h, self._helper_rollout)
-            geom = self.kernel_info()[1:]
+            geom = self.launch_plan()["key"]   # the instantiation the launcher would run with this env's substeps
             if geom in seen:        # the same instantiation as an earlier candidate
                 report[name] = report[seen[geom]]
                 continue
@@ -901,11 +928,30 @@ class QuadVecEnv:
         launch_cache.store(self._launch_cache_key("default" if actions is None else "caller"), report)
         return report
 
-    def kernel_info(self, n_steps=1):
-        """(kernel family, workgroups, threads per workgroup) of the launch `step` (n_steps=1) / `rollout` uses."""
-        g, b = C.c_int32(), C.c_int32()
-        name = self._lib.qr_step_kernel_info(C.byref(self._cenv), n_steps, C.byref(g), C.byref(b))
-        return name.decode(), g.value, b.value
+    def launch_plan(self, n_steps: int = 1, actor: Optional[str] = None) -> dict:
+        """What the launcher runs for step() (n_steps=1) / rollout(T) / rollout_actor(actors, T) with `actor` in ("ppo", "td3",
+        "sac"): dict(name = the kernel instantiation as it appears in a rocprofv3 trace, grid, block, launches, key, and the
+        template arguments traj, adapt, policy, single, help, hrew) — the launcher's own decision function with this env's
+        substeps (qr_launch_plan; host-side, nothing is launched)."""
+        plan = _lib.QrLaunchPlan()
+        form = {None: 0, "ppo": 1, "td3": 1, "sac": 2}[actor]
+        _lib.check(self._lib.qr_launch_plan(C.byref(self._cenv), int(n_steps), self.substeps, form, C.byref(plan)), "qr_launch_plan")
+        return {"name": plan.name.decode(), "grid": plan.grid, "block": plan.block, "launches": plan.launches, "key": int(plan.key),
+                **{k: int(getattr(plan, k)) for k in ("traj", "adapt", "policy", "single", "help", "hrew")}}
+
+    def kernel_info(self, n_steps=1, actor: Optional[str] = None):
+        """(kernel family, workgroups, threads per workgroup) of the launch `step` (n_steps=1) / `rollout` / `rollout_actor` uses."""
+        plan = self.launch_plan(n_steps, actor)
+        return f"qr::step_kernel<{_lib.KIND_ID[self.kind]},...>", plan["grid"], plan["block"]
+
+    def touch(self, actions: torch.Tensor):
+        """The step's memory traffic and nothing else (qr_touch): one launch that reads and writes per env exactly what step()
+        does, without arithmetic — the yardstick bench.py prices a step against.  The state is left as it was (bit for bit); the
+        env's output rows (what the last step() returned) hold zeros afterwards."""
+        a = self._check_actions(actions)
+        with self._on_device():
+            rc = self._lib.qr_touch(C.byref(self._cenv), a.data_ptr(), C.byref(self._cout), self._stream())
+        _lib.check(rc, "qr_touch")
 
     def render(self, *a, **k):
         raise NotImplementedError("render (VPython GUI, quad.py:469-754) is out of scope")
@@ -939,44 +985,114 @@ class CapturedStep:
 
 
 def as_gymnasium_vector_env(env: "QuadVecEnv"):
-    """Wrap `env` as a `gymnasium.vector.VectorEnv` (SURVEY §8b) when gymnasium is importable;
-    raises ImportError otherwise (the engine itself never needs gymnasium).  Observations,
-    rewards and flags stay torch tensors on the GPU; `reset` follows Gymnasium's signature and
-    returns the first observation (reset -> [goal] -> get_norm_error_state, main.py:126-129)."""
+    """`env` as a `gymnasium.vector.VectorEnv` (the reference env is a `gym.Env`, quad.py:19, with the spaces of
+    quad.py:108-132) when gymnasium is importable; raises ImportError otherwise — the engine itself never needs gymnasium.
+
+    Everything stays a torch tensor on the GPU; nothing here synchronises with the host.
+      reset(seed=, options=)  -> (obs[N, D], info).  options: {"env_type": "train" | "eval"} (the reference's extra reset argument,
+                                 quad.py:171), {"reset_mask": bool[N]} (Gymnasium's partial reset).  The first observation is what the
+                                 reference's loop forms after a reset: [goal] -> get_norm_error_state() (main.py:126-129) — the
+                                 integral terms advance by that call exactly as they do there.
+      step(actions[N, A])     -> (obs[N, D], reward, terminated, truncated, info).  obs: the agents' rows side by side (Decoupled:
+                                 15 + 3 = 18 columns; info["obs_per_agent"] holds the tuple).  Single-agent kinds: reward[N],
+                                 terminated[N].  Decoupled: reward[N, 2] (one column per agent, as the reference returns one reward
+                                 per agent) and terminated[N] = either agent's flag — the episode ends and the env is re-sampled on
+                                 either (main.py:183-186); info["terminated_per_agent"] is the [N, 2] tensor.
+      autoreset               metadata["autoreset_mode"] = SAME_STEP when the env was built with auto_reset=True (terminated envs are
+                                 re-sampled inside the step launch: the returned obs row is the new episode's first observation), else
+                                 DISABLED (call reset(options={"reset_mask": ...})).  With final_obs=True the TERMINAL observation of
+                                 every env that ended is reachable as info["final_obs"][N, D] under the mask info["_final_obs"][N]
+                                 (Gymnasium >= 1.0 names; the same tensors under "final_observation" / "_final_observation", the names
+                                 of the Gymnasium 0.28 the reference pins).
+      spaces                  single_observation_space: Box(-inf, inf, (D,)) for the wrappers (normalised errors are not bounded by
+                                 the state box), the reference's state box for kind='quad' (quad.py:108-125); single_action_space:
+                                 Box(-1, 1, (A,)) (quad.py:127-132); observation_space / action_space: their batch_space; all seedable
+                                 (utils.py:17-18 calls .seed()).
+    """
     import gymnasium as gym
 
-    single_obs = gym.spaces.Box(-np.inf, np.inf, shape=(sum(env.obs_dims),), dtype=np.float32)
+    D = sum(env.obs_dims)
+    if env.kind == "quad":
+        so = env.single_observation_space
+        single_obs = gym.spaces.Box(so.low, so.high, dtype=np.float32)
+    else:
+        single_obs = gym.spaces.Box(-np.inf, np.inf, shape=(D,), dtype=np.float32)
     single_act = gym.spaces.Box(-1.0, 1.0, shape=(env.action_dim,), dtype=np.float32)
+    modes = getattr(gym.vector, "AutoresetMode", None)
+    mode = (modes.SAME_STEP if env.auto_reset else modes.DISABLED) if modes is not None else ("SameStep" if env.auto_reset else "Disabled")
 
     class GymnasiumQuadVecEnv(gym.vector.VectorEnv):
-        metadata = {"render_modes": [], "autoreset_mode": "same_step" if env.auto_reset else "disabled"}
+        metadata = {"render_modes": [], "autoreset_mode": mode}
 
         def __init__(self):
+            batch = getattr(getattr(gym.vector, "utils", None), "batch_space", None)
+            obs_space = batch(single_obs, env.num_envs) if batch else single_obs
+            act_space = batch(single_act, env.num_envs) if batch else single_act
+            try:      # Gymnasium 0.28 (the reference's pin): VectorEnv.__init__(num_envs, observation_space, action_space)
+                super().__init__(env.num_envs, single_obs, single_act)
+            except TypeError:   # Gymnasium >= 1.0: no constructor arguments, attributes are set by the subclass
+                super().__init__()
             self.env = env
             self.num_envs = env.num_envs
             self.single_observation_space, self.single_action_space = single_obs, single_act
-            batch = getattr(gym.vector.utils, "batch_space", None)
-            self.observation_space = batch(single_obs, env.num_envs) if batch else single_obs
-            self.action_space = batch(single_act, env.num_envs) if batch else single_act
+            self.observation_space, self.action_space = obs_space, act_space
+            self.render_mode = None
 
-        def _cat(self, obs):
+        @staticmethod
+        def _cat(obs):
             return obs if isinstance(obs, torch.Tensor) else torch.cat(list(obs), 1)
 
-        def reset(self, *, seed=None, options=None):
-            env.reset((options or {}).get("env_type", "train"), seed=seed)
+        def _first_obs(self):
             if env.kind == "quad":
-                return env.get_current_state().to(torch.float32), {}
+                return env.get_current_state().to(torch.float32)
             if env.goal_mode is not None:
-                env.get_desired(store_goal=True)
-            return self._cat(env.get_norm_error_state()), {}
+                env.get_desired(store_goal=True)    # main.py:226-229: mark_traj_start (done by reset), get_desired, set_goal_state, then the observation
+            return self._cat(env.get_norm_error_state())
+
+        def reset(self, *, seed=None, options=None):
+            options = dict(options or {})
+            mask = options.get("reset_mask")
+            if mask is not None:
+                mask = torch.as_tensor(mask, device=env.device).to(torch.bool)
+            if mask is None or env.kind == "quad":
+                env.reset(options.get("env_type", "train"), seed=seed, mask=mask)
+                return self._first_obs(), {}
+            # partial reset: the envs outside the mask keep their integral terms and the observation rows of their last step
+            # (get_norm_error_state() forms rows for the whole batch and advances every env's integrators)
+            keep_integ = env._integ.clone()
+            keep_rows = [t.clone() for t in (env._obs0, env._obs1) if t is not None]
+            env.reset(options.get("env_type", "train"), seed=seed, mask=mask)
+            self._first_obs()
+            env._integ.copy_(torch.where(mask[None, :], env._integ, keep_integ))
+            for t, k in zip([t for t in (env._obs0, env._obs1) if t is not None], keep_rows):
+                t.copy_(torch.where(mask[:, None], t, k))
+            env._last_obs = env._obs()
+            return self._cat(env._last_obs), {}
 
         def step(self, actions):
-            obs, rwd, term, trunc, info = env.step(torch.as_tensor(actions, dtype=torch.float32, device=env.device))
+            obs, rwd, term, trunc, _ = env.step(torch.as_tensor(actions, dtype=torch.float32, device=env.device))
             if obs is None:
                 obs = env.get_current_state().to(torch.float32)
-            return self._cat(obs), rwd, term, trunc, info
+            info = {}
+            if env.n_agents == 1:
+                rwd, ended = rwd[:, 0], term[:, 0]
+            else:
+                info["terminated_per_agent"], info["obs_per_agent"] = term, obs
+                ended = term.any(dim=1)
+            if env._final0 is not None:
+                fin, m = self._cat(env.final_observation()), ended | trunc
+                info["final_obs"], info["_final_obs"] = fin, m
+                info["final_observation"], info["_final_observation"] = fin, m
+            return self._cat(obs), rwd, ended, trunc, info
+
+        def close_extras(self, **kwargs):
+            env.close()
 
         def close(self, **kwargs):
+            parent = getattr(super(), "close", None)
+            if parent is not None:
+                parent(**kwargs)
             env.close()
+            self.closed = True
 
     return GymnasiumQuadVecEnv()

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define QR_ABI_VERSION 13
+#define QR_ABI_VERSION 14
 
 /* env kinds */
 #define QR_KIND_QUAD      0 /* QuadEnv            gym_rotor/envs/quad.py:19            */
@@ -348,11 +348,36 @@ int qr_gae(const float* reward, const uint8_t* done, const float* value, const f
 /* Host-side helpers (no device work). */
 void qr_default_coeffs(QrCoeffs* c);
 int  qr_abi_version(void);
-/* Kernel family name + launch geometry qr_step (n_steps = 1) / qr_rollout would use for this env (for profiling
- * tools): `grid` workgroups of `block` threads — 64 (one wavefront per 64-env tile), or 128 where the launcher adds a
- * helper wavefront per tile (QR_FLAG_AUTO_RESET, default layout, grids in the launch-latency regime).  "" if the env
- * descriptor is invalid. */
+/* What the launcher would run for this env — host-side, no device work; nothing in the reference (profilers, autotuners, tests).
+ * qr_step / qr_rollout (actor = 0) or qr_rollout_actor (actor = 1: PPO / TD3-form actors, 2: the general form with SAC's
+ * log_std head) over n_steps env-steps of `substeps` RK4 substeps: `launches` launches of `grid` workgroups (64-env tiles)
+ * of `block` threads — 64 = one wavefront per tile, 128 = plus a helper wavefront (QR_FLAG_AUTO_RESET, default layout, grids
+ * in the launch-latency regime; launches > 1: qr_rollout_actor in chunks of `grid` resident tiles) — of the instantiation
+ * `name` = qr::step_kernel<KIND, XV, QW, 64, TRAJ, ADAPT, POLICY, SINGLE, HELP, HREW> with the values filled in (the prefix of the
+ * kernel's name in a rocprofv3 trace).  `key` = layout << 16 | kind << 8 | TRAJ | ADAPT << 2 | POLICY << 3 | SINGLE << 5 |
+ * HELP << 6 | HREW << 7: what qr_launch_stats counts under. */
+typedef struct QrLaunchPlan {
+  int32_t grid, block, launches;
+  int32_t traj, adapt, policy, single, help, hrew;
+  uint32_t key;
+  char name[96];
+} QrLaunchPlan;
+int qr_launch_plan(const QrEnv* env, int32_t n_steps, int32_t substeps, int32_t actor, QrLaunchPlan* plan);
+/* The older, shorter form: kernel family name + launch geometry of qr_step (n_steps = 1) / qr_rollout with ONE substep.
+ * "" if the env descriptor is invalid. */
 const char* qr_step_kernel_info(const QrEnv* env, int32_t n_steps, int32_t* grid, int32_t* block);
+/* Host-side launch counters of this process: how many step-kernel launches each (layout, kind, instantiation) `key` has had
+ * since load (or since the last call with reset != 0).  Writes up to `capacity` (key, count) pairs with count > 0, returns
+ * how many there are.  qr_instance_table lists the keys of EVERY instantiation the library holds (126), same convention:
+ * together they tell a test suite which kernels it really ran. */
+int32_t qr_launch_stats(uint32_t* keys, uint32_t* counts, int32_t capacity, int32_t reset);
+int32_t qr_instance_table(uint32_t* keys, int32_t capacity);
+
+/* The step's memory traffic and nothing else: one launch that moves, per env, exactly what qr_step moves — state in and out,
+ * parameters, the action row, [goal], [integrator words in and out], [observation rows], reward and done rows — with no
+ * arithmetic.  The yardstick a step's time is priced against (bench.py: roofline.noop_kernel_us, measured live on the box
+ * and the buffers of the run).  The env's state is written back as read, bit for bit; the output rows hold zeros afterwards. */
+int qr_touch(const QrEnv* env, const float* action, const QrStepOut* out, void* stream);
 
 /* The launch rule's thresholds in force in this process (compiled-in defaults or the QR_HELPER_GRID* environment variables), in
  * 64-env tiles: grids up to *step_quad (Quad-v0) / *step_wrappers (Coupled, Decoupled) tiles run qr_step with a helper wavefront

@@ -24,6 +24,26 @@ def pytest_sessionstart(session):
         subprocess.run(["make", "-C", os.path.join(ROOT, "gym_rotor_amd", "csrc")], check=True)
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """On a GPU box: which step-kernel instantiations did this pytest process really launch?  (qr_launch_stats: host-side counters
+    of the library.)  Written to gpurun_out/launch_stats.json — the record behind DESIGN.md's "every instantiation is exercised"."""
+    try:
+        import json
+        import torch
+        if not torch.cuda.is_available():
+            return
+        from gym_rotor_amd import _lib
+        stats, table = _lib.launch_stats(), _lib.instance_table()
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        json.dump({"instantiations": len(table), "launched": sum(1 for k in table if stats.get(k, 0) > 0),
+                   "never_launched": [_lib.describe_key(k) for k in table if stats.get(k, 0) == 0],
+                   "launches": {_lib.describe_key(k): stats[k] for k in sorted(stats)}},
+                  open(os.path.join(out, f"launch_stats_{os.getpid()}.json"), "w"), indent=1)
+    except Exception:   # a diagnostic: never fails the run
+        pass
+
+
 @pytest.fixture(scope="session")
 def golden():
     cache = {}

@@ -1048,25 +1048,36 @@ def test_rollout_ignores_the_callers_reset_promise(kind):
     assert torch.equal(a.get_current_state(), b.get_current_state())
 
 
-def test_default_autotune_times_once_near_the_threshold_and_then_reads_the_cache(tmp_path, monkeypatch):
-    """The constructor's default (autotune=None): away from the launch rule's threshold nothing is timed or read; within +-25 % of
-    it the env times both step() instantiations once (~0.2 s), records the choice in the launch cache, and the next env of the same
-    (device, library, kind, size, ...) takes it from there.  Whatever is picked, no bit changes; QR_AUTOTUNE=0 and an explicit
-    `helper=` switch it off."""
+def test_default_autotune_reads_the_cache_and_times_only_on_request(tmp_path, monkeypatch):
+    """The constructor's default (autotune=None) launches nothing: away from the launch rule's threshold nothing is read either; within
+    +-25 % of it the choice RECORDED in the launch cache for (device, library, kind, size, substeps, ...) is taken — and without a
+    record the compiled rule stays in force.  Timing is on request: autotune=True (or QR_AUTOTUNE=time) times both step()
+    instantiations once (~0.2 s) and records the choice.  Whatever is picked, no bit changes; QR_AUTOTUNE=0 and an explicit
+    `helper=` switch all of it off."""
     import json
     cache = tmp_path / "launch.json"
     monkeypatch.setenv("QR_LAUNCH_CACHE", str(cache))
+    monkeypatch.delenv("QR_AUTOTUNE", raising=False)
     far = _env("quad", 64 * 700, seed=2, auto_reset=True)
     assert far.autotune_report is None and not cache.exists()                  # 700 tiles against 3328: the rule is unambiguous
     n = 64 * 3400                                                              # 3400 tiles: 2 % above Quad-v0's threshold
-    a = _env("quad", n, seed=2, auto_reset=True)
-    assert a.autotune_report["source"] == "timed" and a.autotune_report["helper"] > 0 and a.autotune_report["no_helper"] > 0
+    cold = _env("quad", n, seed=2, auto_reset=True)
+    assert cold.autotune_report is None and not cache.exists() and cold.kernel_info()[2] == 64   # no record: the compiled rule, nothing timed
+    a = _env("quad", n, seed=2, auto_reset=True, autotune=True)
+    assert a.autotune_report["helper"] > 0 and a.autotune_report["no_helper"] > 0
     entries = json.loads(cache.read_text())["entries"]
-    assert len(entries) == 1 and list(entries.values())[0]["picked"] == a.autotune_report["picked"]
+    assert len(entries) == 1 and list(entries.values())[0]["picked"] == a.autotune_report["picked"] and list(entries)[0].endswith("|s1")
     assert int(a._reset_count.abs().sum()) == 0 and int(a._episode.sum()) == 0  # tuning left no trace in the env
     b = _env("quad", n, seed=2, auto_reset=True)
     assert b.autotune_report["source"] == "cache" and b.autotune_report["picked"] == a.autotune_report["picked"]
     assert b.kernel_info() == a.kernel_info()
+    # another instantiation family (two substeps: its own effective threshold, 2560 tiles, and its own cache entry)
+    assert _env("quad", n, seed=2, auto_reset=True, substeps=2).autotune_report is None            # 3400 tiles are > 1.25 x 2560: not near
+    monkeypatch.setenv("QR_AUTOTUNE", "time")
+    s2 = _env("quad", 64 * 2600, seed=2, auto_reset=True, substeps=2)
+    assert s2.autotune_report["source"] == "timed" and len(json.loads(cache.read_text())["entries"]) == 2
+    assert s2.launch_plan()["help"] == (0 if s2.autotune_report["picked"] == "no_helper" else 1) or s2.autotune_report["picked"] == "default"
+    monkeypatch.delenv("QR_AUTOTUNE")
     c = _env("quad", n, seed=2, auto_reset=True, helper=(a.kernel_info()[2] != 128))   # the OTHER instantiation, pinned
     assert c.autotune_report is None and c.kernel_info()[2] != a.kernel_info()[2]
     monkeypatch.setenv("QR_AUTOTUNE", "0")

@@ -283,6 +283,62 @@ def test_launch_geometry_rule_without_gpu():
     assert info(0, 65536, flag["FORCE_HELPER"])[2] == 64                   # no such instantiation without in-launch resets: ignored
 
 
+def test_launch_plan_names_the_instantiation_without_gpu():
+    """qr_launch_plan (host-only): the launcher's own decision with the env's substeps and, for qr_rollout_actor, the actor form —
+    instantiation name as a rocprofv3 trace prints it, geometry, number of launches (chunked actor rollouts), counter key;
+    qr_instance_table lists all 126 instantiations and every plan's key is one of them."""
+    L = _lib()
+    lib = L.load()
+    AR = L.FLAG_AUTO_RESET
+
+    def plan(kind, n, flags, n_steps=1, substeps=1, actor=0, layout=0, goal_mode=None, rc=0):
+        e = L.QrEnv()
+        lib.qr_default_coeffs(C.byref(e.coeffs))
+        e.kind, e.layout, e.num_envs, e.pos_vel, e.att_rate, e.flags = kind, layout, n, 0x1000, 0x2000, flags
+        if goal_mode is not None:
+            e.goal_mode, e.traj, e.goal = goal_mode, 0x7000, 0x8000
+        p = L.QrLaunchPlan()
+        assert lib.qr_launch_plan(C.byref(e), n_steps, substeps, actor, C.byref(p)) == rc
+        return p
+
+    table = L.instance_table()
+    assert len(table) == 126 and len(set(table)) == 126
+    p = plan(0, 65536, AR)
+    assert p.name == b"qr::step_kernel<0,float,double,64,0,0,0,1,1,1>" and (p.grid, p.block, p.launches) == (1024, 128, 1) and p.key in table
+    assert L.describe_key(p.key) == "mixed/quad TRAJ=0 ADAPT=0 POLICY=0 SINGLE=1 HELP=1 HREW=1"
+    # substeps move the thresholds (3328 -> 2560 tiles for Quad-v0, 2560 -> 2048 for the wrappers) and keep the reward on the helper wave
+    assert plan(0, 64 * 3000, AR).help == 1 and plan(0, 64 * 3000, AR, substeps=2).help == 0
+    assert plan(1, 64 * 2300, AR).help == 1 and plan(1, 64 * 2300, AR, substeps=4).help == 0
+    assert plan(0, 64 * 1500, AR).hrew == 0 and plan(0, 64 * 1500, AR, substeps=10).hrew == 1 and plan(0, 64 * 1400, AR).hrew == 1
+    assert plan(2, 64 * 1700, AR).hrew == 0 and plan(2, 64 * 1600, AR).hrew == 1
+    # free run (no resets) -> the rate-adaptive one-step kernel; the caller's reset promise -> the plain one; uniform layouts: no SINGLE
+    assert (plan(0, 65536, 0).adapt, plan(0, 65536, 0).single) == (1, 1) and plan(0, 65536, L.FLAG_CALLER_RESETS).adapt == 0
+    assert plan(0, 65536, AR, layout=1).name == b"qr::step_kernel<0,double,double,64,0,0,0,0,0,1>"
+    # qr_rollout_actor: PPO / SAC forms, helper wave up to 1024 tiles, beyond it chunks of 1024 tiles (one launch after the other)
+    a = plan(1, 65536, AR, n_steps=32, actor=1)
+    assert (a.policy, a.help, a.block, a.launches, a.grid) == (1, 1, 128, 1, 1024)
+    b = plan(2, 262144, AR, n_steps=32, actor=2)
+    assert (b.policy, b.help, b.launches, b.grid) == (2, 1, 4, 1024) and b.key in table
+    c = plan(1, 262144, AR | L.FLAG_NO_HELPER_ROLLOUT, n_steps=32, actor=1)
+    assert (c.help, c.launches, c.grid, c.block) == (0, 1, 4096, 64)
+    assert plan(1, 65536, AR, n_steps=8, actor=1, goal_mode=L.GOAL_MODE2).name == b"qr::step_kernel<1,float,double,64,2,1,2,0,0,1>"
+    # argument errors
+    plan(0, 65536, AR, actor=1, rc=-2)             # no actor rollouts for Quad-v0
+    plan(1, 65536, AR, substeps=0, rc=-3)
+    plan(1, 65536, AR, actor=3, rc=-3)
+    assert lib.qr_launch_plan(None, 1, 1, 0, C.byref(L.QrLaunchPlan())) == -1
+    # every key a plan can name is in the table (a sweep of the decision function's inputs)
+    for kind in (0, 1, 2):
+        for layout in (0, 1, 2):
+            for flags in (0, AR, AR | L.FLAG_NO_HELPER | L.FLAG_NO_HELPER_ROLLOUT, L.FLAG_CALLER_RESETS):
+                for n_steps, actor in ((1, 0), (5, 0), (5, 1), (5, 2)):
+                    for gm in (None, L.GOAL_MODE0, L.GOAL_MODE5):
+                        if actor and kind == 0:
+                            continue
+                        assert plan(kind, 70000, flags, n_steps=n_steps, actor=actor, layout=layout, goal_mode=gm).key in table
+    assert L.launch_stats() == {} or all(k in table for k in L.launch_stats())    # (no launches on a box without a GPU)
+
+
 def test_no_cpu_fallback():
     """Without a GPU the env refuses to exist; without the library the import of the binding raises."""
     _lib()
@@ -456,15 +512,26 @@ def test_bench_presets_and_scaling_flags_without_gpu(monkeypatch):
     assert parse("--scaling", "strong").global_envs == 65536 and parse("--scaling", "strong", "--envs", "4096").global_envs == 4096
     assert parse("--scaling", "strong", "--global-envs", "777").global_envs == 777
     assert parse("--config", "2").kind == "coupled" and parse("--config", "1").envs == 65536
-    # what the default 1-GPU run measures beside the headline (config.baseline_configs): every other BASELINE.json config in its
-    # per-GPU and one-GPU shape, the fused rollout and the PPO collection loop — eight rows, each priced with SURVEY 8(d)'s bytes
+    # what the default 1-GPU run measures beside the headline: every other BASELINE.json config in its per-GPU and one-GPU shape, the
+    # fused rollout and the PPO collection loop — eight rows, each priced with SURVEY 8(d)'s bytes — then the float64 layout and
+    # three more fused launches; all of it as FLAT scalar keys of `config` (the driver's record drops nested lists)
     shapes = [(c["kind"], c["envs"], c["substeps"], c["workload"], c["horizon"]) for c in bench.BASELINE_CONFIGS]
     assert shapes == [("coupled", 65536, 1, "step", 1), ("decoupled", 32768, 1, "step", 1), ("decoupled", 262144, 1, "step", 1),
                       ("quad", 131072, 10, "step", 1), ("quad", 1048576, 10, "step", 1), ("quad", 1048576, 1, "step", 1),
                       ("quad", 65536, 1, "rollout", 100), ("coupled", 65536, 1, "rollout_actor", 32)]
-    assert all(c["steps"] % c["horizon"] == 0 and c["slabs"] * c["envs"] * 20 < 2 ** 31 for c in bench.BASELINE_CONFIGS + bench.OTHER_FUSED)
-    assert [(c["kind"], c["envs"], c["workload"]) for c in bench.OTHER_FUSED] == [("coupled", 65536, "rollout"), ("decoupled", 65536, "rollout_actor"),
-                                                                                 ("coupled", 262144, "rollout_actor")]
+    assert all(c["steps"] % c["horizon"] == 0 and c["slabs"] * c["envs"] * 20 < 2 ** 31 for c in bench.BASELINE_CONFIGS + bench.OTHER_ROWS)
+    assert [(c["kind"], c["envs"], c["workload"], c.get("layout")) for c in bench.OTHER_ROWS] == [
+        ("quad", 65536, "step", "f64"), ("coupled", 65536, "step", "f64"), ("quad", 1048576, "step", "f64"),
+        ("coupled", 65536, "rollout", None), ("decoupled", 65536, "rollout_actor", None), ("coupled", 262144, "rollout_actor", None)]
+    keys = bench.secondary_keys()
+    for k in ("free_run_us", "c2_coupled65536_us", "c2_coupled65536_frac", "c3_share32768_us", "c3_share32768_frac", "c3_262144_us", "c3_262144_frac",
+              "c4_share131072x10_us", "c4_share131072x10_frac", "c4_1Mx10_us", "c4_1Mx10_frac", "quad1Mx1_us", "quad1Mx1_frac", "quad1Mx1_noop_us",
+              "rollout_T100_us_per_env_step", "ppo_collect_T32_us_per_env_step", "f64_quad65536_us", "f64_quad1Mx1_us", "f64_coupled65536_us"):
+        assert k in keys, k
+    # the whole JSON line must fit the driver's 8 KB record with room to spare: a worst-case line (every secondary key with an
+    # 18-character value on top of ~2.6 KB of headline, roofline and cpu_baseline fields) stays under bench.MAX_LINE_BYTES
+    import json
+    assert bench.MAX_LINE_BYTES <= 6144 and len(json.dumps({k: 0.12345678901234567 for k in keys})) + 2700 <= bench.MAX_LINE_BYTES
     assert [bench.algo_bytes_per_env_step(k) for k in ("quad", "coupled", "decoupled")] == [189, 345, 334]
     assert abs(bench.algo_bytes_per_env_step("quad", "rollout", 100) - (21 + 168 / 100)) < 1e-12
     assert abs(bench.algo_bytes_per_env_step("coupled", "rollout_actor", 32) - (129 + 232 / 32)) < 1e-12
