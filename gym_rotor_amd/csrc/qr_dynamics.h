@@ -197,6 +197,12 @@ __device__ __forceinline__ void integrate(T (&x)[3], T (&v)[3], T (&q)[4], T (&W
 // (Measured and NOT adopted, profiles/r02/ab_quad_builds.txt column q_pk: the quaternion stages on v_pk_fma_f32 / v_pk_mul_f32 with
 // op_sel / neg swizzles, six packed instructions per derivative — 4.45-4.56 against 4.40-4.47 us per launch at 65 536 envs,
 // 33.7-33.8 against 33.0-33.2 at 1 M: the code is gone, the record stays.)
+#ifndef QR_W_COUPLING_F32
+#define QR_W_COUPLING_F32 1
+#endif
+#ifndef QR_STEP_ACCUM_F32
+#define QR_STEP_ACCUM_F32 1
+#endif
 __device__ __forceinline__ void integrate(float (&x)[3], float (&v)[3], double (&q)[4], double (&W)[3], const Dyn<double>& p, int nsub,
                                           double h) {
   const float hf = (float)h, h2f = 0.5f * hf, h6f = hf * (1.0f / 6.0f);
@@ -208,6 +214,15 @@ __device__ __forceinline__ void integrate(float (&x)[3], float (&v)[3], double (
   const float daf = (float)da, dw3 = (float)(0.5 * p.U3 * h2);
   const float u1 = (float)(0.5 * p.U1), u2 = (float)(0.5 * p.U2);
   double W1 = W[0], W2 = W[1];
+#if QR_W_COUPLING_F32
+  const float h3f = hf * (1.0f / 3.0f);
+  const double hU1 = h * p.U1, hU2 = h * p.U2;
+  (void)h6; (void)h3f; (void)hU1; (void)hU2;
+#if QR_STEP_ACCUM_F32
+  float dqs[4] = {0.f, 0.f, 0.f, 0.f}, csa = 0.f, csb = 0.f;
+  const float hu1h = (float)(0.5 * hU1), hu2h = (float)(0.5 * hU2);
+#endif
+#endif
   float g1[3] = {0.f, 0.f, 0.f}, g23[3] = {0.f, 0.f, 0.f}, g4[3] = {0.f, 0.f, 0.f}, xx[3] = {0.f, 0.f, 0.f};
   // thrust direction, un-normalised: R e3 = (2 u0, 2 u1, 1 - 2 u2), u = (xz + wy, yz - wx, xx + yy)
 #define QR_THRUST(G, Qw, Qx, Qy, Qz)                            \
@@ -228,6 +243,69 @@ __device__ __forceinline__ void integrate(float (&x)[3], float (&v)[3], double (
 #pragma unroll
       for (int j = 0; j < 3; ++j) xx[j] += fmaf(2.0f, g23[j], g1[j] + g4[j]);
     }
+#if QR_W_COUPLING_F32
+    // ---- W1, W2: the torque part of the increment is linear in time and taken in float64 exactly (h U per substep); the gyroscopic
+    // coupling part — RK4 of a(t) (W2, -W1), |a W| <= ~22 rad/s^2 in regime — comes from the float32 stage chain the quaternion
+    // needs anyway and is ACCUMULATED in float64 (like q).  18 float64 instructions less per substep, 16 float32 more. ----
+    const float b0 = a3f, bm = a3f + daf, b1 = bm + daf;
+    const float z0 = w3, zm = w3 + dw3, z1 = zm + dw3;
+    float kq[4], acc[4], qt[4];
+    // stage 1
+    QR_QDOT(kq, qs, w1, w2, z0)
+    QR_THRUST(g1, qs[0], qs[1], qs[2], qs[3])
+    float ca = b0 * w2, cb = -b0 * w1;            // coupling parts (half units), k = c + u
+    float sca = ca, scb = cb;
+    float t1 = fmaf(h2f, ca + u1, w1), t2 = fmaf(h2f, cb + u2, w2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[j] = kq[j]; qt[j] = fmaf(h2f, kq[j], qs[j]); }
+    // stage 2
+    QR_QDOT(kq, qt, t1, t2, zm)
+    QR_THRUST(g23, qt[0], qt[1], qt[2], qt[3])
+    ca = bm * t2; cb = -bm * t1;
+    sca = fmaf(2.0f, ca, sca); scb = fmaf(2.0f, cb, scb);
+    t1 = fmaf(h2f, ca + u1, w1); t2 = fmaf(h2f, cb + u2, w2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[j] = fmaf(2.0f, kq[j], acc[j]); qt[j] = fmaf(h2f, kq[j], qs[j]); }
+    // stage 3
+    QR_QDOT(kq, qt, t1, t2, zm)
+    QR_THRUST(g23, qt[0], qt[1], qt[2], qt[3])
+    ca = bm * t2; cb = -bm * t1;
+    sca = fmaf(2.0f, ca, sca); scb = fmaf(2.0f, cb, scb);
+    t1 = fmaf(hf, ca + u1, w1); t2 = fmaf(hf, cb + u2, w2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[j] = fmaf(2.0f, kq[j], acc[j]); qt[j] = fmaf(hf, kq[j], qs[j]); }
+    // stage 4
+    QR_QDOT(kq, qt, t1, t2, z1)
+    QR_THRUST(g4, qt[0], qt[1], qt[2], qt[3])
+    sca = fmaf(b1, t2, sca); scb = fmaf(-b1, t1, scb);
+#if QR_STEP_ACCUM_F32
+    // Within ONE env-step every stage quantity is float32 already; so are, here, the running sums of the substeps' increments —
+    // the float64 state takes them once, at the end of the step (below).  A sum of <= 16 increments of <= 0.016 (q) / 0.06 (W/2)
+    // rounds at ~4e-9 per step, below the float32 stage noise that is there anyway; with ONE substep the result is the same.
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float dq = h6f * (acc[j] + kq[j]);
+      dqs[j] += dq;
+      qs[j] += dq;          // float32 track for the next substep's stages (re-synchronised every env-step)
+    }
+    const float ia = h6f * sca, ib = h6f * scb;   // coupling increments (half units)
+    csa += ia; csb += ib;
+    w1 += hu1h + ia; w2 += hu2h + ib;             // float32 track of W/2 (re-synchronised every env-step)
+    a3f = b1; w3 = z1;
+    const double a1 = a3;   // (the float64 track of a(t) is not needed: a3f carries it)
+#else
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float dq = h6f * (acc[j] + kq[j]);
+      q[j] += (double)dq;   // the float64 state takes the increment exactly
+      qs[j] += dq;          // float32 track for the next substep's stages (re-synchronised every env-step)
+    }
+    // (half units -> full: x 2; h/6 x 2 = h/3)
+    W1 = (W1 + hU1) + (double)(h3f * sca);
+    W2 = (W2 + hU2) + (double)(h3f * scb);
+    const double a1 = a3 + (da + da);
+#endif
+#else
     // ---- W1, W2 in float64: W1' = a(t) W2 + U1, W2' = -a(t) W1 + U2 ----
     const double a0 = a3, am = a3 + da, a1 = am + da;
     const double k1a = fma(a0, W2, p.U1), k1b = fma(-a0, W1, p.U2);
@@ -273,8 +351,11 @@ __device__ __forceinline__ void integrate(float (&x)[3], float (&v)[3], double (
     }
     W1 = fma(h6, fma(2.0, k2a + k3a, k1a + k4a), W1);
     W2 = fma(h6, fma(2.0, k2b + k3b, k1b + k4b), W2);
+#endif
     a3 = a1; a3f = b1; w3 = z1;
+#if !(QR_W_COUPLING_F32 && QR_STEP_ACCUM_F32)
     w1 = 0.5f * (float)W1; w2 = 0.5f * (float)W2;
+#endif
   }
 #undef QR_THRUST
 #undef QR_QDOT
@@ -294,6 +375,15 @@ __device__ __forceinline__ void integrate(float (&x)[3], float (&v)[3], double (
   v[0] = fmaf(-hc3, G[0], v[0]);
   v[1] = fmaf(-hc3, G[1], v[1]);
   v[2] = fmaf(hc3, G[2], fmaf(dtf, gc, v[2]));
+#if QR_W_COUPLING_F32 && QR_STEP_ACCUM_F32
+  {
+    const double dt = h * (double)nsub;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] += (double)dqs[j];
+    W1 = fma(dt, p.U1, W1) + 2.0 * (double)csa;   // torque part exact; coupling part from the float32 chain (half units -> x 2)
+    W2 = fma(dt, p.U2, W2) + 2.0 * (double)csb;
+  }
+#endif
   W[0] = W1; W[1] = W2;
   W[2] = fma(p.U3, h * (double)nsub, W[2]);
 }

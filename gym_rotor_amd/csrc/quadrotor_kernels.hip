@@ -1284,40 +1284,76 @@ __global__ __launch_bounds__(64) void get_desired_kernel(const Args a) {
 // output rows hold zeros afterwards.
 // ------------------------------------------------------------------------------------
 template <int KIND, typename XV, typename QW>
-__global__ __launch_bounds__(64) void touch_kernel(const Args a) {
+__global__ __launch_bounds__(64) void touch_kernel(void* pos_vel, void* att_rate, const float* action, float* params, float* integ_ptr, float* reward,
+                                                   int32_t n_envs, int32_t ld_envs, const Args a_in) {
+  // (like step_kernel: what the first loads need arrives in preloaded SGPRs, the rest is read from the kernarg segment where it is used)
+#if defined(__HIP_DEVICE_COMPILE__)
+  const Args& a = *reinterpret_cast<const Args*>(reinterpret_cast<const char*>(__builtin_amdgcn_kernarg_segment_ptr()) + kArgsOffset);
+  (void)a_in;
+#else
+  const Args& a = a_in;
+#endif
   using KT = KindTraits<KIND>;
   constexpr int A = KT::A, D0 = KT::D0, D1 = KT::D1, NAG = KT::NAG;
+  // the output pointers, read with the wave's first scalar loads (not at the very end, where a scalar-cache miss on the kernarg
+  // segment would hold the wave's registers: the plain step kernel does the same, quadrotor_kernels.hip "done_ptr")
+  uint8_t* const done_ptr = a.done;
+  float* const obs0_ptr = a.obs0;
+  float* const obs1_ptr = KT::D1 > 0 ? a.obs1 : nullptr;
+  float* const goal_ptr = KIND != QR_KIND_QUAD ? a.goal : nullptr;
   const unsigned first = blockIdx.x * 64u, lane = threadIdx.x;
-  const int rows = min((int)(a.n - (int64_t)first), 64);
+  const int rows = min(n_envs - (int)first, 64);
   const unsigned ll = min(lane, (unsigned)(rows - 1));
   const bool active = (int)lane < rows;
-  const SoA<XV> pv(a.pos_vel, 6, a.ld);
-  const SoA<QW> ar(a.att_rate, 6, a.ld);
-  const SoA<float> prm(a.params, 6, a.ld), integ(a.integ, 8, a.ld), goal(a.goal, 12, a.ld);
-  XV x[6]; QW q[6]; float ig[8];
+  const SoA<XV> pv(pos_vel, 6, ld_envs);
+  const SoA<QW> ar(att_rate, 6, ld_envs);
+  const SoA<float> prm(params, 6, ld_envs), integ(integ_ptr, 8, ld_envs), goal(goal_ptr, 12, ld_envs);
+  XV x[6]; QW q[6]; float ig[8], pr[6], ac[A > 4 ? A : 4], gl[12];
   float s = 0.0f;
+  // every load of the wave is issued before anything waits (one batch, like the step kernel's prologue)
 #pragma unroll
   for (int f = 0; f < 6; ++f) q[f] = ar.load(f, first, ll);
 #pragma unroll
   for (int f = 0; f < 6; ++f) x[f] = pv.load(f, first, ll);
 #pragma unroll
-  for (int f = 0; f < 6; ++f) s += prm.load(f, first, ll);
-  const float* abase = a.action + (int64_t)first * A;
+  for (int f = 0; f < 6; ++f) pr[f] = prm.load(f, first, ll);
+  const float* abase = action + (int64_t)first * A;
   if constexpr (A == 4) {
     const float4 v = reinterpret_cast<const float4*>(abase)[ll];
-    s += (v.x + v.y) + (v.z + v.w);
+    ac[0] = v.x; ac[1] = v.y; ac[2] = v.z; ac[3] = v.w;
   } else {
 #pragma unroll
-    for (int j = 0; j < A; ++j) s += abase[ll * A + j];
+    for (int j = 0; j < A; ++j) ac[j] = abase[ll * A + j];
   }
+  const bool has_goal = KIND != QR_KIND_QUAD && goal_ptr != nullptr;
   if constexpr (KIND != QR_KIND_QUAD) {
 #pragma unroll
     for (int f = 0; f < 8; ++f) ig[f] = integ.load(f, first, ll);
-    if (a.goal) {
+    if (has_goal) {
 #pragma unroll
-      for (int f = 0; f < 12; ++f) s += goal.load(f, first, ll);
+      for (int f = 0; f < 12; ++f) gl[f] = goal.load(f, first, ll);
+    } else {
+#pragma unroll
+      for (int f = 0; f < 12; ++f) gl[f] = 0.0f;
     }
   }
+  asm volatile("" ::"s"(done_ptr), "s"(obs0_ptr), "s"(obs1_ptr));   // (the scalar batch is waited for HERE: behind the vector loads' issue)
+  // (pinned: left alone, the compiler sinks the state loads into the `active` block below, BEHIND the wait for the parameter and
+  // action loads — two dependent round trips per wave instead of one batch: 28.7 instead of 24.7 us at 1 M envs)
+#pragma unroll
+  for (int f = 0; f < 6; ++f) asm volatile("" : "+v"(q[f]), "+v"(x[f]), "+v"(pr[f]));
+#pragma unroll
+  for (int j = 0; j < A; ++j) asm volatile("" : "+v"(ac[j]));
+  if constexpr (KIND != QR_KIND_QUAD) {
+#pragma unroll
+    for (int f = 0; f < 8; ++f) asm volatile("" : "+v"(ig[f]));
+#pragma unroll
+    for (int f = 0; f < 12; ++f) { asm volatile("" : "+v"(gl[f])); s += gl[f]; }
+  }
+#pragma unroll
+  for (int f = 0; f < 6; ++f) s += pr[f];
+#pragma unroll
+  for (int j = 0; j < A; ++j) s += ac[j];
   s = s * 0.0f;  // (0 for finite inputs; not foldable without fast-math, so the loads stay)
   if (active) {
 #pragma unroll
@@ -1328,10 +1364,10 @@ __global__ __launch_bounds__(64) void touch_kernel(const Args a) {
 #pragma unroll
       for (int f = 0; f < 8; ++f) integ.store(f, first, lane, ig[f]);
     }
-    if constexpr (NAG == 1) a.reward[first + lane] = s;
-    else reinterpret_cast<float2*>(a.reward)[first + lane] = make_float2(s, s);
-    if constexpr (NAG == 1) a.done[first + lane] = 0;
-    else reinterpret_cast<uchar2*>(a.done)[first + lane] = make_uchar2(0, 0);
+    if constexpr (NAG == 1) reward[first + lane] = s;
+    else reinterpret_cast<float2*>(reward)[first + lane] = make_float2(s, s);
+    if constexpr (NAG == 1) done_ptr[first + lane] = 0;
+    else reinterpret_cast<uchar2*>(done_ptr)[first + lane] = make_uchar2(0, 0);
   }
   auto rows_out = [&](float* base, int D) {  // the tile's rows as they lie in memory: 16-byte stores, like lds_to_rows
     if (base == nullptr) return;
@@ -1342,8 +1378,8 @@ __global__ __launch_bounds__(64) void touch_kernel(const Args a) {
       for (int idx = (int)lane; idx < rows * D; idx += 64) g[idx] = s;
     }
   };
-  rows_out(a.obs0, D0);
-  if constexpr (D1 > 0) rows_out(a.obs1, D1);
+  rows_out(obs0_ptr, D0);
+  if constexpr (D1 > 0) rows_out(obs1_ptr, D1);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1698,13 +1734,15 @@ static void launch_error_obs(const Args& a, int kind, unsigned grid, hipStream_t
 }
 template <typename XV, typename QW>
 static void launch_touch(const Args& a, int kind, unsigned grid, hipStream_t s) {
+#define QR_TOUCH_ARGS a.pos_vel, a.att_rate, a.action, a.params, a.integ, a.reward, (int32_t)a.n, (int32_t)a.ld, a
 #ifdef QR_ONLY_KIND
-  hipLaunchKernelGGL((touch_kernel<QR_ONLY_KIND, XV, QW>), dim3(grid), dim3(64), 0, s, a);
+  hipLaunchKernelGGL((touch_kernel<QR_ONLY_KIND, XV, QW>), dim3(grid), dim3(64), 0, s, QR_TOUCH_ARGS);
   return;
 #endif
-  if (kind == QR_KIND_QUAD) hipLaunchKernelGGL((touch_kernel<QR_KIND_QUAD, XV, QW>), dim3(grid), dim3(64), 0, s, a);
-  else if (kind == QR_KIND_COUPLED) hipLaunchKernelGGL((touch_kernel<QR_KIND_COUPLED, XV, QW>), dim3(grid), dim3(64), 0, s, a);
-  else hipLaunchKernelGGL((touch_kernel<QR_KIND_DECOUPLED, XV, QW>), dim3(grid), dim3(64), 0, s, a);
+  if (kind == QR_KIND_QUAD) hipLaunchKernelGGL((touch_kernel<QR_KIND_QUAD, XV, QW>), dim3(grid), dim3(64), 0, s, QR_TOUCH_ARGS);
+  else if (kind == QR_KIND_COUPLED) hipLaunchKernelGGL((touch_kernel<QR_KIND_COUPLED, XV, QW>), dim3(grid), dim3(64), 0, s, QR_TOUCH_ARGS);
+  else hipLaunchKernelGGL((touch_kernel<QR_KIND_DECOUPLED, XV, QW>), dim3(grid), dim3(64), 0, s, QR_TOUCH_ARGS);
+#undef QR_TOUCH_ARGS
 }
 template <typename XV, typename QW>
 static void launch_reset(const Args& a, unsigned grid, hipStream_t s) {

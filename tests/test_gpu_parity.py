@@ -790,18 +790,20 @@ def test_in_launch_reset_pool_distribution():
     assert np.abs(_np(env.integ)[:, [0, 1, 2, 6]]).max() < 0.05         # integrators restarted (advanced once by the first obs)
 
 
-@pytest.mark.parametrize("kind", KINDS)
-def test_production_mode_1000_steps_every_episode_vs_oracle(kind):
+@pytest.mark.parametrize("kind,substeps", [(k, 1) for k in KINDS] + [("quad", 10), ("decoupled", 4)])
+def test_production_mode_1000_steps_every_episode_vs_oracle(kind, substeps):
     """The mode a training loop runs (default layout, 1 substep, in-launch auto-reset, random
     actions): 512 envs x 1000 steps, ~5000 complete episodes.  The oracle steps every env from its
     own state and only adopts the GPU's freshly sampled state when an episode ends, so the error of
     every env is followed through every whole episode; rewards and done flags are compared at
-    every step including the terminal one."""
+    every step including the terminal one.  Also with 10 substeps (BASELINE.json configs[4]'s mode) and 4:
+    within one env-step the substeps' increments are summed in float32 and the float64 state takes
+    them once — the error must not grow with the substep count."""
     n, T = 512, 1000
     rng = np.random.default_rng(4242 + KINDS.index(kind))
     A = orc.ACTION_DIM[kind]
-    env = _env(kind, n, seed=31, auto_reset=True, obs_rows=True)
-    assert env.layout == "mixed" and env.substeps == 1
+    env = _env(kind, n, seed=31, auto_reset=True, obs_rows=True, substeps=substeps)
+    assert env.layout == "mixed" and env.substeps == substeps
     env.reset("train")
     if kind != "quad":
         env.get_norm_error_state()
@@ -830,7 +832,7 @@ def test_production_mode_1000_steps_every_episode_vs_oracle(kind):
             if kind != "quad":
                 integ[adopt] = _np(env.integ)[adopt]
             episodes += int(ended.sum())
-    print(f"production mode {kind}: {episodes} episodes, worst in-episode state error {worst_state:.2e}, reward {worst_rwd:.2e}, threshold ties {ties}")
+    print(f"production mode {kind} x{substeps}: {episodes} episodes, worst in-episode state error {worst_state:.2e}, reward {worst_rwd:.2e}, threshold ties {ties}")
     assert episodes > 2000 and ties <= 3
     assert worst_state <= 2e-6 and worst_rwd <= 2e-5
 
