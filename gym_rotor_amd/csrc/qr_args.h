@@ -93,6 +93,10 @@ struct Args {
   int32_t dry_run;        // qr_check_state: set_state_kernel validates and counts, writes nothing
   int32_t tile_base;      // multi-step helper launches split into chunks of resident tiles: the first tile of this launch (else 0)
   Coeffs c;
+#ifdef QR_SPAN            // diagnostic build (tools/span_timeline.py); BEHIND the coefficient block: the product's kernarg layout is untouched
+  unsigned long long* span_buf;  // [slots][2 * tiles][2] clock stamps (NULL: none)
+  int32_t span_slot;      // which row of the span buffer this launch writes (-1: none)
+#endif
 };
 
 // Cache policy of the step kernel's stores (gfx940+ aux bits of the buffer / global stores: 1 = sc0, 2 = nt, 16 = sc1; ONE value

@@ -176,16 +176,21 @@ __device__ __forceinline__ void integrate(T (&x)[3], T (&v)[3], T (&q)[4], T (&W
 
 // ------------------------------------------------------------------------------------
 // The default (`mixed`) layout: x, v float32; q, W float64.  Which arithmetic needs float64?
-//   * W: its increments are large (|W'| up to ~120 rad/s^2 from the torques, ~500 from the
-//     gyroscopic term in a tumbling free run) and every error in W is integrated once more into
-//     q.  W1, W2 are therefore integrated by RK4 in float64 — cheap, because W3' = M3/J3 is
-//     constant over the step (zero-order-hold torque, J1 = J2), so W3(t) is linear in time,
-//     drops out of the RK4 vector and turns the W1-W2 system into a linear one with a known
-//     time-varying coefficient a(t) = A1 W3(t).
+//   * W: its increments are large (|W'| up to ~120 rad/s^2 from the torques) and every error in W is integrated once more into q.
+//     W3' = M3/J3 is constant over the step (zero-order-hold torque, J1 = J2), so W3(t) is linear in time, drops out of the RK4
+//     vector and turns the W1-W2 system into a linear one with a known coefficient a(t) = A1 W3(t):
+//         W1' = a(t) W2 + U1,   W2' = -a(t) W1 + U2.
+//     The TORQUE part of the increment (dt U, the large one) is taken in float64, exactly.  The gyroscopic COUPLING part — RK4 of
+//     a(t) (W2, -W1), at most ~22 rad/s^2 in regime — comes out of the float32 stage chain the quaternion needs anyway and is
+//     accumulated like q (round 6; rounds at ~7e-7 rad/s^2 per stage, i.e. ~3e-9 rad/s per step).  Rounds 2-5 ran the whole
+//     W1-W2 RK4 in float64: 24 float64 instructions per substep instead of none (profiles/r06/ab_w_coupling.txt: 1 M envs x 10
+//     substeps 60.3 -> 53.2 us, 131 072 x 10 10.1 -> 8.7, one substep unchanged; production-mode error 1.42-1.56e-6 either way).
+//     The launches WITHOUT in-launch resets, whose envs can leave the regime (|W| to 30 rad/s), keep float64 for W: integrate_delta.
 //   * q: only its ACCUMULATION.  The increment dq = h/6 (k1 + 2 k2 + 2 k3 + k4) is ~|W| h / 2 <= 0.1,
 //     so forming the stage quaternions and derivatives in float32 (from the float32-rounded
-//     substep-start q and float32 copies of the stage rates) perturbs q by ~1e-9 per step,
-//     pseudo-randomly; the float64 state absorbs the increments exactly.
+//     step-start q and float32 copies of the stage rates) perturbs q by ~1e-9 per step,
+//     pseudo-randomly; the float64 state absorbs the step's increment exactly.  Within ONE env-step the substeps' increments
+//     are summed in float32 (<= 16 terms of <= 0.016: ~4e-9 per step) and the float64 state takes the sum once.
 //   * x, v are float32 in memory already; their increments are quadratures of the thrust
 //     direction R(q) e3 over the stages, linear in it, so the stage sums are simply accumulated
 //     over all substeps (float32) and applied once.
@@ -197,32 +202,19 @@ __device__ __forceinline__ void integrate(T (&x)[3], T (&v)[3], T (&q)[4], T (&W
 // (Measured and NOT adopted, profiles/r02/ab_quad_builds.txt column q_pk: the quaternion stages on v_pk_fma_f32 / v_pk_mul_f32 with
 // op_sel / neg swizzles, six packed instructions per derivative — 4.45-4.56 against 4.40-4.47 us per launch at 65 536 envs,
 // 33.7-33.8 against 33.0-33.2 at 1 M: the code is gone, the record stays.)
-#ifndef QR_W_COUPLING_F32
-#define QR_W_COUPLING_F32 1
-#endif
-#ifndef QR_STEP_ACCUM_F32
-#define QR_STEP_ACCUM_F32 1
-#endif
 __device__ __forceinline__ void integrate(float (&x)[3], float (&v)[3], double (&q)[4], double (&W)[3], const Dyn<double>& p, int nsub,
                                           double h) {
   const float hf = (float)h, h2f = 0.5f * hf, h6f = hf * (1.0f / 6.0f);
-  const double h2 = 0.5 * h, h6 = h * (1.0 / 6.0);
+  const double h2 = 0.5 * h;
   // half body rates (q' = q (0, W/2)); a(t) = A1 W3(t) and W3(t)/2 advance by a constant per half substep
-  double a3 = p.A1 * W[2];
-  const double da = p.A1 * p.U3 * h2;
-  float a3f = (float)a3, w3 = 0.5f * (float)W[2];
-  const float daf = (float)da, dw3 = (float)(0.5 * p.U3 * h2);
+  float a3f = (float)(p.A1 * W[2]), w3 = 0.5f * (float)W[2];
+  const float daf = (float)(p.A1 * p.U3 * h2), dw3 = (float)(0.5 * p.U3 * h2);
   const float u1 = (float)(0.5 * p.U1), u2 = (float)(0.5 * p.U2);
   double W1 = W[0], W2 = W[1];
-#if QR_W_COUPLING_F32
-  const float h3f = hf * (1.0f / 3.0f);
-  const double hU1 = h * p.U1, hU2 = h * p.U2;
-  (void)h6; (void)h3f; (void)hU1; (void)hU2;
-#if QR_STEP_ACCUM_F32
+  // running float32 sums of the substeps' increments (see the loop's end): dq; the coupling part of d(W/2); and the torque part of
+  // d(W/2) per substep, for the float32 track of the stage rates
   float dqs[4] = {0.f, 0.f, 0.f, 0.f}, csa = 0.f, csb = 0.f;
-  const float hu1h = (float)(0.5 * hU1), hu2h = (float)(0.5 * hU2);
-#endif
-#endif
+  const float hu1h = (float)(0.5 * h * p.U1), hu2h = (float)(0.5 * h * p.U2);
   float g1[3] = {0.f, 0.f, 0.f}, g23[3] = {0.f, 0.f, 0.f}, g4[3] = {0.f, 0.f, 0.f}, xx[3] = {0.f, 0.f, 0.f};
   // thrust direction, un-normalised: R e3 = (2 u0, 2 u1, 1 - 2 u2), u = (xz + wy, yz - wx, xx + yy)
 #define QR_THRUST(G, Qw, Qx, Qy, Qz)                            \
@@ -243,10 +235,7 @@ __device__ __forceinline__ void integrate(float (&x)[3], float (&v)[3], double (
 #pragma unroll
       for (int j = 0; j < 3; ++j) xx[j] += fmaf(2.0f, g23[j], g1[j] + g4[j]);
     }
-#if QR_W_COUPLING_F32
-    // ---- W1, W2: the torque part of the increment is linear in time and taken in float64 exactly (h U per substep); the gyroscopic
-    // coupling part — RK4 of a(t) (W2, -W1), |a W| <= ~22 rad/s^2 in regime — comes from the float32 stage chain the quaternion
-    // needs anyway and is ACCUMULATED in float64 (like q).  18 float64 instructions less per substep, 16 float32 more. ----
+    // ---- stage rates in float32 (half units); c = the gyroscopic coupling part of W' (k = c + u), summed with RK4's weights ----
     const float b0 = a3f, bm = a3f + daf, b1 = bm + daf;
     const float z0 = w3, zm = w3 + dw3, z1 = zm + dw3;
     float kq[4], acc[4], qt[4];
@@ -278,7 +267,6 @@ __device__ __forceinline__ void integrate(float (&x)[3], float (&v)[3], double (
     QR_QDOT(kq, qt, t1, t2, z1)
     QR_THRUST(g4, qt[0], qt[1], qt[2], qt[3])
     sca = fmaf(b1, t2, sca); scb = fmaf(-b1, t1, scb);
-#if QR_STEP_ACCUM_F32
     // Within ONE env-step every stage quantity is float32 already; so are, here, the running sums of the substeps' increments —
     // the float64 state takes them once, at the end of the step (below).  A sum of <= 16 increments of <= 0.016 (q) / 0.06 (W/2)
     // rounds at ~4e-9 per step, below the float32 stage noise that is there anyway; with ONE substep the result is the same.
@@ -292,70 +280,6 @@ __device__ __forceinline__ void integrate(float (&x)[3], float (&v)[3], double (
     csa += ia; csb += ib;
     w1 += hu1h + ia; w2 += hu2h + ib;             // float32 track of W/2 (re-synchronised every env-step)
     a3f = b1; w3 = z1;
-    const double a1 = a3;   // (the float64 track of a(t) is not needed: a3f carries it)
-#else
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float dq = h6f * (acc[j] + kq[j]);
-      q[j] += (double)dq;   // the float64 state takes the increment exactly
-      qs[j] += dq;          // float32 track for the next substep's stages (re-synchronised every env-step)
-    }
-    // (half units -> full: x 2; h/6 x 2 = h/3)
-    W1 = (W1 + hU1) + (double)(h3f * sca);
-    W2 = (W2 + hU2) + (double)(h3f * scb);
-    const double a1 = a3 + (da + da);
-#endif
-#else
-    // ---- W1, W2 in float64: W1' = a(t) W2 + U1, W2' = -a(t) W1 + U2 ----
-    const double a0 = a3, am = a3 + da, a1 = am + da;
-    const double k1a = fma(a0, W2, p.U1), k1b = fma(-a0, W1, p.U2);
-    double s1 = fma(h2, k1a, W1), s2 = fma(h2, k1b, W2);
-    const double k2a = fma(am, s2, p.U1), k2b = fma(-am, s1, p.U2);
-    s1 = fma(h2, k2a, W1); s2 = fma(h2, k2b, W2);
-    const double k3a = fma(am, s2, p.U1), k3b = fma(-am, s1, p.U2);
-    s1 = fma(h, k3a, W1); s2 = fma(h, k3b, W2);
-    const double k4a = fma(a1, s2, p.U1), k4b = fma(-a1, s1, p.U2);
-    // ---- stage rates in float32 (half units) for the quaternion ----
-    const float b0 = a3f, bm = a3f + daf, b1 = bm + daf;
-    const float z0 = w3, zm = w3 + dw3, z1 = zm + dw3;
-    float kq[4], acc[4], qt[4];
-    // stage 1
-    QR_QDOT(kq, qs, w1, w2, z0)
-    QR_THRUST(g1, qs[0], qs[1], qs[2], qs[3])
-    float ka = fmaf(b0, w2, u1), kb = fmaf(-b0, w1, u2);
-    float t1 = fmaf(h2f, ka, w1), t2 = fmaf(h2f, kb, w2);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { acc[j] = kq[j]; qt[j] = fmaf(h2f, kq[j], qs[j]); }
-    // stage 2
-    QR_QDOT(kq, qt, t1, t2, zm)
-    QR_THRUST(g23, qt[0], qt[1], qt[2], qt[3])
-    ka = fmaf(bm, t2, u1); kb = fmaf(-bm, t1, u2);
-    t1 = fmaf(h2f, ka, w1); t2 = fmaf(h2f, kb, w2);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { acc[j] = fmaf(2.0f, kq[j], acc[j]); qt[j] = fmaf(h2f, kq[j], qs[j]); }
-    // stage 3
-    QR_QDOT(kq, qt, t1, t2, zm)
-    QR_THRUST(g23, qt[0], qt[1], qt[2], qt[3])
-    ka = fmaf(bm, t2, u1); kb = fmaf(-bm, t1, u2);
-    t1 = fmaf(hf, ka, w1); t2 = fmaf(hf, kb, w2);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { acc[j] = fmaf(2.0f, kq[j], acc[j]); qt[j] = fmaf(hf, kq[j], qs[j]); }
-    // stage 4
-    QR_QDOT(kq, qt, t1, t2, z1)
-    QR_THRUST(g4, qt[0], qt[1], qt[2], qt[3])
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float dq = h6f * (acc[j] + kq[j]);
-      q[j] += (double)dq;   // the float64 state takes the increment exactly
-      qs[j] += dq;          // float32 track for the next substep's stages (re-synchronised every env-step)
-    }
-    W1 = fma(h6, fma(2.0, k2a + k3a, k1a + k4a), W1);
-    W2 = fma(h6, fma(2.0, k2b + k3b, k1b + k4b), W2);
-#endif
-    a3 = a1; a3f = b1; w3 = z1;
-#if !(QR_W_COUPLING_F32 && QR_STEP_ACCUM_F32)
-    w1 = 0.5f * (float)W1; w2 = 0.5f * (float)W2;
-#endif
   }
 #undef QR_THRUST
 #undef QR_QDOT
@@ -375,15 +299,13 @@ __device__ __forceinline__ void integrate(float (&x)[3], float (&v)[3], double (
   v[0] = fmaf(-hc3, G[0], v[0]);
   v[1] = fmaf(-hc3, G[1], v[1]);
   v[2] = fmaf(hc3, G[2], fmaf(dtf, gc, v[2]));
-#if QR_W_COUPLING_F32 && QR_STEP_ACCUM_F32
-  {
+  {  // the float64 state takes the step's increments once
     const double dt = h * (double)nsub;
 #pragma unroll
     for (int j = 0; j < 4; ++j) q[j] += (double)dqs[j];
     W1 = fma(dt, p.U1, W1) + 2.0 * (double)csa;   // torque part exact; coupling part from the float32 chain (half units -> x 2)
     W2 = fma(dt, p.U2, W2) + 2.0 * (double)csb;
   }
-#endif
   W[0] = W1; W[1] = W2;
   W[2] = fma(p.U3, h * (double)nsub, W[2]);
 }

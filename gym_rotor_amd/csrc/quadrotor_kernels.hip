@@ -66,7 +66,9 @@ namespace qr {
 // byte offset of the Args block in the step kernel's kernarg segment: 6 pointers + 2 x int32 precede it
 [[maybe_unused]] constexpr int kArgsOffset = 6 * 8 + 2 * 4;
 static_assert(alignof(Args) == 8, "Args follows the leading scalar arguments without padding");
+#ifndef QR_SPAN
 static_assert(sizeof(Coeffs) <= 5 * 64 && offsetof(Args, c) + sizeof(Coeffs) == sizeof(Args), "the step kernel touches the five kernarg lines of the coefficient block (the last field of Args)");
+#endif
 
 // QR_STAMPS: diagnostic build (tools/stamp_timeline.py).  Every wave records the 100 MHz real-time clock at
 // seven points of the step; the values go to a buffer of their own that nothing else reads.
@@ -107,6 +109,44 @@ __device__ unsigned long long* g_hwid = nullptr;
 #define QR_HSTAMP(k, dep) do { } while (0)
 #define QR_PSTAMP(k, dep) do { } while (0)
 #define QR_HWID() do { } while (0)
+#endif
+
+// QR_SPAN: the light diagnostic build (tools/span_timeline.py).  Every wave records the 100 MHz real-time clock twice — with its first
+// instruction and behind its last — into row `span_slot` of a buffer of its own; a chain of launches with slots 0, 1, 2, ... then
+// shows, on the device's own clock, each launch's SPAN (first wave in to last wave out) and the GAP to the next launch.  Two scalar
+// memory-time reads per wave and one 16-byte store at the very end: the build runs within a few per cent of the product's period
+// (the seven-stamp QR_STAMPS build: +50 %), which is what makes span + gap a usable clock for kernels rocprofv3 inflates.
+#ifdef QR_SPAN
+static unsigned long long* g_span_buf = nullptr;  // (host) the stamp buffer and the row the next launches write: qr_debug_set_span[_slot]
+static int g_span_slot = -1;
+// Buffer pointer and row come with the launch's own kernarg.  A clock read is a scalar
+// memory operation whose result lands asynchronously: it is WAITED FOR on the spot (the compiler knows nothing of the pending
+// write and would otherwise reuse the register pair), which costs its wave ~0.3 us.  So only a sample of the waves pays:
+//   ENTRY stamps: the first eight workgroups (one per XCD; the dispatcher starts with them) — a launch's "first wave in";
+//   EXIT stamps: the workgroups of every fourth tile, spread over the XCDs — a launch's "last wave out" is then a stamped one in
+//   a quarter of the launches, and the chain's MEDIAN period stays within ~1 % of the product's.
+// (buffer pointer and row are read from the kernarg segment by the stamped waves only, at their end and BEHIND the clock read: one more
+// kernarg line requested at the kernel's start would sit in every wave's first scalar wait — 0.3 us per launch)
+#define QR_SPAN_BEGIN()                                                  \
+  unsigned long long span_t0_ = 0;                                       \
+  if (blockIdx.x < 8u) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(span_t0_) : : "memory")
+#define QR_SPAN_END()                                                                                          \
+  do {                                                                                                         \
+    const bool exit_ = (((blockIdx.x >> 3) + blockIdx.x) & 3u) == 0u;                                          \
+    if (exit_ || blockIdx.x < 8u) {                                                                            \
+      unsigned long long t1_ = 0;                                                                              \
+      if (exit_) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) : : "memory");            \
+      unsigned long long* const span_buf_ = ka.span_buf;                                                       \
+      const int span_slot_ = ka.span_slot;                                                                     \
+      if (span_buf_ != nullptr && span_slot_ >= 0 && (threadIdx.x & 63u) == 0) {                               \
+        const size_t w_ = ((size_t)span_slot_ * (((unsigned)n_envs + 63u) >> 6) + blockIdx.x) * 2 + (threadIdx.x >> 6); \
+        span_buf_[2 * w_] = span_t0_; span_buf_[2 * w_ + 1] = t1_;                                             \
+      }                                                                                                        \
+    }                                                                                                          \
+  } while (0)
+#else
+#define QR_SPAN_BEGIN() do { } while (0)
+#define QR_SPAN_END() do { } while (0)
 #endif
 
 #ifndef QR_STEP_PRIO
@@ -267,6 +307,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
 #else
   const Args& ka = a_in;  // (host pass of the single-source compile: never executed)
 #endif
+  QR_SPAN_BEGIN();
   Args a;  // the fields the helpers touch, assembled from the preloaded scalars
   a.pos_vel = pos_vel; a.att_rate = att_rate; a.action = action; a.params = params; a.integ = integ;
   a.reset_count = reset_count;
@@ -430,6 +471,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         asm volatile("s_barrier" ::: "memory");  // the tile of the last step
         lds_to_rows<B, D0, AUX>(ob0 + ((int64_t)(hsteps - 1) * n_envs + first) * D0, smem, hl, rows);
         if constexpr (KT::D1 > 0) lds_to_rows<B, D1, AUX>(ob1 + ((int64_t)(hsteps - 1) * n_envs + first) * D1, smem1, hl, rows);
+        QR_SPAN_END();
         return;
       }
       if constexpr (!SINGLE) {  // a rollout: one pool per env-step, each handed over at that step's barrier
@@ -453,6 +495,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
           lds_to_rows<B, D0, AUX>(hob0 + ((int64_t)(hsteps - 1) * n_envs + first) * D0, rtile0 + ((hsteps - 1) & 1) * (B * D0), hl, rows);
           if constexpr (KT::D1 > 0) lds_to_rows<B, D1, AUX>(hob1 + ((int64_t)(hsteps - 1) * n_envs + first) * D1, rtile1 + ((hsteps - 1) & 1) * (B * D1), hl, rows);
         }
+        QR_SPAN_END();
         return;
       }
       QR_HSTAMP(1, hrole.off[0] + (float)rc);
@@ -471,6 +514,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
           if constexpr (KT::D1 > 0) lds_to_rows<B, D1, AUX>(hob1 + first * D1, smem1, hl, rows);
         }
       }
+      QR_SPAN_END();
       return;
     }
   }
@@ -1089,6 +1133,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
     a.reset_count[tile_id] = (int32_t)(rcount_s + (uint32_t)n_steps);  // never reuse a (tile, counter)
   }
   QR_STAMP(6, tid);
+  QR_SPAN_END();
 }
 
 // get_norm_error_state on the current state (quad.py:421-466)
@@ -1811,6 +1856,9 @@ static int do_rollout(const QrEnv* env, const float* action, const QrPolicyRollo
   a.action = action; a.obs0 = out->obs0; a.obs1 = out->obs1; a.final_obs0 = out->final_obs0; a.final_obs1 = out->final_obs1;
   a.reward = out->reward; a.reward_raw = out->reward_raw; a.done = out->done; a.truncated = out->truncated;
   a.n_steps = n_steps; a.substeps = substeps;
+#ifdef QR_SPAN
+  a.span_slot = g_span_slot; a.span_buf = g_span_buf;
+#endif
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = 0;
   QR_DISPATCH_LAYOUT(env->layout, (rc = launch_step<XV, QW>(a, env->kind, s)));
@@ -1820,6 +1868,14 @@ static int do_rollout(const QrEnv* env, const float* action, const QrPolicyRollo
 }  // namespace qr
 
 extern "C" {
+
+#ifdef QR_SPAN
+int qr_debug_set_span(void* buf) {  // diagnostic build only: device buffer [slots][2 * tiles][2] of uint64 (NULL = off) for the NEXT launches
+  qr::g_span_buf = reinterpret_cast<unsigned long long*>(buf);
+  return 0;
+}
+void qr_debug_set_span_slot(int slot) { qr::g_span_slot = slot; }  // the row the NEXT launches write (baked into a captured launch)
+#endif
 
 #ifdef QR_STAMPS
 int qr_debug_set_stamps(void* buf) {  // diagnostic builds only: device buffer of 8 x uint64 per wave (NULL = off)

@@ -32,6 +32,14 @@ prof rollout_actor_coupled65536_T32 --workload rollout_actor --kind coupled --ho
 prof rollout_actor_sac_coupled65536_T32 --workload rollout_actor --kind coupled --horizon 32 --steps 960 --actor sac
 prof rollout_coupled65536_T100 --workload rollout --kind coupled --horizon 100 --steps 1000
 prof rollout_actor_coupled262144_T32 --workload rollout_actor --kind coupled --envs 262144 --horizon 32 --steps 320
+# the do-nothing kernel (qr_touch) under the same tool: what rocprofv3 reports for a kernel that only moves the step's bytes
+prof touch_quad65536 --workload touch --steps 500
+prof touch_quad1M --workload touch --envs 1048576 --action-batches 16 --steps 100
+# kernel span + launch gap on the device's own clock (the profile clock of the kernels rocprofv3 inflates): the light stamp build
+make -C gym_rotor_amd/csrc span-lib > "$OUT/span_lib_build.log" 2>&1
+SPAN_CFGS="quad:65536:1 coupled:65536:1 decoupled:32768:1 quad:131072:10 quad:131072:1 quad:1048576:1 decoupled:262144:1 quad:65536:1:rollout:100 coupled:65536:1:rollout_actor:32"
+QR_LIB=$PWD/build/ab/libquadrotor_hip_span.so python3 tools/span_timeline.py --json "$OUT/span_timeline.json" $SPAN_CFGS > /dev/null 2> "$OUT/span_timeline.txt"
+python3 tools/span_timeline.py --json "$OUT/span_product_hip_events.json" $SPAN_CFGS > /dev/null 2> "$OUT/span_product_hip_events.txt"
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
 # (2) the bench lines themselves (un-profiled)
@@ -53,6 +61,8 @@ b config2 --config 2 ; b config3 --config 3 ; b config4 --config 4
 python3 bench.py > "$OUT/bench_full_line.json" 2>> "$OUT/bench.err"
 python3 bench.py --steps 20 --warmup 5 > "$OUT/bench_full_line_steps20.json" 2>> "$OUT/bench.err"
 python3 tools/eager_cost.py > "$OUT/eager_cost.json" 2>> "$OUT/bench.err"
+b f64_quad65536 --layout f64 ; b f64_coupled65536 --layout f64 --kind coupled ; b f64_quad1M --layout f64 --envs 1048576 --action-batches 16 --steps 300
+python3 tools/noop_yardstick.py > "$OUT/noop_yardstick.json" 2> "$OUT/noop_yardstick.err"
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = ab ]; then
 # (3) build-time ablations (A/B of libraries), run-time A/B, timelines, microbenchmarks
@@ -73,5 +83,7 @@ if [ "$WHAT" = all ] || [ "$WHAT" = tests ]; then
 # (4) the parity figures the GPU tests print, and the soak run of the final build
 python3 -m pytest tests -q -m gpu -s 2>&1 | grep -E "[0-9]e-[0-9]|passed|failed" | cut -c1-400 > "$OUT/parity_summary.txt"
 python3 tools/soak.py 100000 > "$OUT/soak.json" 2> "$OUT/soak.err"
+python3 tools/make_digest.py "$OUT/digest_gfx950.json" > /dev/null 2> "$OUT/digest.err"
+cp gpurun_out/launch_stats_*.json "$OUT/" 2>/dev/null
 fi
 ls "$OUT"
