@@ -27,6 +27,13 @@ CONFIGS = [  # summary file -> (kind, envs, layout, auto_reset, substeps[, workl
     ("rollout_quad65536_T100_summary.txt", "quad", 65536, "mixed", True, 1, "rollout", 100),
     ("rollout_actor_coupled65536_T32_summary.txt", "coupled", 65536, "mixed", True, 1, "rollout_actor", 32),
 ]
+# kernel span + launch gap on the device's own clock (tools/span_timeline.py, the QR_SPAN build), per configuration: the profile clock
+# of the kernels rocprofv3 inflates (shorter than ~6 us: an empty kernel reads 4.3-4.8 us under the tool, qr_touch 5.4 instead of 2.6)
+SPAN = {}
+sp = os.path.join(ROOT, "profiles", RND, "span_timeline.json")
+if os.path.exists(sp):
+    for r in json.load(open(sp))["rows"]:
+        SPAN[(r["kind"], r["envs"], r["substeps"], r["workload"], r["env_steps_per_launch"])] = r
 out = []
 for cfg in CONFIGS:
     fn, kind, envs, layout, ar, sub = cfg[:6]
@@ -81,6 +88,16 @@ for cfg in CONFIGS:
             v["valu_active_frac"] = round(act * 4 / (1024 * dur_s * 2.4e9), 4)
         v["issue_slots_used_frac_note"] = ("issue_slots_used_frac prices an instruction at 2 clocks (the packed-fp32 peak) and UNDERCOUNTS: see "
                                            "valu_time_frac_microbench / valu_active_frac")
+    span = SPAN.get((kind, envs, sub, workload, horizon)) if (ar and layout == "mixed") else None
+    if span:
+        prof["kernel_span_us"], prof["launch_gap_us"] = round(span["span_us_median"], 3), round(span["gap_us_median"], 3)
+        prof["span_build_period_us"] = round(span["period_us_median"], 3)
+    # ONE profile clock per configuration (bench.py: roofline.profile_period_us / frac_profile_clock): rocprofv3's kernel duration where
+    # the tool does not inflate it (>= 6 us: it then equals the launch-to-launch period), else the stamp build's span + gap
+    if ka and int(ka.group(1)) >= 6000:
+        prof["profile_period_us"], prof["profile_clock"] = int(ka.group(1)) / 1e3, "rocprofv3 --kernel-trace mean kernel duration"
+    elif span:
+        prof["profile_period_us"], prof["profile_clock"] = prof["span_build_period_us"], "QR_SPAN build: kernel span + launch gap (device real-time clock)"
     out.append({**prof, "kind": kind, "envs": envs, "layout": layout, "auto_reset": ar, "substeps": sub, "workload": workload,
                 "env_steps_per_launch": horizon, "FETCH_SIZE_KB_raw": fetch,
                 "WRITE_SIZE_KB": write, "bytes_per_launch": b, "bytes_per_env_step": round(b / envs / horizon, 1),
