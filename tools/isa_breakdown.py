@@ -42,7 +42,7 @@ if not elf:
                     f"--output={elf}"], check=True)
 
 # the instantiation's symbol
-want = f"step_kernelILi{a.kind}EfdLi64ELi{traj}ELb{adapt}ELi{policy}ELb{single}ELb{helpw}EE"
+want = f"step_kernelILi{a.kind}EfdLi64ELi{traj}ELb{adapt}ELi{policy}ELb{single}ELb{helpw}ELb1EE"   # (..., HREW = true)
 syms = subprocess.run([f"{LLVM}/llvm-objdump", "-t", elf], capture_output=True, text=True, check=True).stdout
 sym = None
 for l in syms.splitlines():
