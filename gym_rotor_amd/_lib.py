@@ -19,7 +19,7 @@ FLAG_AUTO_RESET, FLAG_EVAL_RESET, FLAG_NO_UDM = 1, 2, 4
 FLAG_FORCE_HELPER, FLAG_NO_HELPER = 8, 16   # launch-rule overrides of the one-step launch (speed only)
 FLAG_CALLER_RESETS = 32                     # the caller resets every done env before stepping it again (one-step launches)
 FLAG_FORCE_HELPER_ROLLOUT, FLAG_NO_HELPER_ROLLOUT = 64, 128   # the same overrides for qr_rollout / qr_rollout_actor
-ABI_VERSION = 14
+ABI_VERSION = 15
 GOAL_EXTERNAL, GOAL_MODE0, GOAL_MODE1, GOAL_MODE6, GOAL_MODE2, GOAL_MODE3, GOAL_MODE4, GOAL_MODE5 = 0, 1, 2, 3, 4, 5, 6, 7
 GOAL_ID = {None: 0, 0: 1, 1: 2, 6: 3, 2: 4, 3: 5, 4: 6, 5: 7}  # TrajectoryGenerator mode -> QR_GOAL_*
 LAYOUT_ID = {"mixed": 0, "f64": 1, "f32": 2}
@@ -77,7 +77,7 @@ class QrPolicyRollout(C.Structure):
 class QrLaunchPlan(C.Structure):
     _fields_ = [("grid", C.c_int32), ("block", C.c_int32), ("launches", C.c_int32),
                 ("traj", C.c_int32), ("adapt", C.c_int32), ("policy", C.c_int32), ("single", C.c_int32), ("help", C.c_int32), ("hrew", C.c_int32),
-                ("key", C.c_uint32), ("name", C.c_char * 96)]
+                ("mag", C.c_int32), ("key", C.c_uint32), ("name", C.c_char * 96)]
 
 
 class QuadrotorLibError(RuntimeError):
@@ -174,10 +174,10 @@ KIND_NAME = {v: k for k, v in KIND_ID.items()}
 
 
 def describe_key(key: int) -> str:
-    """'layout/kind TRAJ=.. ADAPT=.. POLICY=.. SINGLE=.. HELP=.. HREW=..' of a qr_launch_stats / qr_instance_table key."""
+    """'layout/kind TRAJ=.. ADAPT=.. POLICY=.. SINGLE=.. HELP=.. HREW=.. MAG=..' of a qr_launch_stats / qr_instance_table key."""
     b = key & 0xFF
-    return (f"{LAYOUT_NAME[key >> 16]}/{KIND_NAME[(key >> 8) & 0xFF]} TRAJ={b & 3} ADAPT={(b >> 2) & 1} POLICY={(b >> 3) & 3} "
-            f"SINGLE={(b >> 5) & 1} HELP={(b >> 6) & 1} HREW={(b >> 7) & 1}")
+    return (f"{LAYOUT_NAME[key >> 16]}/{KIND_NAME[(key >> 8) & 0xF]} TRAJ={b & 3} ADAPT={(b >> 2) & 1} POLICY={(b >> 3) & 3} "
+            f"SINGLE={(b >> 5) & 1} HELP={(b >> 6) & 1} HREW={(b >> 7) & 1} MAG={(key >> 12) & 1}")
 
 
 def launch_stats(reset: bool = False) -> dict:

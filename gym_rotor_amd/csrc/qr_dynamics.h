@@ -311,6 +311,145 @@ __device__ __forceinline__ void integrate(float (&x)[3], float (&v)[3], double (
 }
 
 // ------------------------------------------------------------------------------------
+// TWO OR MORE substeps per env-step in the default layout (instantiations MAG = true, picked by the host from `substeps`; round 6,
+// second pass): a 4th-order Lie-group (Magnus) substep instead of RK4's four stages — 74 float32 VALU instructions per substep
+// instead of 149 (tools/numerics_magnus.py is the NumPy emulation against the DOP853 oracle).  What makes it cheap is what the
+// zero-order hold already gave RK4: W3(t) = W3 + U3 t is exact, and w = W1 + i W2 obeys the LINEAR equation w' = -i a(t) w + u with
+// a(t) = A1 W3(t), so
+//   * w(t) over the whole env-step is a Taylor polynomial about the step's start, (k + 1) c_{k+1} = -i (a0 c_k + a' c_{k-1})
+//     (+ u for k = 0), formed ONCE per env-step.  |a| dt <= 0.02 in regime (0.09 at |W3| = 30 rad/s), so degree 4 leaves
+//     (|a| dt)^5 / 120 |w| <= 2e-10 rad/s (emulated with degree 5: no difference; degree 3 is visibly short);
+//   * a substep [t, t + h] needs no stages: with Wm, Wm', Wm'' at its midpoint (the polynomial, then the equation itself)
+//         Theta = h Wm + h^3/24 Wm'' + h^3/12 (Wm x Wm')        (Magnus terms 1 and 2 about the midpoint: local error O(h^5))
+//         q <- q (x) exp(Theta / 2),   taken as the INCREMENT q (x) (cos - 1, sin ...) so that float32 only rounds terms <= 0.016;
+//   * the thrust direction u(q) at the substep BOUNDARIES only: the integrals for v and x by the trapezoid rule plus the
+//     Euler-Maclaurin end correction h^2/12 (g'(0) - g'(dt)) — the interior derivative terms telescope, so ONE u per substep and
+//     u' = (R (W x e3))-terms at the two ends of the env-step (error O(dt h^4), any substep count).
+// Precision bookkeeping as in RK4 above: every per-substep quantity float32, the substeps' increments of q summed in float32, the
+// float64 state updated once per env-step, the torque part of dW (dt U) exact in float64 and only the coupling part
+// C(dt) = w(dt) - w0 - u dt from the float32 polynomial.  Emulated against DOP853, x and v kept float64 between steps (the
+// integrator's own error, in regime): 1.3e-7 / 7.9e-9 at 1 / 2 substeps against RK4's 2.2e-7 / 1.4e-8; with the float32 storage both
+// sit at 1.4-1.5e-6.
+// Why ONE substep keeps RK4 although this is 100 instructions shorter there too: its instructions depend on one another.  A lone
+// wave pays 3.6-3.9 ns for a vector instruction that waits for the one before it and 2.0-2.3 ns for an independent one
+// (tools/valu_ilp_microbench.hip, profiles/r06/valu_ilp_microbench.json); RK4's four quaternion components are four chains side by
+// side, the Magnus substep is one.  Measured with this code on every substep count: the 65 536-env step +2.1 %, the fused rollout
+// +9.3 % (one stepping wave per SIMD: latency binds), 1 M x 10 substeps -22 %, 131 072 x 10 -17 % (issue binds): profiles/r06/ab_magnus.txt.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void integrate_magnus(float (&x)[3], float (&v)[3], double (&q)[4], double (&W)[3], const Dyn<double>& p,
+                                                 int nsub, double h) {
+  const float hf = (float)h, hh = 0.5f * hf;     // Theta / 2 directly: half units
+  const float h3 = hf * hf * hf, kdd = h3 * (1.0f / 48.0f), kcr = h3 * (1.0f / 24.0f);
+  const float a0 = (float)(p.A1 * W[2]), ad = (float)(p.A1 * p.U3);
+  const float U1 = (float)p.U1, U2 = (float)p.U2, U3 = (float)p.U3, w3_0 = (float)W[2];
+  // Taylor coefficients of w(t); (-i)(zr + i zi) = zi - i zr.  k1 = the coupling part of c1 (c1 = k1 + u).
+  const float c0r = (float)W[0], c0i = (float)W[1];
+  const float k1r = a0 * c0i, k1i = -(a0 * c0r);
+  const float c1r = fmaf(a0, c0i, U1), c1i = fmaf(-a0, c0r, U2);
+  float zr = fmaf(a0, c1r, ad * c0r), zi = fmaf(a0, c1i, ad * c0i);
+  const float c2r = 0.5f * zi, c2i = -0.5f * zr;
+  zr = fmaf(a0, c2r, ad * c1r); zi = fmaf(a0, c2i, ad * c1i);
+  const float c3r = (1.0f / 3.0f) * zi, c3i = (-1.0f / 3.0f) * zr;
+  zr = fmaf(a0, c3r, ad * c2r); zi = fmaf(a0, c3i, ad * c2i);
+  const float c4r = 0.25f * zi, c4i = -0.25f * zr;
+  float qs[4], dqs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) qs[j] = (float)q[j];
+  // Thrust direction, un-normalised: R e3 = (2 u0, 2 u1, 1 - 2 u2), u = (xz + wy, yz - wx, xx + yy); its rate along the flow,
+  // R (W x e3) = W2 b1 - W1 b2 (b1, b2: columns of R), in the same convention: ud = (b3'_0 / 2, b3'_1 / 2, -b3'_2 / 2).
+#define QR_UVEC_ACC(Gv)                                          \
+  Gv[0] = fmaf(qs[1], qs[3], fmaf(qs[0], qs[2], Gv[0]));         \
+  Gv[1] = fmaf(qs[2], qs[3], fmaf(-qs[0], qs[1], Gv[1]));        \
+  Gv[2] = fmaf(qs[1], qs[1], fmaf(qs[2], qs[2], Gv[2]));
+#define QR_UDOT(UD, HW1, HW2) /* HW = W / 2 */                                                  \
+  {                                                                                             \
+    const float xy = qs[1] * qs[2];                                                             \
+    const float n1 = fmaf(-2.0f, fmaf(qs[2], qs[2], qs[3] * qs[3]), 1.0f);   /* b1_0 */         \
+    const float n2_ = fmaf(-2.0f, fmaf(qs[1], qs[1], qs[3] * qs[3]), 1.0f);  /* b2_1 */         \
+    UD[0] = fmaf(HW2, n1, -2.0f * (HW1 * fmaf(-qs[0], qs[3], xy)));                             \
+    UD[1] = fmaf(-HW1, n2_, 2.0f * (HW2 * fmaf(qs[0], qs[3], xy)));                             \
+    UD[2] = 2.0f * fmaf(HW1, fmaf(qs[2], qs[3], qs[0] * qs[1]), -(HW2 * fmaf(qs[1], qs[3], -(qs[0] * qs[2])))); \
+  }
+  float u0[3] = {0.f, 0.f, 0.f}, ud0[3], G[3], XX[3] = {0.f, 0.f, 0.f};
+  QR_UVEC_ACC(u0)
+  QR_UDOT(ud0, 0.5f * c0r, 0.5f * c0i)
+#pragma unroll
+  for (int j = 0; j < 3; ++j) G[j] = u0[j];
+  float tm = hh;                                  // the substep's midpoint
+  for (int s = 0; s < nsub; ++s) {
+    const float W1m = fmaf(tm, fmaf(tm, fmaf(tm, fmaf(tm, c4r, c3r), c2r), c1r), c0r);
+    const float W2m = fmaf(tm, fmaf(tm, fmaf(tm, fmaf(tm, c4i, c3i), c2i), c1i), c0i);
+    const float W3m = fmaf(U3, tm, w3_0), am = fmaf(ad, tm, a0);
+    const float d1 = fmaf(am, W2m, U1), d2 = fmaf(-am, W1m, U2);             // Wm'
+    const float e1 = fmaf(ad, W2m, am * d2), e2 = fmaf(ad, W1m, am * d1);    // Wm'' = (e1, -e2, 0)
+    const float cx = fmaf(W2m, U3, -(W3m * d2)), cy = fmaf(W3m, d1, -(W1m * U3)), cz = fmaf(W1m, d2, -(W2m * d1));
+    const float t1 = fmaf(kcr, cx, fmaf(kdd, e1, hh * W1m));
+    const float t2 = fmaf(kcr, cy, fmaf(-kdd, e2, hh * W2m));
+    const float t3 = fmaf(kcr, cz, hh * W3m);
+    const float n2 = fmaf(t1, t1, fmaf(t2, t2, t3 * t3));
+    const float sn = fmaf(n2, fmaf(n2, 1.0f / 120.0f, -1.0f / 6.0f), 1.0f);  // sin|t| / |t|
+    const float cm = n2 * fmaf(n2, 1.0f / 24.0f, -0.5f);                     // cos|t| - 1
+    const float A = sn * t1, B = sn * t2, C = sn * t3;
+    float dq[4];
+    dq[0] = fmaf(qs[0], cm, -fmaf(qs[1], A, fmaf(qs[2], B, qs[3] * C)));
+    dq[1] = fmaf(qs[1], cm, fmaf(qs[0], A, fmaf(qs[2], C, -(qs[3] * B))));
+    dq[2] = fmaf(qs[2], cm, fmaf(qs[0], B, fmaf(qs[3], A, -(qs[1] * C))));
+    dq[3] = fmaf(qs[3], cm, fmaf(qs[0], C, fmaf(qs[1], B, -(qs[2] * A))));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dqs[j] += dq[j]; qs[j] += dq[j]; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) XX[j] += G[j];    // prefix sums: sum_{k < n} G_k = sum_k (n - k) u_k, the double integral for x
+    QR_UVEC_ACC(G)
+    tm += hf;
+  }
+  // W1, W2 at the step's end (float32: for u' there), and the coupling part alone (for the float64 state)
+  const float dtf = hf * (float)nsub;
+  const float Pr = fmaf(dtf, fmaf(dtf, c4r, c3r), c2r), Pi = fmaf(dtf, fmaf(dtf, c4i, c3i), c2i);
+  const float Cr = dtf * fmaf(dtf, Pr, k1r), Ci = dtf * fmaf(dtf, Pi, k1i);
+  const float W1e = fmaf(dtf, fmaf(dtf, Pr, c1r), c0r), W2e = fmaf(dtf, fmaf(dtf, Pi, c1i), c0i);
+  float un[3], udn[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) un[j] = 0.f;
+  QR_UVEC_ACC(un)
+  QR_UDOT(udn, 0.5f * W1e, 0.5f * W2e)
+#undef QR_UVEC_ACC
+#undef QR_UDOT
+  // With Iv = int u dt = h (G - (u0 + un) / 2) + h^2/12 (u0' - un') and Ix = int (dt - t) u dt = h^2 (XX - n u0 / 2) + h^2/12 (un - u0 + dt u0'):
+  //   v_end = v0 + dt (0, 0, g - c) + 2 c s Iv,   x_end = x0 + dt v0 + dt^2/2 (0, 0, g - c) + 2 c s Ix,   s = (-1, -1, +1)
+  // (g - c formed in float64: near hover the two cancel, and rounding each to float32 first would bias the vertical
+  // acceleration by ~5e-7 m/s^2 for a whole flight)
+  const float cf = (float)p.c, gc = (float)(p.g - p.c);
+  const float c2h = 2.0f * cf * hf, c2hh = c2h * hf, e12 = c2h * hf * (1.0f / 12.0f), nh = -0.5f * (float)nsub;
+  float Iv[3], Ix[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    Iv[j] = fmaf(e12, ud0[j] - udn[j], c2h * fmaf(-0.5f, u0[j] + un[j], G[j]));
+    Ix[j] = fmaf(e12, fmaf(dtf, ud0[j], un[j] - u0[j]), c2hh * fmaf(nh, u0[j], XX[j]));
+  }
+  x[0] = fmaf(dtf, v[0], x[0]) - Ix[0];
+  x[1] = fmaf(dtf, v[1], x[1]) - Ix[1];
+  x[2] = fmaf(0.5f * dtf * dtf, gc, fmaf(dtf, v[2], x[2])) + Ix[2];
+  v[0] -= Iv[0];
+  v[1] -= Iv[1];
+  v[2] = fmaf(dtf, gc, v[2]) + Iv[2];
+  {  // the float64 state takes the step's increments once: dq; W = W0 + dt U (exact) + the coupling part of the polynomial at dt
+    const double dt = h * (double)nsub;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] += (double)dqs[j];
+    W[0] = fma(dt, p.U1, W[0]) + (double)Cr;
+    W[1] = fma(dt, p.U2, W[1]) + (double)Ci;
+    W[2] = fma(p.U3, dt, W[2]);
+  }
+}
+
+// The integrator of an instantiation: MAG = true exists for the default layout only (the uniform layouts are plain RK4 in T).
+template <bool MAG, typename XV, typename QW>
+__device__ __forceinline__ void integrate_sel(XV (&x)[3], XV (&v)[3], QW (&q)[4], QW (&W)[3], const Dyn<QW>& p, int nsub, QW h) {
+  if constexpr (MAG && std::is_same<XV, float>::value && std::is_same<QW, double>::value) integrate_magnus(x, v, q, W, p, nsub, h);
+  else integrate(x, v, q, W, p, nsub, h);
+}
+
+// ------------------------------------------------------------------------------------
 // The same step with the quaternion stages in DELTA FORM — the arithmetic of the launches that step envs on WITHOUT
 // in-launch resets (the rate-adaptive instantiations, ADAPT), where a free run far beyond termination amplifies the
 // float32 stage noise of `integrate` (~1e-9 per step) through the Decoupled action map's feedback ~100x over 900 steps

@@ -285,7 +285,8 @@ struct PostLds {
 // a lone wave issues one VALU instruction per ~5.6 cycles, two waves on a SIMD one per ~2.9 (tools/valu_microbench.hip),
 // so the helper runs in issue slots that are otherwise empty, and the stepping wave's reset block shrinks from
 // ~230 instructions (Philox, role scaling, attitude, 24 cross-lane reads) to six LDS reads.
-template <int KIND, typename XV, typename QW, int B, int TRAJ, bool ADAPT, int POLICY = 0, bool SINGLE = false, bool HELP = false, bool HREW = true>
+template <int KIND, typename XV, typename QW, int B, int TRAJ, bool ADAPT, int POLICY = 0, bool SINGLE = false, bool HELP = false, bool HREW = true,
+          bool MAG = false>
 __global__ __launch_bounds__(B + (HELP ? 64 : 0), ((HELP && POLICY) ? 2 : (TRAJ || POLICY) ? 1 : 2))  // (HELP: both waves of every tile resident)
 void step_kernel(void* pos_vel, void* att_rate, const float* action, float* params, float* integ, int32_t* reset_count,
                  int32_t n_envs, int32_t ld_envs, const Args a_in) {
@@ -815,12 +816,12 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
         integrate_delta(w.x, w.v, w.q, w.W, dyn, nsub, T(c.dt) * recip(T(nsub)));
       } else if (__ballot(need > T(1)) == 0) {  // in regime: exactly the plain kernel's code path (one ballot)
         const int nsub = ka.substeps;
-        integrate(w.x, w.v, w.q, w.W, dyn, nsub, T(c.dt) * recip(T(nsub)));
+        integrate_sel<MAG>(w.x, w.v, w.q, w.W, dyn, nsub, T(c.dt) * recip(T(nsub)));
       } else {
         int mul = 2;
         while (mul < 16 && __ballot(need > T(mul))) ++mul;
         const int nsub = ka.substeps * mul;
-        integrate(w.x, w.v, w.q, w.W, dyn, nsub, T(c.dt) * recip(T(nsub)));
+        integrate_sel<MAG>(w.x, w.v, w.q, w.W, dyn, nsub, T(c.dt) * recip(T(nsub)));
       }
     } else {
       const int nsub = ka.substeps;
@@ -830,7 +831,7 @@ void step_kernel(void* pos_vel, void* att_rate, const float* action, float* para
       if constexpr (HELP && SINGLE) {
         if (nsub >= QR_PRIO_SUBSTEPS) __builtin_amdgcn_s_setprio(QR_STEP_PRIO);
       }
-      integrate(w.x, w.v, w.q, w.W, dyn, nsub, T(c.dt) * recip(T(nsub)));
+      integrate_sel<MAG>(w.x, w.v, w.q, w.W, dyn, nsub, T(c.dt) * recip(T(nsub)));
     }
     renorm_quat(w.q);  //@sec renorm-late-loads-pack
     if constexpr (kLateLoads) {
@@ -1627,13 +1628,16 @@ static inline unsigned rollout_chunk(const Args& a, int kind, int layout) {
 // reports it), and ONE table (QR_INSTANCES) lists every instantiation that exists.
 // ------------------------------------------------------------------------------------
 struct Pick {
-  int traj; bool adapt; int policy; bool single, help, hrew;
-  // the bits qr_launch_stats counts under (with layout << 16 | kind << 8)
-  unsigned bits() const { return (unsigned)traj | (adapt ? 4u : 0u) | ((unsigned)policy << 3) | (single ? 32u : 0u) | (help ? 64u : 0u) | (hrew ? 128u : 0u); }
+  int traj; bool adapt; int policy; bool single, help, hrew, mag = false;
+  // the bits qr_launch_stats counts under (with layout << 16 | kind << 8; MAG is bit 12, above the kind's two bits)
+  unsigned bits() const {
+    return (unsigned)traj | (adapt ? 4u : 0u) | ((unsigned)policy << 3) | (single ? 32u : 0u) | (help ? 64u : 0u) | (hrew ? 128u : 0u) | (mag ? 0x1000u : 0u);
+  }
+  unsigned slot() const { return (bits() & 0xFFu) | (mag ? 0x100u : 0u); }   // index into the counters
 };
 
 // `tiles_of_launch` != 0: one chunk of a chunked qr_rollout_actor (rollout_chunk).
-static inline Pick pick_instance(const Args& a, int kind, int layout, unsigned tiles_of_launch = 0) {
+static inline Pick pick_shape(const Args& a, int kind, int layout, unsigned tiles_of_launch) {
   const bool mixed = layout == QR_LAYOUT_MIXED;  // the only layout with one-step (SINGLE) and helper-wave (HELP) instantiations
   const unsigned tiles = tiles_of_launch ? tiles_of_launch : (unsigned)((a.n + 63) / 64);
   // Rate adaptivity can only trigger when an env starts a step with max|W_i| > w_adapt.  With
@@ -1690,9 +1694,21 @@ static inline Pick pick_instance(const Args& a, int kind, int layout, unsigned t
   return {0, false, 0, false, help, true};  // (rollouts in the default layout: a helper wave per tile for grids it pays on)
 }
 
-// Every instantiation: (TRAJ, ADAPT, POLICY, SINGLE, HELP, HREW).  POLICY != 0 exists for the wrappers only; SINGLE, HELP and the
+// The integrator rides on the env's `substeps` alone — never on the grid, so that a shard computes the bits of the global batch:
+// two or more substeps in the default layout take the Magnus substep (MAG; qr_dynamics.h: 74 instead of 149 instructions per
+// substep), one substep keeps RK4 in kernels that hold nothing else (byte-identical to the build without MAG).  The rate-adaptive
+// delta-form instantiations (ADAPT without an actor: the launches whose envs may leave the regime) have their own arithmetic.
+static constexpr bool uses_plain_integrate(int adapt, int policy) { return !(adapt && QR_DELTA_STAGES && !policy); }
+static inline Pick pick_instance(const Args& a, int kind, int layout, unsigned tiles_of_launch = 0) {
+  Pick p = pick_shape(a, kind, layout, tiles_of_launch);
+  p.mag = layout == QR_LAYOUT_MIXED && a.substeps >= 2 && uses_plain_integrate(p.adapt, p.policy);
+  return p;
+}
+
+// Every instantiation: (TRAJ, ADAPT, POLICY, SINGLE, HELP, HREW) x MAG.  POLICY != 0 exists for the wrappers only; SINGLE, HELP and the
 // non-adaptive actor rollouts for the default layout only (inst_exists) — 16 Quad-v0 + 2 x 27 wrapper kernels in the default
-// layout, 6 + 2 x 11 in each uniform one.  tests/test_gpu_instances.py walks this table and checks that the suite launches all of it.
+// layout, 6 + 2 x 11 in each uniform one; MAG = 1 twins of the default layout's rows that call `integrate` (all but the delta-form
+// ones and the one-substep-only HREW = 0 rows): 9 Quad-v0 + 2 x 20.  175 in all.  tests/test_gpu_instances.py walks this table and checks that the suite launches all of it.
 #define QR_INSTANCES(X)                                                                                                  \
   X(0, 0, 0, 0, 0, 1) X(0, 1, 0, 0, 0, 1) X(1, 0, 0, 0, 0, 1) X(1, 1, 0, 0, 0, 1) X(2, 0, 0, 0, 0, 1) X(2, 1, 0, 0, 0, 1) \
   X(0, 1, 1, 0, 0, 1) X(0, 1, 2, 0, 0, 1) X(1, 1, 1, 0, 0, 1) X(1, 1, 2, 0, 0, 1) X(2, 1, 2, 0, 0, 1)                     \
@@ -1700,13 +1716,16 @@ static inline Pick pick_instance(const Args& a, int kind, int layout, unsigned t
   X(0, 0, 0, 0, 1, 1)                                                                                                    \
   X(0, 0, 0, 1, 0, 1) X(0, 1, 0, 1, 0, 1) X(1, 0, 0, 1, 0, 1) X(1, 1, 0, 1, 0, 1) X(2, 0, 0, 1, 0, 1) X(2, 1, 0, 1, 0, 1) \
   X(1, 0, 0, 1, 1, 1) X(0, 0, 0, 1, 1, 1) X(0, 0, 0, 1, 1, 0)
-static constexpr bool inst_exists(int kind, bool mixed, int tr, int ad, int po, int si, int he, int hr) {
-  (void)tr; (void)hr;
-  return !(po != 0 && kind == QR_KIND_QUAD) && (mixed || !(si || he || (po != 0 && !ad)));
+static constexpr bool inst_exists(int kind, bool mixed, int tr, int ad, int po, int si, int he, int hr, int mg = 0) {
+  (void)tr;
+  // (MAG: the default layout's rows that call `integrate`; HREW = 0 is a one-substep choice, pick_shape)
+  return !(po != 0 && kind == QR_KIND_QUAD) && (mixed || !(si || he || (po != 0 && !ad))) && (!mg || (mixed && uses_plain_integrate(ad, po) && hr));
 }
+// (a consumer of the table defines QR_X1 with the seventh column, MAG)
+#define QR_X(TR, AD, PO, SI, HE, HR) QR_X1(TR, AD, PO, SI, HE, HR, 0) QR_X1(TR, AD, PO, SI, HE, HR, 1)
 
 // Host-side launch counters, one per (layout, kind, instantiation): which kernels a process really ran (qr_launch_stats).
-static std::atomic<uint32_t> g_launches[3][3][256];
+static std::atomic<uint32_t> g_launches[3][3][512];
 
 template <int KIND, typename XV, typename QW>
 static int launch_kind(const Args& a, hipStream_t s, unsigned tiles_of_launch = 0) {
@@ -1728,16 +1747,17 @@ static int launch_kind(const Args& a, hipStream_t s, unsigned tiles_of_launch = 
   const dim3 grid(tiles_of_launch ? tiles_of_launch : (unsigned)((a.n + 63) / 64));
   const Pick p = pick_instance(a, KIND, kLayout, tiles_of_launch);
 #define QR_STEP_ARGS a.pos_vel, a.att_rate, a.action, a.params, a.integ, ((a.flags & QR_FLAG_AUTO_RESET) ? a.reset_count : nullptr), (int32_t)a.n, (int32_t)a.ld, a
-#define QR_X(TR, AD, PO, SI, HE, HR)                                                                                              \
-  if constexpr (inst_exists(KIND, kMixed, TR, AD, PO, SI, HE, HR)) {                                                              \
-    if (p.traj == TR && p.adapt == (bool)AD && p.policy == PO && p.single == (bool)SI && p.help == (bool)HE && p.hrew == (bool)HR) { \
-      g_launches[kLayout][KIND][p.bits()].fetch_add(1u, std::memory_order_relaxed);                                              \
-      hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, TR, (bool)AD, PO, (bool)SI, (bool)HE, (bool)HR>), grid, dim3(HE ? 128 : 64), 0, s, QR_STEP_ARGS); \
+#define QR_X1(TR, AD, PO, SI, HE, HR, MG)                                                                                         \
+  if constexpr (inst_exists(KIND, kMixed, TR, AD, PO, SI, HE, HR, MG)) {                                                          \
+    if (p.traj == TR && p.adapt == (bool)AD && p.policy == PO && p.single == (bool)SI && p.help == (bool)HE && p.hrew == (bool)HR && \
+        p.mag == (bool)MG) {                                                                                                      \
+      g_launches[kLayout][KIND][p.slot()].fetch_add(1u, std::memory_order_relaxed);                                              \
+      hipLaunchKernelGGL((step_kernel<KIND, XV, QW, 64, TR, (bool)AD, PO, (bool)SI, (bool)HE, (bool)HR, (bool)MG>), grid, dim3(HE ? 128 : 64), 0, s, QR_STEP_ARGS); \
       return 0;                                                                                                                   \
     }                                                                                                                             \
   }
   QR_INSTANCES(QR_X)
-#undef QR_X
+#undef QR_X1
 #undef QR_STEP_ARGS
   return QR_E_KIND;  // (unreachable: pick_instance only returns rows of the table)
 }
@@ -2050,11 +2070,12 @@ int qr_launch_plan(const QrEnv* env, int32_t n_steps, int32_t substeps, int32_t 
   plan->block = p.help ? 128 : 64;
   plan->launches = chunk ? (int32_t)((tiles + chunk - 1) / chunk) : 1;
   plan->traj = p.traj; plan->adapt = p.adapt; plan->policy = p.policy; plan->single = p.single; plan->help = p.help; plan->hrew = p.hrew;
+  plan->mag = p.mag;
   plan->key = ((uint32_t)env->layout << 16) | ((uint32_t)env->kind << 8) | p.bits();
   static const char* const kXV[3] = {"float", "double", "float"};
   static const char* const kQW[3] = {"double", "double", "float"};
-  snprintf(plan->name, sizeof(plan->name), "qr::step_kernel<%d,%s,%s,64,%d,%d,%d,%d,%d,%d>", (int)env->kind, kXV[env->layout], kQW[env->layout],
-           p.traj, (int)p.adapt, p.policy, (int)p.single, (int)p.help, (int)p.hrew);
+  snprintf(plan->name, sizeof(plan->name), "qr::step_kernel<%d,%s,%s,64,%d,%d,%d,%d,%d,%d,%d>", (int)env->kind, kXV[env->layout], kQW[env->layout],
+           p.traj, (int)p.adapt, p.policy, (int)p.single, (int)p.help, (int)p.hrew, (int)p.mag);
   return 0;
 }
 
@@ -2075,10 +2096,10 @@ int32_t qr_launch_stats(uint32_t* keys, uint32_t* counts, int32_t capacity, int3
   int32_t n = 0;
   for (int l = 0; l < 3; ++l)
     for (int k = 0; k < 3; ++k)
-      for (int b = 0; b < 256; ++b) {
+      for (int b = 0; b < 512; ++b) {
         const uint32_t c = reset ? qr::g_launches[l][k][b].exchange(0u, std::memory_order_relaxed) : qr::g_launches[l][k][b].load(std::memory_order_relaxed);
         if (c == 0) continue;
-        if (n < capacity && keys && counts) { keys[n] = ((uint32_t)l << 16) | ((uint32_t)k << 8) | (uint32_t)b; counts[n] = c; }
+        if (n < capacity && keys && counts) { keys[n] = ((uint32_t)l << 16) | ((uint32_t)k << 8) | (uint32_t)(b & 0xFF) | (b & 0x100 ? 0x1000u : 0u); counts[n] = c; }
         ++n;
       }
   return n;
@@ -2088,13 +2109,13 @@ int32_t qr_instance_table(uint32_t* keys, int32_t capacity) {
   int32_t n = 0;
   for (int l = 0; l < 3; ++l)
     for (int k = 0; k < 3; ++k) {
-#define QR_X(TR, AD, PO, SI, HE, HR)                                                                   \
-  if (qr::inst_exists(k, l == QR_LAYOUT_MIXED, TR, AD, PO, SI, HE, HR)) {                              \
-    if (n < capacity && keys) keys[n] = ((uint32_t)l << 16) | ((uint32_t)k << 8) | qr::Pick{TR, (bool)AD, PO, (bool)SI, (bool)HE, (bool)HR}.bits(); \
+#define QR_X1(TR, AD, PO, SI, HE, HR, MG)                                                              \
+  if (qr::inst_exists(k, l == QR_LAYOUT_MIXED, TR, AD, PO, SI, HE, HR, MG)) {                          \
+    if (n < capacity && keys) keys[n] = ((uint32_t)l << 16) | ((uint32_t)k << 8) | qr::Pick{TR, (bool)AD, PO, (bool)SI, (bool)HE, (bool)HR, (bool)MG}.bits(); \
     ++n;                                                                                               \
   }
       QR_INSTANCES(QR_X)
-#undef QR_X
+#undef QR_X1
     }
   return n;
 }

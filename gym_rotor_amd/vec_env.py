@@ -931,13 +931,13 @@ class QuadVecEnv:
     def launch_plan(self, n_steps: int = 1, actor: Optional[str] = None) -> dict:
         """What the launcher runs for step() (n_steps=1) / rollout(T) / rollout_actor(actors, T) with `actor` in ("ppo", "td3",
         "sac"): dict(name = the kernel instantiation as it appears in a rocprofv3 trace, grid, block, launches, key, and the
-        template arguments traj, adapt, policy, single, help, hrew) — the launcher's own decision function with this env's
+        template arguments traj, adapt, policy, single, help, hrew, mag) — the launcher's own decision function with this env's
         substeps (qr_launch_plan; host-side, nothing is launched)."""
         plan = _lib.QrLaunchPlan()
         form = {None: 0, "ppo": 1, "td3": 1, "sac": 2}[actor]
         _lib.check(self._lib.qr_launch_plan(C.byref(self._cenv), int(n_steps), self.substeps, form, C.byref(plan)), "qr_launch_plan")
         return {"name": plan.name.decode(), "grid": plan.grid, "block": plan.block, "launches": plan.launches, "key": int(plan.key),
-                **{k: int(getattr(plan, k)) for k in ("traj", "adapt", "policy", "single", "help", "hrew")}}
+                **{k: int(getattr(plan, k)) for k in ("traj", "adapt", "policy", "single", "help", "hrew", "mag")}}
 
     def kernel_info(self, n_steps=1, actor: Optional[str] = None):
         """(kernel family, workgroups, threads per workgroup) of the launch `step` (n_steps=1) / `rollout` / `rollout_actor` uses."""

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define QR_ABI_VERSION 14
+#define QR_ABI_VERSION 15
 
 /* env kinds */
 #define QR_KIND_QUAD      0 /* QuadEnv            gym_rotor/envs/quad.py:19            */
@@ -202,7 +202,7 @@ typedef struct QrStepOut {
   uint8_t* truncated;   /* optional [N]                                                   */
   /* Optional, with QR_FLAG_AUTO_RESET: rows [N][D0] / [N][D1] (same shapes as obs0 / obs1; QUAD: [N][18])
    * that receive the TERMINAL observation of every env that is re-sampled in this step — the
-   * obs_next the reference stores for that transition (main.py:163-178; obs0/obs1 then already hold
+   * obs_next the reference stores for that transition (main.py:163-175; obs0/obs1 then already hold
    * the first observation of the new episode).  Rows of envs that did not reset are left untouched. */
   float*   final_obs0;
   float*   final_obs1;
@@ -213,8 +213,11 @@ typedef struct QrStepOut {
  * crash override, for all N envs in one fused launch.
  *   action   [N][A] float32, A = 4 (QUAD, COUPLED) or 5 (DECOUPLED: agents' actions
  *            concatenated, main.py:161).  16-byte aligned (A = 4) / 4-byte aligned (A = 5).
- *   substeps number of fixed RK4 substeps of h = dt/substeps replacing
- *            scipy.integrate.solve_ivp(DOP853) (quad.py:265); >= 1. */
+ *   substeps number of fixed 4th-order substeps of h = dt/substeps replacing
+ *            scipy.integrate.solve_ivp(DOP853) (quad.py:265); >= 1.  ONE substep is an RK4 step; with two or more the default
+ *            layout takes a Lie-group (Magnus) substep of the same order at half the instructions (qr_dynamics.h; the uniform
+ *            layouts stay RK4).  The choice rides on `substeps` alone, never on the batch size or the launch family: a shard, a
+ *            rollout and an actor rollout compute the bits of the global, per-step launches of the same `substeps`. */
 int qr_step(const QrEnv* env, const float* action, int32_t substeps, const QrStepOut* out, void* stream);
 
 /* K env-steps in ONE launch with the state held in registers between steps:
@@ -353,12 +356,12 @@ int  qr_abi_version(void);
  * log_std head) over n_steps env-steps of `substeps` RK4 substeps: `launches` launches of `grid` workgroups (64-env tiles)
  * of `block` threads — 64 = one wavefront per tile, 128 = plus a helper wavefront (QR_FLAG_AUTO_RESET, default layout, grids
  * in the launch-latency regime; launches > 1: qr_rollout_actor in chunks of `grid` resident tiles) — of the instantiation
- * `name` = qr::step_kernel<KIND, XV, QW, 64, TRAJ, ADAPT, POLICY, SINGLE, HELP, HREW> with the values filled in (the prefix of the
- * kernel's name in a rocprofv3 trace).  `key` = layout << 16 | kind << 8 | TRAJ | ADAPT << 2 | POLICY << 3 | SINGLE << 5 |
- * HELP << 6 | HREW << 7: what qr_launch_stats counts under. */
+ * `name` = qr::step_kernel<KIND, XV, QW, 64, TRAJ, ADAPT, POLICY, SINGLE, HELP, HREW, MAG> with the values filled in (the prefix of
+ * the kernel's name in a rocprofv3 trace; MAG = 1: the Magnus substep, substeps >= 2 in the default layout).  `key` = layout << 16 |
+ * MAG << 12 | kind << 8 | TRAJ | ADAPT << 2 | POLICY << 3 | SINGLE << 5 | HELP << 6 | HREW << 7: what qr_launch_stats counts under. */
 typedef struct QrLaunchPlan {
   int32_t grid, block, launches;
-  int32_t traj, adapt, policy, single, help, hrew;
+  int32_t traj, adapt, policy, single, help, hrew, mag;
   uint32_t key;
   char name[96];
 } QrLaunchPlan;
@@ -368,7 +371,7 @@ int qr_launch_plan(const QrEnv* env, int32_t n_steps, int32_t substeps, int32_t 
 const char* qr_step_kernel_info(const QrEnv* env, int32_t n_steps, int32_t* grid, int32_t* block);
 /* Host-side launch counters of this process: how many step-kernel launches each (layout, kind, instantiation) `key` has had
  * since load (or since the last call with reset != 0).  Writes up to `capacity` (key, count) pairs with count > 0, returns
- * how many there are.  qr_instance_table lists the keys of EVERY instantiation the library holds (126), same convention:
+ * how many there are.  qr_instance_table lists the keys of EVERY instantiation the library holds (175), same convention:
  * together they tell a test suite which kernels it really ran. */
 int32_t qr_launch_stats(uint32_t* keys, uint32_t* counts, int32_t capacity, int32_t reset);
 int32_t qr_instance_table(uint32_t* keys, int32_t capacity);

@@ -1,4 +1,4 @@
-"""Every step_kernel instantiation the library holds (126: quadrotor_kernels.hip QR_INSTANCES) is reachable through the public API,
+"""Every step_kernel instantiation the library holds (175: quadrotor_kernels.hip QR_INSTANCES x MAG) is reachable through the public API,
 runs, and agrees with the float64 layout's instantiation of the same workload — and the process' launch counters (qr_launch_stats)
 show that all of them were really launched ("nothing records which instantiations the GPU tests launch").
 Also here: qr_touch, the do-nothing kernel bench.py prices a step against."""
@@ -14,24 +14,28 @@ KINDS = ("quad", "coupled", "decoupled")
 BIG = 64 * 1700 + 5      # 1701 tiles: beyond QR_HELP_REWARD_TILES / QR_HELP_ROWS_TILES, inside the helper-wave thresholds
 
 
-def _make(kind, n, layout, goal_mode, auto_reset, w_adapt, helper=None):
+def _make(kind, n, layout, goal_mode, auto_reset, w_adapt, helper=None, substeps=1):
     from gym_rotor_amd import QuadVecEnv
     return QuadVecEnv(kind, n, device="cuda", seed=4, layout=layout, goal_mode=goal_mode, auto_reset=auto_reset, w_adapt=w_adapt,
-                      helper=helper, helper_rollout=helper, autotune=False)
+                      helper=helper, helper_rollout=helper, autotune=False, substeps=substeps)
 
 
 def _recipes():
     """One way of reaching every instantiation: walk a grid of env configurations and workloads, ask the launcher's own decision
     function (launch_plan: host-side) which kernel each would run, keep the first recipe per kernel."""
     found = {}
-    for layout, kind, goal_mode, auto_reset, w_adapt, n in itertools.product(("mixed", "f64", "f32"), KINDS, (None, 0, 2), (True, False), (16.0, 8.0), (640, BIG)):
-        env = _make(kind, n, layout, goal_mode, auto_reset, w_adapt)
+    for layout, kind, goal_mode, auto_reset, w_adapt, n, sub in itertools.product(("mixed", "f64", "f32"), KINDS, (None, 0, 2), (True, False), (16.0, 8.0),
+                                                                                  (640, BIG), (1, 2)):
+        if sub == 2 and layout != "mixed":      # (the Magnus twins exist in the default layout only)
+            continue
+        env = _make(kind, n, layout, goal_mode, auto_reset, w_adapt, substeps=sub)
         for helper, (T, actor) in itertools.product((None, False), ((1, None), (3, None), (3, "ppo"), (3, "sac"))):
             if actor and kind == "quad":
                 continue
             env.set_launch(helper, helper)
             key = env.launch_plan(T, actor)["key"]
-            found.setdefault(key, dict(layout=layout, kind=kind, goal_mode=goal_mode, auto_reset=auto_reset, w_adapt=w_adapt, n=n, helper=helper, T=T, actor=actor))
+            found.setdefault(key, dict(layout=layout, kind=kind, goal_mode=goal_mode, auto_reset=auto_reset, w_adapt=w_adapt, n=n, helper=helper, T=T, actor=actor,
+                                       substeps=sub))
         del env
     return found
 
@@ -39,7 +43,7 @@ def _recipes():
 def _run(r, layout, helper):
     """The recipe's workload on `layout`: three env-steps from a seeded reset; returns (state, any-done over the steps)."""
     from gym_rotor_amd import random_actors
-    env = _make(r["kind"], r["n"], layout, r["goal_mode"], r["auto_reset"], r["w_adapt"], helper)
+    env = _make(r["kind"], r["n"], layout, r["goal_mode"], r["auto_reset"], r["w_adapt"], helper, r["substeps"])
     env.reset("train")
     if r["kind"] != "quad":
         if r["goal_mode"] is not None:
@@ -65,7 +69,7 @@ def _run(r, layout, helper):
 def test_every_instantiation_is_reachable_runs_and_agrees_with_the_float64_layout():
     from gym_rotor_amd import _lib
     table = _lib.instance_table()
-    assert len(table) == len(set(table)) == 126
+    assert len(table) == len(set(table)) == 175
     recipes = _recipes()
     missing = [_lib.describe_key(k) for k in table if k not in recipes]
     assert not missing, f"no recipe reaches: {missing}"
@@ -76,7 +80,7 @@ def test_every_instantiation_is_reachable_runs_and_agrees_with_the_float64_layou
         r = recipes[key]
         state, done, plan = _run(r, r["layout"], r["helper"])
         assert plan["key"] == key and np.isfinite(state).all(), (_lib.describe_key(key), r)
-        rk = (r["kind"], r["n"], r["goal_mode"], r["auto_reset"], r["w_adapt"], r["T"], r["actor"])
+        rk = (r["kind"], r["n"], r["goal_mode"], r["auto_reset"], r["w_adapt"], r["T"], r["actor"], r["substeps"])
         if rk not in refs:
             refs[rk] = _run(r, "f64", None)[:2]
         ref_state, ref_done = refs[rk]

@@ -82,6 +82,62 @@ def test_onestep_golden(kind, layout, substeps, golden):
     assert nbad <= 2
 
 
+
+@pytest.mark.parametrize("substeps", [2, 3, 4, 10])
+@pytest.mark.parametrize("kind", KINDS)
+def test_onestep_golden_magnus_substeps(kind, substeps, golden):
+    """Two or more substeps in the default layout: the Magnus-substep instantiations (MAG = 1; qr_dynamics.h: integrate_magnus)
+    against the reference's one-step vectors — the set holds saturated torques at |W| ~ 2 pi.  The plain (non-adaptive) kernel
+    is reached with the caller's reset promise; same bar as the default layout's RK4 step (x, v are stored as float32)."""
+    d = golden(f"onestep_{kind}")
+    n = d["state"].shape[0]
+    env = _env(kind, n, layout="mixed", substeps=substeps, obs_rows=True, reset_on_done=True)
+    plan = env.launch_plan()
+    assert plan["mag"] == 1 and plan["adapt"] == 0 and plan["name"].endswith(",1>")
+    env.set_state(d["state"], integ=d["integ"], params=d["params"])
+    _set_goal(env, d["goal"])
+    obs, rwd, done, _, _ = env.step(torch.from_numpy(d["action"].astype(np.float32)).cuda())
+    torch.cuda.synchronize()
+    err = grouped_rel_err(_np(env.get_current_state()), d["next_state"])
+    print(f"onestep {kind}/mixed/Magnus S={substeps}: {err:.2e}")
+    assert err <= 2e-7
+    for k, o in enumerate(_obs_list(obs)):
+        ref = d[f"obs{k}"].astype(np.float64)
+        assert (np.abs(_np(o).astype(np.float64) - ref) / np.maximum(np.abs(ref), 1.0)).max() <= 2e-6
+    assert np.abs(_np(rwd).astype(np.float64) - d["reward"]).max() <= 1e-5
+    assert _done_mismatch_ok(kind, d, _np(done)) <= 2
+
+
+def test_magnus_substeps_same_bits_in_every_launch_family():
+    """The integrator rides on `substeps` alone: with 2 substeps a rollout equals the per-step launches, the helper-wave launch equals
+    the plain one and a shard equals its slice of the global batch — bit for bit, as with one substep."""
+    n, T = 64 * 40 + 9, 6
+    g = torch.Generator(device="cuda"); g.manual_seed(12)
+    acts = torch.rand(T, n, 4, device="cuda", generator=g) * 2 - 1
+
+    def run(mode, **kw):
+        env = _env("coupled", n if "env_offset" not in kw else 64 * 10, seed=5, auto_reset=True, obs_rows=True, substeps=2, autotune=False, **kw)
+        env.reset("train")
+        env.get_norm_error_state()
+        a = acts if "env_offset" not in kw else acts[:, kw["env_offset"]:kw["env_offset"] + 64 * 10]
+        if mode == "rollout":
+            out = env.rollout(a.contiguous())
+            rw = out["reward"]
+        else:
+            rw = torch.stack([env.step(a[t].contiguous())[1].clone() for t in range(T)])
+        return _np(env.get_current_state()), _np(rw), env
+
+    s0, r0, e0 = run("step")
+    assert e0.launch_plan()["mag"] == 1 and e0.launch_plan()["help"] == 1
+    s1, r1, e1 = run("step", helper=False)
+    assert e1.launch_plan()["help"] == 0 and e1.launch_plan()["mag"] == 1
+    s2, r2, e2 = run("rollout")
+    assert e2.launch_plan(T)["mag"] == 1 and e2.launch_plan(T)["single"] == 0
+    s3, r3, _ = run("step", env_offset=64 * 7)
+    assert np.array_equal(s0, s1) and np.array_equal(r0, r1)
+    assert np.array_equal(s0, s2) and np.array_equal(r0.reshape(r2.shape), r2)
+    assert np.array_equal(s0[64 * 7:64 * 17], s3) and np.array_equal(r0[:, 64 * 7:64 * 17], r3)
+
 @pytest.mark.parametrize("layout,mode", [("mixed", "free"), ("mixed", "reset"), ("f64", "free")])
 @pytest.mark.parametrize("kind", KINDS)
 def test_trajectory_golden_1000_steps(kind, layout, mode, golden):
@@ -790,20 +846,20 @@ def test_in_launch_reset_pool_distribution():
     assert np.abs(_np(env.integ)[:, [0, 1, 2, 6]]).max() < 0.05         # integrators restarted (advanced once by the first obs)
 
 
-@pytest.mark.parametrize("kind,substeps", [(k, 1) for k in KINDS] + [("quad", 10), ("decoupled", 4)])
+@pytest.mark.parametrize("kind,substeps", [(k, 1) for k in KINDS] + [("quad", 10), ("decoupled", 4), ("coupled", 2), ("quad", 3)])
 def test_production_mode_1000_steps_every_episode_vs_oracle(kind, substeps):
     """The mode a training loop runs (default layout, 1 substep, in-launch auto-reset, random
     actions): 512 envs x 1000 steps, ~5000 complete episodes.  The oracle steps every env from its
     own state and only adopts the GPU's freshly sampled state when an episode ends, so the error of
     every env is followed through every whole episode; rewards and done flags are compared at
-    every step including the terminal one.  Also with 10 substeps (BASELINE.json configs[4]'s mode) and 4:
-    within one env-step the substeps' increments are summed in float32 and the float64 state takes
-    them once — the error must not grow with the substep count."""
+    every step including the terminal one.  Also with 10 substeps (BASELINE.json configs[4]'s mode), 4, 2 and 3 — the
+    Magnus-substep instantiations (MAG = 1): within one env-step the substeps' increments are summed in float32 and the
+    float64 state takes them once — the error must not grow with the substep count."""
     n, T = 512, 1000
     rng = np.random.default_rng(4242 + KINDS.index(kind))
     A = orc.ACTION_DIM[kind]
     env = _env(kind, n, seed=31, auto_reset=True, obs_rows=True, substeps=substeps)
-    assert env.layout == "mixed" and env.substeps == substeps
+    assert env.layout == "mixed" and env.substeps == substeps and env.launch_plan()["mag"] == int(substeps >= 2)
     env.reset("train")
     if kind != "quad":
         env.get_norm_error_state()

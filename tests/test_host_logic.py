@@ -286,7 +286,7 @@ def test_launch_geometry_rule_without_gpu():
 def test_launch_plan_names_the_instantiation_without_gpu():
     """qr_launch_plan (host-only): the launcher's own decision with the env's substeps and, for qr_rollout_actor, the actor form —
     instantiation name as a rocprofv3 trace prints it, geometry, number of launches (chunked actor rollouts), counter key;
-    qr_instance_table lists all 126 instantiations and every plan's key is one of them."""
+    qr_instance_table lists all 175 instantiations and every plan's key is one of them."""
     L = _lib()
     lib = L.load()
     AR = L.FLAG_AUTO_RESET
@@ -302,18 +302,25 @@ def test_launch_plan_names_the_instantiation_without_gpu():
         return p
 
     table = L.instance_table()
-    assert len(table) == 126 and len(set(table)) == 126
+    assert len(table) == 175 and len(set(table)) == 175
     p = plan(0, 65536, AR)
-    assert p.name == b"qr::step_kernel<0,float,double,64,0,0,0,1,1,1>" and (p.grid, p.block, p.launches) == (1024, 128, 1) and p.key in table
-    assert L.describe_key(p.key) == "mixed/quad TRAJ=0 ADAPT=0 POLICY=0 SINGLE=1 HELP=1 HREW=1"
+    assert p.name == b"qr::step_kernel<0,float,double,64,0,0,0,1,1,1,0>" and (p.grid, p.block, p.launches) == (1024, 128, 1) and p.key in table
+    assert L.describe_key(p.key) == "mixed/quad TRAJ=0 ADAPT=0 POLICY=0 SINGLE=1 HELP=1 HREW=1 MAG=0"
     # substeps move the thresholds (3328 -> 2560 tiles for Quad-v0, 2560 -> 2048 for the wrappers) and keep the reward on the helper wave
     assert plan(0, 64 * 3000, AR).help == 1 and plan(0, 64 * 3000, AR, substeps=2).help == 0
     assert plan(1, 64 * 2300, AR).help == 1 and plan(1, 64 * 2300, AR, substeps=4).help == 0
     assert plan(0, 64 * 1500, AR).hrew == 0 and plan(0, 64 * 1500, AR, substeps=10).hrew == 1 and plan(0, 64 * 1400, AR).hrew == 1
     assert plan(2, 64 * 1700, AR).hrew == 0 and plan(2, 64 * 1600, AR).hrew == 1
+    # two or more substeps in the default layout: the Magnus-substep twin (MAG = 1) of the same instantiation — whatever the launch family,
+    # never in the uniform layouts, never for the delta-form (free-run) kernels
+    m = plan(0, 65536, AR, substeps=10)
+    assert m.mag == 1 and m.name == b"qr::step_kernel<0,float,double,64,0,0,0,1,1,1,1>" and m.key in table and m.key == p.key | 0x1000
+    assert L.describe_key(m.key) == "mixed/quad TRAJ=0 ADAPT=0 POLICY=0 SINGLE=1 HELP=1 HREW=1 MAG=1"
+    assert plan(1, 65536, AR, n_steps=32, substeps=2, actor=1).mag == 1 and plan(2, 65536, AR, n_steps=8, substeps=3).mag == 1
+    assert plan(0, 65536, AR, substeps=10, layout=1).mag == 0 and plan(0, 65536, 0, substeps=4).mag == 0 and plan(0, 65536, AR).mag == 0
     # free run (no resets) -> the rate-adaptive one-step kernel; the caller's reset promise -> the plain one; uniform layouts: no SINGLE
     assert (plan(0, 65536, 0).adapt, plan(0, 65536, 0).single) == (1, 1) and plan(0, 65536, L.FLAG_CALLER_RESETS).adapt == 0
-    assert plan(0, 65536, AR, layout=1).name == b"qr::step_kernel<0,double,double,64,0,0,0,0,0,1>"
+    assert plan(0, 65536, AR, layout=1).name == b"qr::step_kernel<0,double,double,64,0,0,0,0,0,1,0>"
     # qr_rollout_actor: PPO / SAC forms, helper wave up to 1024 tiles, beyond it chunks of 1024 tiles (one launch after the other)
     a = plan(1, 65536, AR, n_steps=32, actor=1)
     assert (a.policy, a.help, a.block, a.launches, a.grid) == (1, 1, 128, 1, 1024)
@@ -321,7 +328,7 @@ def test_launch_plan_names_the_instantiation_without_gpu():
     assert (b.policy, b.help, b.launches, b.grid) == (2, 1, 4, 1024) and b.key in table
     c = plan(1, 262144, AR | L.FLAG_NO_HELPER_ROLLOUT, n_steps=32, actor=1)
     assert (c.help, c.launches, c.grid, c.block) == (0, 1, 4096, 64)
-    assert plan(1, 65536, AR, n_steps=8, actor=1, goal_mode=L.GOAL_MODE2).name == b"qr::step_kernel<1,float,double,64,2,1,2,0,0,1>"
+    assert plan(1, 65536, AR, n_steps=8, actor=1, goal_mode=L.GOAL_MODE2).name == b"qr::step_kernel<1,float,double,64,2,1,2,0,0,1,0>"
     # argument errors
     plan(0, 65536, AR, actor=1, rc=-2)             # no actor rollouts for Quad-v0
     plan(1, 65536, AR, substeps=0, rc=-3)
@@ -335,7 +342,8 @@ def test_launch_plan_names_the_instantiation_without_gpu():
                     for gm in (None, L.GOAL_MODE0, L.GOAL_MODE5):
                         if actor and kind == 0:
                             continue
-                        assert plan(kind, 70000, flags, n_steps=n_steps, actor=actor, layout=layout, goal_mode=gm).key in table
+                        for sub in (1, 2):
+                            assert plan(kind, 70000, flags, n_steps=n_steps, substeps=sub, actor=actor, layout=layout, goal_mode=gm).key in table
     assert L.launch_stats() == {} or all(k in table for k in L.launch_stats())    # (no launches on a box without a GPU)
 
 

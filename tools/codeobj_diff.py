@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Which kernels' machine code differs between two builds of the library?  CPU only (no GPU needed).
 
-    python tools/codeobj_diff.py A.so B.so [--list]
+    python tools/codeobj_diff.py A.so B.so [--list] [--strip-mag]
 
 Extracts the gfx950 code object of each library (llvm-objdump --offloading), disassembles it and compares every kernel's
 instruction stream symbol by symbol (addresses and branch targets normalised).  Prints the kernels that exist in one build
 only and those whose code differs; exit code 0 when the device code of every common kernel is identical.  What it is for:
 a host-side change (launch rule, C-ABI) must leave every kernel untouched; a kernel change shows exactly which of the 126
 step_kernel instantiations it reached (tests/test_gpu_digest.py then tells whether their RESULTS changed).
+--strip-mag: compare a build from before the 11th template argument (MAG, round 6) with one after it — the MAG = false kernels of
+the newer build are matched with the older build's kernels of the same first ten arguments.
 """
 import hashlib
 import os
@@ -65,6 +67,10 @@ def main():
     if len(args) != 2:
         raise SystemExit(__doc__)
     a, b = kernels(args[0]), kernels(args[1])
+    if "--strip-mag" in sys.argv:
+        def strip(d):
+            return {re.sub(r"(step_kernel<(?:[^,<>]+, ){9}[^,<>]+), false>", r"\1>", k): v for k, v in d.items()}
+        a, b = strip(a), strip(b)
     only_a, only_b = sorted(set(a) - set(b)), sorted(set(b) - set(a))
     diff = sorted(k for k in set(a) & set(b) if a[k][0] != b[k][0])
     print(f"{args[0]}: {len(a)} kernels; {args[1]}: {len(b)} kernels; common {len(set(a) & set(b))}, identical {len(set(a) & set(b)) - len(diff)}")
