@@ -285,6 +285,8 @@ struct PostLds {
 // a lone wave issues one VALU instruction per ~5.6 cycles, two waves on a SIMD one per ~2.9 (tools/valu_microbench.hip),
 // so the helper runs in issue slots that are otherwise empty, and the stepping wave's reset block shrinks from
 // ~230 instructions (Philox, role scaling, attitude, 24 cross-lane reads) to six LDS reads.
+// MAG = the substeps are Magnus substeps (qr_dynamics.h: integrate_magnus; default layout, `substeps` >= 2 — the host's choice from
+// the substep count alone, pick_instance); MAG = false kernels hold RK4 only and run the one-substep launches.
 template <int KIND, typename XV, typename QW, int B, int TRAJ, bool ADAPT, int POLICY = 0, bool SINGLE = false, bool HELP = false, bool HREW = true,
           bool MAG = false>
 __global__ __launch_bounds__(B + (HELP ? 64 : 0), ((HELP && POLICY) ? 2 : (TRAJ || POLICY) ? 1 : 2))  // (HELP: both waves of every tile resident)

@@ -84,7 +84,8 @@ class QuadVecEnv:
 
     kind            'quad' | 'coupled' | 'decoupled'  (MONO: coupled, MODUL: decoupled)
     num_envs        N envs owned by this object (this GPU's shard)
-    substeps        RK4 substeps per env-step replacing solve_ivp(DOP853) (quad.py:265)
+    substeps        fixed 4th-order substeps per env-step replacing solve_ivp(DOP853) (quad.py:265): 1 = one RK4 step; with two or
+                    more the default layout takes Magnus substeps (half the instructions), the uniform layouts RK4
     w_adapt         [rad/s] rate-adaptive substepping, the stand-in for DOP853's error control: a
                     wavefront holding an env with max|W_i| > w_adapt takes ceil(max|W_i| / w_adapt)
                     times the substeps.  Never active in regime (|W| < 2 pi), and with auto_reset it

@@ -19,9 +19,9 @@ for l in open('/tmp/qr_dev.log'):
     else:
         cur[m.group(1).split()[0]] = m.group(2)
 for r in rows:
-    t = re.search(r'step_kernelILi(\d)E(\w)(\w)Li64EL[bi](\d)ELb(\d)ELi(\d)ELb(\d)ELb(\d)E', r['name'])
+    t = re.search(r'step_kernelILi(\d)E(\w)(\w)Li64EL[bi](\d)ELb(\d)ELi(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)E', r['name'])
     if t:
-        print("kind=%s %s%s TRAJ=%s ADAPT=%s POLICY=%s SINGLE=%s HELP=%s" % t.groups(), '| VGPR', r.get('VGPRs'), 'SGPR', r.get('TotalSGPRs'),
+        print("kind=%s %s%s TRAJ=%s ADAPT=%s POLICY=%s SINGLE=%s HELP=%s HREW=%s MAG=%s" % t.groups(), '| VGPR', r.get('VGPRs'), 'SGPR', r.get('TotalSGPRs'),
               'scratch', r.get('ScratchSize'), 'waves', r.get('Occupancy'), 'LDS', r.get('LDS'))
 PY
 python3 $ROOT/tools/isa_stats.py /tmp/qr_dev.s "${FILTER:-}"

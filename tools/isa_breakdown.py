@@ -24,12 +24,14 @@ SRC = os.path.join(ROOT, "gym_rotor_amd", "csrc", "quadrotor_kernels.hip")
 
 p = argparse.ArgumentParser()
 p.add_argument("--kind", type=int, default=0)
-p.add_argument("--flags", default="0,0,0,1,0", help="TRAJ,ADAPT,POLICY,SINGLE,HELP of the instantiation")
+p.add_argument("--flags", default="0,0,0,1,0", help="TRAJ,ADAPT,POLICY,SINGLE,HELP[,HREW[,MAG]] of the instantiation (HREW = 1, MAG = 0 by default)")
 p.add_argument("--elf", default="")
 p.add_argument("--by-callee", action="store_true")
 p.add_argument("--extra", default="", help="extra -D flags for the build")
 a = p.parse_args()
-traj, adapt, policy, single, helpw = [int(x) for x in a.flags.split(",")]
+traj, adapt, policy, single, helpw, hrew, mag = ([int(x) for x in a.flags.split(",")] + [1, 0])[:7] if len(a.flags.split(",")) < 7 else [int(x) for x in a.flags.split(",")]
+if len(a.flags.split(",")) == 5:
+    hrew, mag = 1, 0
 
 elf = a.elf
 if not elf:
@@ -42,7 +44,7 @@ if not elf:
                     f"--output={elf}"], check=True)
 
 # the instantiation's symbol
-want = f"step_kernelILi{a.kind}EfdLi64ELi{traj}ELb{adapt}ELi{policy}ELb{single}ELb{helpw}ELb1EE"   # (..., HREW = true)
+want = f"step_kernelILi{a.kind}EfdLi64ELi{traj}ELb{adapt}ELi{policy}ELb{single}ELb{helpw}ELb{hrew}ELb{mag}EE"
 syms = subprocess.run([f"{LLVM}/llvm-objdump", "-t", elf], capture_output=True, text=True, check=True).stdout
 sym = None
 for l in syms.splitlines():

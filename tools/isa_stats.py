@@ -77,8 +77,8 @@ for f in re.split(r'\n(?=_ZN2qr11step_kernel\S*:)', txt):
     body = f.split('.Lfunc_end')[0]
     lines = body.splitlines()
     insts = [l for l in lines if is_inst(l)]
-    tag = re.search(r'ILi(\d)E(\w)(\w)Li64EL[bi](\d)ELb(\d)ELi(\d)ELb(\d)ELb(\d)E', m.group(1))
-    name = "kind=%s %s%s TRAJ=%s ADAPT=%s POLICY=%s SINGLE=%s HELP=%s" % tag.groups() if tag else m.group(1)
+    tag = re.search(r'ILi(\d)E(\w)(\w)Li64EL[bi](\d)ELb(\d)ELi(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)E', m.group(1))
+    name = "kind=%s %s%s TRAJ=%s ADAPT=%s POLICY=%s SINGLE=%s HELP=%s HREW=%s MAG=%s" % tag.groups() if tag else m.group(1)
     print(name, '| insts', len(insts), 'writelane', body.count('v_writelane'), 'readlane', body.count('v_readlane'),
           'scratch', body.count('scratch_'), 'vload', len(re.findall(r'(buffer|global)_load', body)),
           'vstore', len(re.findall(r'(buffer|global)_store', body)), 'waitcnt_vm', len(re.findall(r's_waitcnt.*vmcnt', body)))
