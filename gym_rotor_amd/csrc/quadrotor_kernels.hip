@@ -161,6 +161,9 @@ static int g_span_slot = -1;
 #ifndef QR_PRIO_SUBSTEPS
 #define QR_PRIO_SUBSTEPS 2
 #endif
+#ifndef QR_HELPER_GRID_WRAP_SUBSTEPS
+#define QR_HELPER_GRID_WRAP_SUBSTEPS 1664  // the wrappers' one-step helper-wave launches with two or more substeps: up to this many tiles (wants_helper)
+#endif
 #ifndef QR_PRIO_SINGLE_TILES
 #define QR_PRIO_SINGLE_TILES 768
 #endif
@@ -208,7 +211,7 @@ static int g_span_slot = -1;
 // from cache (r03/ab_helper_thresholds.txt, 8 slabs: 14.9 against 15.7 us), behind it beyond 131 072 envs when they stream from HBM (r03/ab_helper_wave.txt, 64 slabs:
 // 131 072 envs 9.4 against 9.1 us, 262 144 envs 18.4 against 16.5 — three stepping waves per SIMD hide less latency than four).  Round 5, with the rows on
 // the stepping wave beyond QR_HELP_ROWS_TILES: ahead up to 163 840 envs with either action source (10.2-10.4 against 10.5-10.7), mixed at 196 608: 2560 tiles
-// (one substep; 2048 with more and with the fused goal generator)
+// (one substep; 1664 with more: QR_HELPER_GRID_WRAP_SUBSTEPS; 2048 with the fused goal generator)
 #endif
 // ------------------------------------------------------------------------------------
 // Quad-v0 reward and termination (quad.py:274-318) from the post-step state
@@ -1598,7 +1601,10 @@ static inline bool wants_helper(const Args& a, int kind, int layout, unsigned ti
   // 2.97 us per env-step plain, Coupled 5.06 against 3.74)
   const Tuning& tn = tuning();
   const unsigned quad_limit = a.substeps <= 1 || tn.helper_grid < (unsigned)QR_HELPER_GRID_SUBSTEPS ? tn.helper_grid : (unsigned)QR_HELPER_GRID_SUBSTEPS;
-  const unsigned wrap_limit = a.substeps <= 1 || tn.helper_grid_wrap < 2048u ? tn.helper_grid_wrap : 2048u;  // (2560 measured with one substep only)
+  // (2560 measured with one substep only.  Several substeps — since round 6 the Magnus substep — re-measured, profiles/r06/
+  //  ab_magnus_helper_sweep.txt: the wrappers' helper launch is ahead up to 1664 tiles (x 2 / x 4: -6...7 %), level at 1792, behind
+  //  from 1920 on (2048 tiles: +5...15 %); Quad-v0 keeps QR_HELPER_GRID_SUBSTEPS = 2560.)
+  const unsigned wrap_limit = a.substeps <= 1 || tn.helper_grid_wrap < (unsigned)QR_HELPER_GRID_WRAP_SUBSTEPS ? tn.helper_grid_wrap : (unsigned)QR_HELPER_GRID_WRAP_SUBSTEPS;
   const unsigned limit = a.n_steps > 1 ? tn.helper_grid_rollout : (kind == QR_KIND_QUAD ? quad_limit : wrap_limit);
   return layout == QR_LAYOUT_MIXED && a.act_out == nullptr && a.goal_mode == QR_GOAL_EXTERNAL && !wants_adapt(a) &&
          (a.flags & QR_FLAG_AUTO_RESET) && helper_choice(a, tiles, limit);
@@ -1607,9 +1613,10 @@ static inline bool wants_helper(const Args& a, int kind, int layout, unsigned ti
 static inline bool wants_helper_traj(const Args& a, int kind) {  // the same with the fused goal generator (one-step launches)
   const unsigned tiles = (unsigned)((a.n + 63) / 64);
   const Tuning& tn = tuning();
+  const unsigned wrap_traj = a.substeps <= 1 ? 2048u : (unsigned)QR_HELPER_GRID_WRAP_SUBSTEPS;
   return a.act_out == nullptr && a.goal_mode != QR_GOAL_EXTERNAL && a.goal_mode < QR_GOAL_MODE2 && !wants_adapt(a) && (a.flags & QR_FLAG_AUTO_RESET) &&
          helper_choice(a, tiles, kind == QR_KIND_QUAD ? (tn.helper_grid < (unsigned)QR_HELPER_GRID_SUBSTEPS ? tn.helper_grid : (unsigned)QR_HELPER_GRID_SUBSTEPS)
-                                                      : (tn.helper_grid_wrap < 2048u ? tn.helper_grid_wrap : 2048u));
+                                                      : (tn.helper_grid_wrap < wrap_traj ? tn.helper_grid_wrap : wrap_traj));
 }
 
 // qr_rollout_actor beyond the grid on which a stepping AND a helper wave per tile are all resident: instead of the plain

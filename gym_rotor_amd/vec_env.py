@@ -850,7 +850,9 @@ class QuadVecEnv:
         thr = _lib.launch_thresholds()
         if self.kind == "quad":
             return thr["step_quad"] if (self.substeps <= 1 and self.goal_mode is None) else min(thr["step_quad"], 2560)
-        return thr["step_wrappers"] if (self.substeps <= 1 and self.goal_mode is None) else min(thr["step_wrappers"], 2048)
+        if self.substeps > 1:
+            return min(thr["step_wrappers"], 1664)
+        return thr["step_wrappers"] if self.goal_mode is None else min(thr["step_wrappers"], 2048)
 
     def _autotune_from_cache(self, time_if_absent: bool = False):
         """The default path of the constructor: nothing unless the grid is near the rule's threshold; then the choice RECORDED for

@@ -353,7 +353,7 @@ void qr_default_coeffs(QrCoeffs* c);
 int  qr_abi_version(void);
 /* What the launcher would run for this env — host-side, no device work; nothing in the reference (profilers, autotuners, tests).
  * qr_step / qr_rollout (actor = 0) or qr_rollout_actor (actor = 1: PPO / TD3-form actors, 2: the general form with SAC's
- * log_std head) over n_steps env-steps of `substeps` RK4 substeps: `launches` launches of `grid` workgroups (64-env tiles)
+ * log_std head) over n_steps env-steps of `substeps` substeps: `launches` launches of `grid` workgroups (64-env tiles)
  * of `block` threads — 64 = one wavefront per tile, 128 = plus a helper wavefront (QR_FLAG_AUTO_RESET, default layout, grids
  * in the launch-latency regime; launches > 1: qr_rollout_actor in chunks of `grid` resident tiles) — of the instantiation
  * `name` = qr::step_kernel<KIND, XV, QW, 64, TRAJ, ADAPT, POLICY, SINGLE, HELP, HREW, MAG> with the values filled in (the prefix of

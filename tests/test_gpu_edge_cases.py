@@ -572,3 +572,34 @@ def test_rollout_helper_launch_equals_the_plain_one_and_the_steps(kind):
         for e in envs[1:]:
             if getattr(envs[0], name) is not None:            # (Quad-v0 has no integrator words)
                 assert torch.equal(getattr(envs[0], name), getattr(e, name)), name
+
+
+@pytest.mark.parametrize("kind,substeps", [("quad", 2), ("decoupled", 4), ("coupled", 64)])
+def test_magnus_substeps_outside_the_regime_and_with_many_substeps(kind, substeps):
+    """The Magnus substep (two or more substeps, default layout) stepped on BEYOND termination under the caller's reset promise —
+    body rates to 25 rad/s, where the Taylor polynomial for W1, W2 over the env-step has its largest argument (|a| dt ~ 0.07) —
+    and with a substep count far above anything benchmarked: 20 steps against the float64 DOP853 oracle, every step."""
+    n, T = 512, 20
+    rng = np.random.default_rng(77)
+    A = orc.ACTION_DIM[kind]
+    env = _env(kind, n, layout="mixed", substeps=substeps, use_UDM=True, obs_rows=True, reset_on_done=True)
+    plan = env.launch_plan()
+    assert plan["mag"] == 1 and plan["adapt"] == 0
+    state = orc.sample_reset_state(rng, n)
+    state[:, 15:18] = rng.uniform(-25.0, 25.0, (n, 3))          # far beyond W_lim = 2 pi
+    state = state.astype(np.float32).astype(np.float64)
+    params = orc.sample_params(rng, n).astype(np.float32).astype(np.float64)
+    integ = np.zeros((n, 8))
+    env.set_state(state, integ=integ, params=params)
+    s, it = _np(env.get_current_state()), integ
+    worst = 0.0
+    for t in range(T):
+        act = rng.uniform(-1, 1, (n, A)).astype(np.float32)
+        env.step(torch.from_numpy(act).cuda())
+        o = orc.step_batch(kind, s, act.astype(np.float64), params, None, it)
+        s, it = o["state"], o["integ"]
+        got = _np(env.get_current_state())
+        assert np.isfinite(got).all()
+        worst = max(worst, grouped_rel_err(got, s))
+    print(f"Magnus x{substeps} {kind}, |W| to {np.abs(s[:, 15:18]).max():.0f} rad/s, 20 steps beyond termination: {worst:.2e}")
+    assert worst <= 3e-6

@@ -309,6 +309,7 @@ def test_launch_plan_names_the_instantiation_without_gpu():
     # substeps move the thresholds (3328 -> 2560 tiles for Quad-v0, 2560 -> 2048 for the wrappers) and keep the reward on the helper wave
     assert plan(0, 64 * 3000, AR).help == 1 and plan(0, 64 * 3000, AR, substeps=2).help == 0
     assert plan(1, 64 * 2300, AR).help == 1 and plan(1, 64 * 2300, AR, substeps=4).help == 0
+    assert plan(1, 64 * 1664, AR, substeps=4).help == 1 and plan(2, 64 * 1700, AR, substeps=2).help == 0   # (re-measured with the Magnus substep)
     assert plan(0, 64 * 1500, AR).hrew == 0 and plan(0, 64 * 1500, AR, substeps=10).hrew == 1 and plan(0, 64 * 1400, AR).hrew == 1
     assert plan(2, 64 * 1700, AR).hrew == 0 and plan(2, 64 * 1600, AR).hrew == 1
     # two or more substeps in the default layout: the Magnus-substep twin (MAG = 1) of the same instantiation — whatever the launch family,

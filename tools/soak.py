@@ -1,16 +1,19 @@
 #!/usr/bin/env python3
 """Soak run on the GPU box: many env-steps of the helper-wave launches (step, rollout, policy rollout) with in-launch resets,
 invariants checked as it goes — finite state, unit attitude, rewards in {-1} u [0, 1], the tile counters advancing by exactly
-one per env-step, episode counters equal to the number of terminations seen.   usage: soak.py [steps per kind]"""
+one per env-step, episode counters equal to the number of terminations seen.   usage: soak.py [steps per kind] [substeps]
+(substeps >= 2: the Magnus-substep instantiations)"""
 import os, sys, json, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gym_rotor_amd import QuadVecEnv, random_actors
 dev = torch.device("cuda", 0)
 total = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+SUB = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 K = 100
 res = {}
 for kind, n in (("quad", 65536), ("coupled", 65536), ("decoupled", 32768)):
-    env = QuadVecEnv(kind, n, device=dev, auto_reset=True, obs_rows=True, seed=5)
+    env = QuadVecEnv(kind, n, device=dev, auto_reset=True, obs_rows=True, seed=5, substeps=SUB)
+    assert env.launch_plan()["mag"] == int(SUB >= 2)
     assert env.kernel_info()[2] == 128
     env.reset("train")
     if kind != "quad":
@@ -56,7 +59,7 @@ for kind, n in (("quad", 65536), ("coupled", 65536), ("decoupled", 32768)):
 gsteps = max(200, total // 10)
 for gm in range(7):
     n = 16384
-    env = QuadVecEnv("decoupled", n, device=dev, auto_reset=True, goal_mode=gm, max_episode_steps=700, seed=9)
+    env = QuadVecEnv("decoupled", n, device=dev, auto_reset=True, goal_mode=gm, max_episode_steps=700, seed=9, substeps=SUB)
     env.reset("train")
     env.get_desired(store_goal=True)
     env.get_norm_error_state()
