@@ -33,7 +33,9 @@ time, `roofline.achieved` = SURVEY.md 8(d) algorithmic bytes per launch / (that 
 same number again as `roofline.avg_launch_us`).  The host wall clock of the same repetitions
 (which adds the graph submission and the synchronize round trip, ~20 us per repetition whatever
 K is) is reported beside it as `wall_ms_per_step`; `--steps 20` and `--steps 1000` therefore
-agree.  `roofline.traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed under
+agree.  The default 1-GPU run then replays the headline graph back to back for --sustain seconds
+(3) without synchronising in between: `config.sustained_us` / `sustained_steps`, the rate under sustained load.
+`roofline.traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed under
 profiles/ (tools/profile.sh), when one exists for this configuration.
 
 Secondary figures (rank 0, --extras 1), all through the same harness as the headline and all FLAT scalars under `config` (the
@@ -98,7 +100,7 @@ OTHER_ROWS = [
 
 def secondary_keys():
     """The flat `config` keys a full default run adds beside the headline (tests pin them; DESIGN.md 5 explains each)."""
-    keys = ["free_run_us"]
+    keys = ["sustained_us", "sustained_steps", "free_run_us"]
     for spec in BASELINE_CONFIGS + OTHER_ROWS:
         tag = spec["tag"]
         if spec["workload"] == "step":
@@ -130,6 +132,7 @@ def parse():
     p.add_argument("--action-batches", type=int, default=64, help="distinct pre-generated [N,A] action slabs cycled through (64 x 1 MiB > L2: every step streams its actions)")
     p.add_argument("--extras", type=int, default=1, help="0: only the headline measurement (used under rocprofv3); 1: + config.other_reset_mode and "
                                                          "config.baseline_configs within --extras-budget; 2: all of them whatever they take")
+    p.add_argument("--sustain", type=float, default=3.0, help="seconds of back-to-back replays of the headline graph after the timed repetitions (config.sustained_us; 0 = skip; 1-GPU default run only)")
     p.add_argument("--extras-budget", type=float, default=60.0, help="seconds after which the remaining secondary rows are skipped (--extras 1)")
     p.add_argument("--actor", default="ppo", choices=["ppo", "sac"], help="--workload rollout_actor: the actor form (ppo: parameter log_std, "
                                                                             "tanh-of-mean rule; sac: state-dependent log_std head, tanh-of-sample rule = the POLICY=2 kernel)")
@@ -356,10 +359,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def run(w, ar: bool, timed: bool):
+    def run(w, ar: bool, timed: bool, sustain_s: float = 0.0):
         """`w` = the workload (kind, envs, env_offset, substeps, workload, horizon, steps, slabs, helper, actor).  W warm-up
         steps, then repetitions of exactly K = w.steps timed env-steps; returns the per-repetition (HIP-event ms, wall ms) lists
-        and a few facts about the final state.  timed=False: no cross-rank barrier (rank-0-only secondary measurements)."""
+        and a few facts about the final state.  timed=False: no cross-rank barrier (rank-0-only secondary measurements).
+        sustain_s > 0 (graph mode, in-launch resets): afterwards the timed graph is replayed back to back for about that many seconds
+        with NO synchronisation in between — the rate the chip holds under sustained load (its clocks under power, not a 4 ms burst)."""
         H, K, n = w.horizon, w.steps, w.envs
         env = QuadVecEnv(w.kind, n, device=dev, seed=0, substeps=w.substeps, layout=getattr(w, "layout", a.layout), use_UDM=True,
                          auto_reset=ar, env_offset=w.env_offset, **{"helper" if w.workload in ("step", "touch") else "helper_rollout": TRI[w.helper]},
@@ -461,6 +466,19 @@ def main():
                 stop = bool(flag.item())
             if stop:
                 break
+        sustained = None
+        if sustain_s > 0 and graph is not None and ar:
+            per_replay_ms = float(np.median(dev_ms)) * copies
+            n_rep = max(1, int(sustain_s * 1e3 / per_replay_ms))
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            issue_lead()
+            ev0.record()
+            for _ in range(n_rep):
+                graph.replay()
+            ev1.record()
+            torch.cuda.synchronize(dev)
+            sustained = (ev0.elapsed_time(ev1) / (n_rep * copies), n_rep * copies * K)   # (ms per K steps, env-steps per env in the window)
         finite = bool(torch.isfinite(env.get_current_state()).all())
         done_rate = float(last_done().float().mean())
         tuned = env.autotune_report   # None unless a recorded choice of the launch cache applies (grids near a threshold of the launch rule)
@@ -468,12 +486,13 @@ def main():
         plan = env.launch_plan(H, actor=(w.actor if w.workload == "rollout_actor" else None))   # the launcher's own decision, this env's substeps
         if w.workload == "touch":
             plan = dict(plan, name=f"qr::touch_kernel<{_lib.KIND_ID[w.kind]},...>", block=64, launches=1)
-        return dev_ms, wall_ms, finite, done_rate, (plan, launch_rule), n_lead * H, copies
+        return dev_ms, wall_ms, finite, done_rate, (plan, launch_rule), n_lead * H, copies, sustained
 
     from types import SimpleNamespace as NS
     head = NS(kind=a.kind, envs=N, env_offset=env_offset, substeps=a.substeps, workload=a.workload, horizon=a.horizon, steps=a.steps,
               slabs=a.action_batches, helper=a.helper, actor=a.actor, layout=a.layout)
-    dev_ms, wall_ms, finite, done_rate, kinfo, n_lead, copies = run(head, auto_reset, True)
+    sustain_s = a.sustain if (world == 1 and a.extras and a.workload == "step") else 0.0
+    dev_ms, wall_ms, finite, done_rate, kinfo, n_lead, copies, sustained = run(head, auto_reset, True, sustain_s)
     reps = len(dev_ms)
     med_dev, med_wall = float(np.median(dev_ms)), float(np.median(wall_ms))
     tmax = torch.tensor([med_dev, med_wall], dtype=torch.float64, device=dev if on_dev else "cpu")
@@ -542,6 +561,8 @@ def main():
             def touch_of(w):   # the do-nothing kernel over the same configuration
                 return NS(**{**vars(w), "workload": "touch", "horizon": 1, "steps": 300})
 
+            if sustained is not None:   # the headline launch replayed back to back for ~a.sustain seconds, no synchronisation in between
+                cfg["sustained_us"], cfg["sustained_steps"] = round(sustained[0] * 1e3 / a.steps * H, 4), int(sustained[1])
             noop = us_per_launch(touch_of(head))
             out["roofline"]["noop_kernel_us"] = round(noop, 4)
             out["roofline"]["frac_of_noop_kernel"] = round(noop / launch_us, 4)

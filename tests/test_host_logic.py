@@ -533,7 +533,7 @@ def test_bench_presets_and_scaling_flags_without_gpu(monkeypatch):
         ("quad", 65536, "step", "f64"), ("coupled", 65536, "step", "f64"), ("quad", 1048576, "step", "f64"),
         ("coupled", 65536, "rollout", None), ("decoupled", 65536, "rollout_actor", None), ("coupled", 262144, "rollout_actor", None)]
     keys = bench.secondary_keys()
-    for k in ("free_run_us", "c2_coupled65536_us", "c2_coupled65536_frac", "c3_share32768_us", "c3_share32768_frac", "c3_262144_us", "c3_262144_frac",
+    for k in ("sustained_us", "free_run_us", "c2_coupled65536_us", "c2_coupled65536_frac", "c3_share32768_us", "c3_share32768_frac", "c3_262144_us", "c3_262144_frac",
               "c4_share131072x10_us", "c4_share131072x10_frac", "c4_1Mx10_us", "c4_1Mx10_frac", "quad1Mx1_us", "quad1Mx1_frac", "quad1Mx1_noop_us",
               "rollout_T100_us_per_env_step", "ppo_collect_T32_us_per_env_step", "f64_quad65536_us", "f64_quad1Mx1_us", "f64_coupled65536_us"):
         assert k in keys, k
@@ -545,7 +545,7 @@ def test_bench_presets_and_scaling_flags_without_gpu(monkeypatch):
     assert abs(bench.algo_bytes_per_env_step("quad", "rollout", 100) - (21 + 168 / 100)) < 1e-12
     assert abs(bench.algo_bytes_per_env_step("coupled", "rollout_actor", 32) - (129 + 232 / 32)) < 1e-12
     a = parse()
-    assert a.extras == 1 and a.extras_budget > 0 and a.actor == "ppo" and parse("--actor", "sac").actor == "sac"
+    assert a.extras == 1 and a.extras_budget > 0 and a.actor == "ppo" and parse("--actor", "sac").actor == "sac" and 0 < a.sustain <= 10
 
 
 def test_bench_gpus_n_spawns_its_own_ranks_without_gpu(monkeypatch):
