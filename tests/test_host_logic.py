@@ -224,16 +224,16 @@ def test_abi_argument_errors_under_sanitizers(tmp_path):
     env = dict(os.environ, QR_LIB=str(out), LD_PRELOAD=rt[0], ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", PYTHONPATH=ROOT,
                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_host_logic.py"),
-                        "-k", "test_abi_argument_errors_without_gpu or test_launch_geometry_rule_without_gpu or test_library_exports"],
+                        "-k", "test_abi_argument_errors_without_gpu or test_launch_geometry_rule_without_gpu or test_library_exports or test_launch_plan_names"],
                        env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
-    assert "3 passed" in r.stdout and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+    assert "4 passed" in r.stdout and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
 
 
 def test_launch_geometry_rule_without_gpu():
     """qr_step_kernel_info (host-only) reports the launch the step launcher would use: one 64-lane wavefront per 64-env
     tile, plus a helper wavefront (128 threads per workgroup) exactly for: in-launch auto-reset, default layout, no rate
-    adaptivity in reach, and grids of <= 3328 tiles (Quad-v0, one substep; 2560 with more) / <= 2560 (wrappers; 2048 with more substeps) / <= 1024 (rollouts); with the fused
+    adaptivity in reach, and grids of <= 3328 tiles (Quad-v0, one substep; 2560 with more) / <= 2560 (wrappers; 1664 with more substeps) / <= 1024 (rollouts); with the fused
     goal generator only for one-step launches."""
     L = _lib()
     lib = L.load()
